@@ -1,0 +1,177 @@
+/*
+ * adcensus_c_api.h -- C ABI of the MI355X-native AD-Census stereo matcher.
+ *
+ * This is the drop-in boundary underneath the C++ facade `ADCensusStereo`
+ * (include/ADCensusStereo.h).  Everything crossing it is plain C: pointers, sizes, PODs.
+ * No torch / HIP types appear in any signature (a stream is passed as an opaque void*).
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths are relative to the reference checkout, AD-Census/...):
+ *
+ *   adc_option            <- struct ADCensusOption            adcensus_types.h:45-75
+ *   adc_create            <- ADCensusStereo::Initialize        ADCensusStereo.cpp:21-67
+ *   adc_match             <- ADCensusStereo::Match             ADCensusStereo.cpp:69-132
+ *   adc_destroy           <- ~ADCensusStereo / Release         ADCensusStereo.cpp:15-19,312-316
+ *   (Reset == adc_destroy + adc_create                         ADCensusStereo.cpp:134-144)
+ *
+ * Additive entry points (no reference counterpart; they do not change Match semantics):
+ *   adc_match_device      device-resident in/out buffers (bench: inputs already in HBM)
+ *   adc_match_async/wait  several objects in flight from one host thread
+ *   adc_get_stage_ms      HIP-event stage timers (the reference printf()s stage times,
+ *                         ADCensusStereo.cpp:81-129)
+ *   adc_debug_*           per-stage entry points used ONLY by the parity tests
+ *
+ * Image format (cost_computor.cpp:66-68, main.cpp:65-76): tightly packed row-major
+ * uint8[H][W][3], channel order B,G,R.  Output: float32[H][W] left-view disparity.
+ */
+#ifndef ADCENSUS_C_API_H_
+#define ADCENSUS_C_API_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Plain-C mirror of ADCensusOption (adcensus_types.h:45-75); same fields, same order,
+ * same defaults (adc_option_default).  bools are uint8_t. */
+typedef struct adc_option {
+    int32_t min_disparity;               /* default 0   */
+    int32_t max_disparity;               /* default 64  */
+    int32_t lambda_ad;                   /* default 10  */
+    int32_t lambda_census;               /* default 30  */
+    int32_t cross_L1;                    /* default 34  */
+    int32_t cross_L2;                    /* default 17  */
+    int32_t cross_t1;                    /* default 20  */
+    int32_t cross_t2;                    /* default 6   */
+    float   so_p1;                       /* default 1.0 */
+    float   so_p2;                       /* default 3.0 */
+    int32_t so_tso;                      /* default 15  */
+    int32_t irv_ts;                      /* default 20  */
+    float   irv_th;                      /* default 0.4 */
+    float   lrcheck_thres;               /* default 1.0 */
+    uint8_t do_lr_check;                 /* default 1   */
+    uint8_t do_filling;                  /* default 1   */
+    uint8_t do_discontinuity_adjustment; /* default 0   */
+    uint8_t reserved_;
+} adc_option;
+
+typedef struct adc_handle adc_handle;
+
+/* Fills *opt with the reference defaults (adcensus_types.h:67-74). */
+void adc_option_default(adc_option* opt);
+
+/* Library / device info. Returns number of visible HIP devices (<=0: none / error). */
+int adc_device_count(void);
+const char* adc_version(void);
+/* Last error text of the calling thread ("" if none). */
+const char* adc_last_error(void);
+
+/*
+ * Initialize.  Returns NULL when the reference's Initialize returns false
+ * (width<=0 || height<=0, ADCensusStereo.cpp:31-33; max_disparity-min_disparity<=0, :38-40),
+ * on a HIP failure, or when the disparity range exceeds ADC_MAX_DISP_RANGE.
+ * device < 0 means "current device".  All device scratch is allocated here, once.
+ */
+#define ADC_MAX_DISP_RANGE 256
+adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int device);
+void adc_destroy(adc_handle* h);
+
+/*
+ * Match (synchronous).  Host pointers.  0 = ok; nonzero = the reference's `false`
+ * (any pointer NULL, ADCensusStereo.cpp:74-76) or a HIP error.
+ * Does H2D (2 x 3*W*H bytes), the kernels, D2H (4*W*H bytes) on the handle's stream.
+ */
+int adc_match(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left);
+
+/* Same pipeline, device-resident buffers (already in HBM); asynchronous on the handle's
+ * stream; call adc_wait() before reading d_disp_left. */
+int adc_match_device(adc_handle* h, const void* d_bgr_left, const void* d_bgr_right, void* d_disp_left);
+
+/* Host buffers, asynchronous (pinned staging inside the handle); adc_wait() completes it and
+ * copies the result to disp_left given here. */
+int adc_match_async(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left);
+int adc_wait(adc_handle* h);
+
+/* Stage timers (ms, HIP events on the handle's stream) of the most recent completed match.
+ * Enable with adc_set_profiling(h,1).  Order: see adc_stage_name(). */
+enum {
+    ADC_STAGE_COST = 0,       /* gray + census + AD-census cost volume   (cost_computor.cpp)      */
+    ADC_STAGE_ARMS,           /* cross arms + support counts             (cross_aggregator.cpp:76-86,271-325) */
+    ADC_STAGE_AGGREGATE,      /* 4 iterations x (H,V) passes             (cross_aggregator.cpp:89-118) */
+    ADC_STAGE_SCANLINE,       /* 4 chained DP passes                     (scanline_optimizer.cpp:40-61) */
+    ADC_STAGE_WTA,            /* left + right WTA / sub-pixel            (ADCensusStereo.cpp:188-310) */
+    ADC_STAGE_REFINE,         /* LR check, region voting, interpolation, [DDA], median (multistep_refiner.cpp:60-87) */
+    ADC_STAGE_COUNT
+};
+const char* adc_stage_name(int stage);
+void adc_set_profiling(adc_handle* h, int on);
+int adc_get_stage_ms(adc_handle* h, float* ms, int n);
+/* Per-kernel-launch average of the aggregation pass kernel over the last match (ms), and the
+ * number of launches it averaged (8 for 4 iterations). */
+int adc_get_aggregate_pass_ms(adc_handle* h, float* avg_ms, int* launches);
+
+/* Print the reference's six timing lines from Match (ADCensusStereo.cpp:88-129); default off. */
+void adc_set_verbose(adc_handle* h, int on);
+
+/* Plumbing for callers that own device memory / streams elsewhere (e.g. torch). */
+void* adc_get_stream(adc_handle* h);                 /* hipStream_t as void* */
+int   adc_device_synchronize(void);
+void* adc_device_malloc(size_t bytes);
+void  adc_device_free(void* p);
+int   adc_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int   adc_memcpy_d2h(void* dst, const void* src, size_t bytes);
+
+/* -------------------------------------------------------------------------------------------
+ * Test-only debug surface (parity tests drive single stages with oracle-provided inputs).
+ * Volumes cross this boundary in the REFERENCE layout [H][W][D] float32 (D = max-min disparity);
+ * the padded internal layout is private.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    ADC_BUF_GRAY_LEFT = 0,    /* u8  [H][W]                                                    */
+    ADC_BUF_GRAY_RIGHT,       /* u8  [H][W]                                                    */
+    ADC_BUF_CENSUS_LEFT,      /* u64 [H][W]                                                    */
+    ADC_BUF_CENSUS_RIGHT,     /* u64 [H][W]                                                    */
+    ADC_BUF_ARMS,             /* u8  [H][W][4] = left,right,top,bottom (CrossArm, cross_aggregator.h:17-20) */
+    ADC_BUF_SUPCOUNT_H,       /* u16 [H][W]  horizontal-first support count (vec_sup_count_[0]) */
+    ADC_BUF_SUPCOUNT_V,       /* u16 [H][W]  vertical-first support count   (vec_sup_count_[1]) */
+    ADC_BUF_VOLUME_A,         /* f32 [H][W][D]  the volume holding the latest stage result      */
+    ADC_BUF_DISP_LEFT,        /* f32 [H][W]  current left disparity map                         */
+    ADC_BUF_DISP_RIGHT,       /* f32 [H][W]                                                     */
+    ADC_BUF_OUTLIER_LABEL,    /* u8  [H][W]  0 valid, 1 mismatch, 2 occlusion                   */
+    ADC_BUF_COUNT
+};
+/* Copies a device buffer to host (de-padding volumes). dst must hold the full buffer. */
+int adc_debug_read(adc_handle* h, int which, void* dst);
+/* Overwrites a device buffer from host (padding volumes). */
+int adc_debug_write(adc_handle* h, int which, const void* src);
+/* Uploads the image pair without running anything. */
+int adc_debug_set_images(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right);
+
+enum {
+    ADC_RUN_GRAY_CENSUS = 0,  /* images -> gray, census                                        */
+    ADC_RUN_COST,             /* images, census -> VOLUME_A                                    */
+    ADC_RUN_ARMS,             /* left image -> arms, support counts                            */
+    ADC_RUN_AGGREGATE,        /* VOLUME_A, arms, counts -> VOLUME_A (4 iterations)             */
+    ADC_RUN_SCANLINE,         /* VOLUME_A, images -> VOLUME_A (4 passes)                       */
+    ADC_RUN_WTA,              /* VOLUME_A -> DISP_LEFT, DISP_RIGHT                             */
+    ADC_RUN_LRCHECK,          /* DISP_LEFT, DISP_RIGHT -> DISP_LEFT, OUTLIER_LABEL             */
+    ADC_RUN_REGION_VOTING,    /* DISP_LEFT, OUTLIER_LABEL, arms -> DISP_LEFT                   */
+    ADC_RUN_INTERPOLATION,    /* DISP_LEFT, OUTLIER_LABEL, left image -> DISP_LEFT             */
+    ADC_RUN_DISCONTINUITY,    /* DISP_LEFT, VOLUME_A -> DISP_LEFT                              */
+    ADC_RUN_MEDIAN,           /* DISP_LEFT -> DISP_LEFT (in-place semantics)                   */
+    ADC_RUN_COUNT
+};
+/* Runs ONE stage on the handle's current device buffers and synchronizes. `arg` is stage
+ * specific (ADC_RUN_AGGREGATE: number of iterations, 0 -> 4; ADC_RUN_SCANLINE: number of
+ * chained passes 1..4, 0 -> 4; else ignored). */
+int adc_debug_run(adc_handle* h, int stage, int arg);
+/* Statistics of the last region-voting run: total fixed-point rounds over the 10 passes and
+ * total vote evaluations. */
+int adc_debug_voting_stats(adc_handle* h, int64_t* rounds, int64_t* evaluations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADCENSUS_C_API_H_ */
