@@ -1,0 +1,114 @@
+// adc_device_fn.h -- per-element arithmetic shared by the HIP kernels (and, for unit checks of the
+// order-aware parallel formulations, by a g++-compiled CPU emulation under tests/emul/).
+//
+// Everything here is exact integer / IEEE-754 arithmetic that must reproduce the reference CPU
+// program bit for bit.  Rules: no FMA contraction (files are compiled with
+// -ffp-contract=off and carry the pragma below), no fast-math, no approximate reciprocals,
+// transcendental values only through host-built tables.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ADC_HD __host__ __device__ __forceinline__
+#else
+#define ADC_HD inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+#define ADC_LARGE_FLOAT 99999.0f        // Large_Float,   adcensus_types.h:35
+#define ADC_INVALID_FLOAT __builtin_inff() // Invalid_Float, adcensus_types.h:33
+
+#define ADC_LABEL_VALID 0
+#define ADC_LABEL_MISMATCH 1
+#define ADC_LABEL_OCCLUSION 2
+
+ADC_HD int adc_iabs(int a) { return a < 0 ? -a : a; }
+ADC_HD int adc_imax(int a, int b) { return a > b ? a : b; }
+ADC_HD int adc_imin(int a, int b) { return a < b ? a : b; }
+
+// gray = uint8(r*0.299 + g*0.587 + b*0.114), operands in double, left to right, truncation
+// (cost_computor.cpp:66-69).  Unfused: 3 mul + 2 add.
+ADC_HD uint8_t adc_gray(uint8_t b, uint8_t g, uint8_t r)
+{
+    const double t0 = (double)r * 0.299;
+    const double t1 = (double)g * 0.587;
+    const double t2 = (double)b * 0.114;
+    const double s = (t0 + t1) + t2;
+    return (uint8_t)s;
+}
+
+// max-channel colour distance (cross_aggregator.h:78-80, scanline_optimizer.h:66-68). p -> B,G,R.
+ADC_HD int adc_color_dist_max(const uint8_t* a, const uint8_t* b)
+{
+    return adc_imax(adc_iabs((int)a[2] - (int)b[2]), adc_imax(adc_iabs((int)a[1] - (int)b[1]), adc_iabs((int)a[0] - (int)b[0])));
+}
+ADC_HD int adc_color_dist_max_u32(uint32_t a, uint32_t b) // packed 0x00RRGGBB
+{
+    const int d0 = adc_iabs((int)(a & 255u) - (int)(b & 255u));
+    const int d1 = adc_iabs((int)((a >> 8) & 255u) - (int)((b >> 8) & 255u));
+    const int d2 = adc_iabs((int)((a >> 16) & 255u) - (int)((b >> 16) & 255u));
+    return adc_imax(d2, adc_imax(d1, d0));
+}
+// L1 colour distance used by the interpolation (multistep_refiner.cpp:281).
+ADC_HD int adc_color_dist_l1(const uint8_t* a, const uint8_t* b)
+{
+    return adc_iabs((int)a[2] - (int)b[2]) + adc_iabs((int)a[1] - (int)b[1]) + adc_iabs((int)a[0] - (int)b[0]);
+}
+
+// ---- scanline optimiser: which right-image colour difference a disparity sees ----
+// The reference initialises d2 = d1 once per pixel and overwrites it only while 0 < xr < W-1
+// (scanline_optimizer.cpp:116-126, :225-235), xr = x - d - dmin descending in d, so out-of-interval
+// disparities inherit the last in-interval value ("sticky").  Closed form:
+//   xr in (0, W-1)                       -> own column xr
+//   xr <= 0 and the interval was entered -> column 1      (entered <=> x - dmin >= 1 and W >= 3)
+//   otherwise                            -> d1 (returns -1)
+// Returns the column of the right-image difference map to use, or -1 for "use d1".
+ADC_HD int adc_so_d2_column(int x, int dmin, int d, int W)
+{
+    const int xr = x - d - dmin;
+    if (xr > 0 && xr < W - 1) return xr;
+    if (xr <= 0 && (x - dmin) >= 1 && W >= 3) return 1; // interval was entered at d' = x-dmin-1 < d
+    return -1;
+}
+
+// penalty class: 0 -> (p1,p2), 1 -> (p1/4,p2/4), 2 -> (p1/10,p2/10)  (scanline_optimizer.cpp:129-141)
+ADC_HD int adc_so_penalty_class(int d1, int d2, int tso) { return (d1 >= tso ? 1 : 0) + (d2 >= tso ? 1 : 0); }
+
+// ---- WTA sub-pixel (ADCensusStereo.cpp:227-240) ----
+ADC_HD float adc_subpixel(int best, float c1, float c2, float cmin)
+{
+    const float denom = c1 + c2 - 2 * cmin;
+    if (denom != 0.0f) return (float)best + (c1 - c2) / (denom * 2.0f);
+    return (float)best;
+}
+
+// ---- region voting decision (multistep_refiner.cpp:199-214) ----
+// returns the filled disparity or +inf
+ADC_HD float adc_vote_decide(int best_bin, int max_ht, int count, int dmin, int irv_ts, float irv_th)
+{
+    if (max_ht > 0 && count > irv_ts && (float)max_ht * 1.0f / (float)count > irv_th) return (float)(best_bin + dmin);
+    return ADC_INVALID_FLOAT;
+}
+
+// ---- sorting network for the 3x3 median (adcensus_util.cpp:55-81): full sort of 9, select [n/2] ----
+ADC_HD void adc_cswap(float& a, float& b)
+{
+    const float lo = b < a ? b : a;
+    const float hi = b < a ? a : b;
+    a = lo;
+    b = hi;
+}
+// Sorts v[0..8] ascending (25 compare-exchanges, optimal-size network for n=9).
+ADC_HD void adc_sort9(float* v)
+{
+    adc_cswap(v[0], v[3]); adc_cswap(v[1], v[7]); adc_cswap(v[2], v[5]); adc_cswap(v[4], v[8]);
+    adc_cswap(v[0], v[7]); adc_cswap(v[2], v[4]); adc_cswap(v[3], v[8]); adc_cswap(v[5], v[6]);
+    adc_cswap(v[0], v[2]); adc_cswap(v[1], v[3]); adc_cswap(v[4], v[5]); adc_cswap(v[7], v[8]);
+    adc_cswap(v[1], v[4]); adc_cswap(v[3], v[6]); adc_cswap(v[5], v[7]);
+    adc_cswap(v[0], v[1]); adc_cswap(v[2], v[4]); adc_cswap(v[3], v[5]); adc_cswap(v[6], v[8]);
+    adc_cswap(v[2], v[3]); adc_cswap(v[4], v[5]); adc_cswap(v[6], v[7]);
+    adc_cswap(v[1], v[2]); adc_cswap(v[3], v[4]); adc_cswap(v[5], v[6]);
+}

@@ -1,0 +1,93 @@
+// adc_internal.h -- private state of an adc_handle and the kernel-launch entry points.
+//
+// HBM layout (all buffers allocated once in adc_create, 288 GB HBM3E is plentiful):
+//   img_l / img_r      u8  [H][W][3]  BGR, as handed over by the caller
+//   gray_l / gray_r    u8  [H][W]
+//   census_l/census_r  u64 [H][W]
+//   arms               u8x4[H][W]     left,right,top,bottom
+//   sup_h / sup_v      u16 [H][W]     support counts of the H-first / V-first iterations
+//   cdiff_*            u8  [H][W]     max-channel colour difference to the left / upper neighbour of
+//                                     the left (L) and right (R) image (scanline penalties)
+//   vol_a / vol_b      f32 [H][W][Dp] cost volumes (ping-pong).  d innermost, Dp = 64*VPL, VPL in
+//                                     {1,2,4}: lanes = disparities, lane l holds d = l*VPL .. l*VPL+VPL-1.
+//                                     d >= D are padding (never read by a reduction).
+//   disp_l / disp_r    f32 [H][W]
+//   label              u8  [H][W]     outlier class (0 valid, 1 mismatch, 2 occlusion)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/adcensus_c_api.h"
+
+#define ADC_WAVE 64
+
+struct AdcParams {
+    int W, H;
+    int dmin, dmax, D; // D = dmax - dmin
+    int VPL;           // disparities per lane (1,2,4)
+    int Dp;            // padded disparity count = 64*VPL
+    adc_option opt;
+};
+
+struct adc_handle {
+    AdcParams p;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+
+    // images + per-pixel maps
+    uint8_t *img_l, *img_r;
+    uint8_t *gray_l, *gray_r;
+    uint64_t *census_l, *census_r;
+    uint8_t* arms;
+    uint16_t *sup_h, *sup_v;
+    uint8_t *cdiff_lh, *cdiff_lv, *cdiff_rh, *cdiff_rv;
+    // volumes
+    float *vol_a, *vol_b;
+    // host-built tables: same libm as the CPU reference
+    float* lut_ad;      // [766] A[k] = (1 - expf(-(k/3.0f)/lambda_ad)) + 1
+    float* lut_census;  // [64]  C[h] = expf(-(float)h/lambda_census)
+    double* ray_sincos; // [16][2] (sin, cos) of the 16 interpolation angles
+    float so_P1[3], so_P2[3]; // penalty classes (p, p/4, p/10)
+    // disparity maps and refinement state
+    float *disp_l, *disp_r, *disp_tmp;
+    uint8_t* label;
+    uint8_t* elig;       // region voting: eligible mask of the current pass
+    int32_t* vote_list;  // compact list of eligible pixels
+    int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...
+    uint8_t *chg_a, *chg_b; // changed-tile maps (previous / next round)
+    uint8_t* edge;       // discontinuity adjustment edge mask
+    // pinned staging for adc_match / adc_match_async
+    uint8_t* pin_in;  // 2 * 3*W*H
+    float* pin_out;   // W*H
+    float* async_dst;
+    // profiling
+    int profiling, verbose;
+    hipEvent_t ev[ADC_STAGE_COUNT + 1];
+    hipEvent_t ev_agg[9];
+    float stage_ms[ADC_STAGE_COUNT];
+    float agg_pass_ms;
+    int agg_launches;
+    bool timings_pending;
+    // region voting statistics of the last run
+    int64_t vote_rounds, vote_evals;
+    // which volume holds the latest result (always vol_a at stage boundaries)
+};
+
+// ------------------------------------------------------------------ kernel launchers (one per stage)
+// All launch on h->stream, asynchronous, return hipError_t of the launch.
+hipError_t adc_launch_gray_census(adc_handle* h);
+hipError_t adc_launch_cost(adc_handle* h, float* vol_out);
+hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps
+hipError_t adc_launch_aggregate(adc_handle* h, int iterations); // vol_a -> vol_a via vol_b
+hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
+hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
+hipError_t adc_launch_lrcheck(adc_handle* h);
+hipError_t adc_run_region_voting(adc_handle* h); // contains host-side convergence checks
+hipError_t adc_launch_interpolation(adc_handle* h);
+hipError_t adc_launch_discontinuity(adc_handle* h);
+hipError_t adc_launch_median(adc_handle* h);
+// layout helpers for the debug surface
+hipError_t adc_launch_pad_volume(adc_handle* h, const float* src_HWD, float* dst_HWDp);
+hipError_t adc_launch_unpad_volume(adc_handle* h, const float* src_HWDp, float* dst_HWD);

@@ -1,0 +1,414 @@
+// capi.hip -- the C ABI of include/adcensus_c_api.h: object lifetime, the Match pipeline
+// (ADCensusStereo.cpp:69-132 stage order) and the test-only per-stage debug surface.
+// Host code only; kernels live in the k_*.hip files.
+#include "adc_internal.h"
+#include "adc_device_fn.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <new>
+
+static thread_local std::string g_last_error;
+
+static void set_error(const char* what, hipError_t e)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+#define HIP_OK(call)                          \
+    do {                                      \
+        hipError_t e__ = (call);              \
+        if (e__ != hipSuccess) {              \
+            set_error(#call, e__);            \
+            return e__;                       \
+        }                                     \
+    } while (0)
+
+extern "C" {
+
+void adc_option_default(adc_option* o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->min_disparity = 0;  o->max_disparity = 64; // adcensus_types.h:67-74
+    o->lambda_ad = 10;     o->lambda_census = 30;
+    o->cross_L1 = 34;      o->cross_L2 = 17;
+    o->cross_t1 = 20;      o->cross_t2 = 6;
+    o->so_p1 = 1.0f;       o->so_p2 = 3.0f;      o->so_tso = 15;
+    o->irv_ts = 20;        o->irv_th = 0.4f;
+    o->lrcheck_thres = 1.0f;
+    o->do_lr_check = 1;    o->do_filling = 1;    o->do_discontinuity_adjustment = 0;
+}
+
+int adc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+const char* adc_version(void) { return "adcensus-mi355x 0.1 (gfx950)"; }
+const char* adc_last_error(void) { return g_last_error.c_str(); }
+
+static hipError_t alloc_all(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    const size_t P = (size_t)p.W * p.H;
+    const size_t VB = P * p.Dp * sizeof(float);
+    HIP_OK(hipMalloc(&h->img_l, P * 3));
+    HIP_OK(hipMalloc(&h->img_r, P * 3));
+    HIP_OK(hipMalloc(&h->gray_l, P));
+    HIP_OK(hipMalloc(&h->gray_r, P));
+    HIP_OK(hipMalloc(&h->census_l, P * 8));
+    HIP_OK(hipMalloc(&h->census_r, P * 8));
+    HIP_OK(hipMalloc(&h->arms, P * 4));
+    HIP_OK(hipMalloc(&h->sup_h, P * 2));
+    HIP_OK(hipMalloc(&h->sup_v, P * 2));
+    HIP_OK(hipMalloc(&h->cdiff_lh, P));
+    HIP_OK(hipMalloc(&h->cdiff_lv, P));
+    HIP_OK(hipMalloc(&h->cdiff_rh, P));
+    HIP_OK(hipMalloc(&h->cdiff_rv, P));
+    HIP_OK(hipMalloc(&h->vol_a, VB));
+    HIP_OK(hipMalloc(&h->vol_b, VB));
+    HIP_OK(hipMalloc(&h->lut_ad, 768 * sizeof(float)));
+    HIP_OK(hipMalloc(&h->lut_census, 64 * sizeof(float)));
+    HIP_OK(hipMalloc(&h->ray_sincos, 32 * sizeof(double)));
+    HIP_OK(hipMalloc(&h->disp_l, P * 4));
+    HIP_OK(hipMalloc(&h->disp_r, P * 4));
+    HIP_OK(hipMalloc(&h->disp_tmp, P * 4));
+    HIP_OK(hipMalloc(&h->label, P));
+    HIP_OK(hipMalloc(&h->elig, P));
+    HIP_OK(hipMalloc(&h->vote_list, P * 4));
+    HIP_OK(hipMalloc(&h->vote_counters, 16 * sizeof(int32_t)));
+    const size_t tiles = (size_t)((p.W + 15) / 16) * ((p.H + 15) / 16);
+    HIP_OK(hipMalloc(&h->chg_a, tiles));
+    HIP_OK(hipMalloc(&h->chg_b, tiles));
+    HIP_OK(hipMalloc(&h->edge, P));
+    HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
+    HIP_OK(hipMemset(h->label, 0, P));
+    HIP_OK(hipMemset(h->chg_a, 0, tiles));
+    HIP_OK(hipMemset(h->chg_b, 0, tiles));
+    HIP_OK(hipMemset(h->vol_a, 0, VB));
+    HIP_OK(hipMemset(h->vol_b, 0, VB));
+    return hipSuccess;
+}
+
+// Host-built tables: evaluated with the host's libm so the GPU result is
+// bit-identical to what the CPU reference computes with the same libm.
+static hipError_t upload_tables(adc_handle* h)
+{
+    const adc_option& o = h->p.opt;
+    float A[768], C[64];
+    memset(A, 0, sizeof(A));
+    for (int k = 0; k <= 765; k++) {
+        const float cost_ad = (float)k / 3.0f;                     // cost_computor.cpp:110
+        const float ea = expf(-cost_ad / (float)o.lambda_ad);      // :117
+        A[k] = (1.0f - ea) + 1.0f;
+    }
+    for (int hm = 0; hm < 64; hm++) C[hm] = expf(-(float)hm / (float)o.lambda_census);
+    HIP_OK(hipMemcpy(h->lut_ad, A, sizeof(A), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h->lut_census, C, sizeof(C), hipMemcpyHostToDevice));
+    // 16 ray angles: ang = 0.0 (double); ang += pi/16 with float pi, float divide (multistep_refiner.cpp:234,254-268)
+    double sc[32];
+    const float pi = 3.1415926f;
+    double ang = 0.0;
+    for (int s = 0; s < 16; s++) {
+        sc[2 * s] = sin(ang);
+        sc[2 * s + 1] = cos(ang);
+        ang += pi / 16;
+    }
+    HIP_OK(hipMemcpy(h->ray_sincos, sc, sizeof(sc), hipMemcpyHostToDevice));
+    // penalty classes (scanline_optimizer.cpp:129-141): f32 divides on the host
+    h->so_P1[0] = o.so_p1;      h->so_P2[0] = o.so_p2;
+    h->so_P1[1] = o.so_p1 / 4;  h->so_P2[1] = o.so_p2 / 4;
+    h->so_P1[2] = o.so_p1 / 10; h->so_P2[2] = o.so_p2 / 10;
+    return hipSuccess;
+}
+
+adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int device)
+{
+    g_last_error.clear();
+    if (!opt) { g_last_error = "adc_create: null option"; return nullptr; }
+    if (width <= 0 || height <= 0) { g_last_error = "adc_create: width/height <= 0"; return nullptr; }            // ADCensusStereo.cpp:31-33
+    const long long range = (long long)opt->max_disparity - (long long)opt->min_disparity;
+    if (range <= 0) { g_last_error = "adc_create: disparity range <= 0"; return nullptr; }                         // :38-40
+    if (range > ADC_MAX_DISP_RANGE) { g_last_error = "adc_create: disparity range > ADC_MAX_DISP_RANGE"; return nullptr; }
+    if ((long long)width * height > (1LL << 30)) { g_last_error = "adc_create: image too large"; return nullptr; }
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { g_last_error = "adc_create: hipSetDevice failed"; return nullptr; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { g_last_error = "adc_create: no HIP device (the HIP path is mandatory, there is no CPU fallback)"; return nullptr; }
+
+    adc_handle* h = new (std::nothrow) adc_handle();
+    if (!h) return nullptr;
+    memset(h, 0, sizeof(*h));
+    h->device = dev;
+    h->p.W = width; h->p.H = height;
+    h->p.dmin = opt->min_disparity; h->p.dmax = opt->max_disparity; h->p.D = (int)range;
+    h->p.VPL = range <= 64 ? 1 : (range <= 128 ? 2 : 4);
+    h->p.Dp = 64 * h->p.VPL;
+    h->p.opt = *opt;
+    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    h->own_stream = ok;
+    for (int i = 0; ok && i <= ADC_STAGE_COUNT; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+    for (int i = 0; ok && i < 9; i++) ok = hipEventCreate(&h->ev_agg[i]) == hipSuccess;
+    if (ok) ok = alloc_all(h) == hipSuccess;
+    if (ok) ok = upload_tables(h) == hipSuccess;
+    if (!ok) {
+        if (g_last_error.empty()) g_last_error = "adc_create: HIP resource creation failed";
+        std::string keep = g_last_error;
+        adc_destroy(h);
+        g_last_error = keep;
+        return nullptr;
+    }
+    return h;
+}
+
+void adc_destroy(adc_handle* h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
+                    h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
+                    h->ray_sincos, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->vote_list, h->vote_counters,
+                    h->chg_a, h->chg_b, h->edge};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (h->pin_in) hipHostFree(h->pin_in);
+    if (h->pin_out) hipHostFree(h->pin_out);
+    for (int i = 0; i <= ADC_STAGE_COUNT; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 9; i++) if (h->ev_agg[i]) hipEventDestroy(h->ev_agg[i]);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// ------------------------------------------------------------------------------ the pipeline
+static hipError_t run_refine(adc_handle* h)
+{
+    // MultiStepRefiner::Refine (multistep_refiner.cpp:60-87); do_filling drives both the voting and the
+    // interpolation (ADCensusStereo.cpp:182-183).  Without an LR check both lists are empty.
+    const adc_option& o = h->p.opt;
+    const size_t P = (size_t)h->p.W * h->p.H;
+    if (o.do_lr_check) HIP_OK(adc_launch_lrcheck(h));
+    else HIP_OK(hipMemsetAsync(h->label, 0, P, h->stream));
+    if (o.do_filling && o.do_lr_check) {
+        HIP_OK(adc_run_region_voting(h));
+        HIP_OK(adc_launch_interpolation(h));
+    }
+    if (o.do_discontinuity_adjustment) HIP_OK(adc_launch_discontinuity(h));
+    HIP_OK(adc_launch_median(h));
+    return hipSuccess;
+}
+
+static hipError_t run_pipeline(adc_handle* h)
+{
+    const bool prof = h->profiling != 0;
+#define MARK(i) do { if (prof) HIP_OK(hipEventRecord(h->ev[i], h->stream)); } while (0)
+    MARK(0);
+    HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
+    HIP_OK(adc_launch_cost(h, h->vol_a));
+    MARK(1);
+    HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
+    MARK(2);
+    HIP_OK(adc_launch_aggregate(h, 4));          // aggregator_.Aggregate(4), :164
+    MARK(3);
+    HIP_OK(adc_launch_scanline(h, 4));           // ScanlineOptimize, :100
+    MARK(4);
+    HIP_OK(adc_launch_wta(h));                   // ComputeDisparity + ComputeDisparityRight, :108-109
+    MARK(5);
+    HIP_OK(run_refine(h));                       // MultiStepRefine, :117
+    MARK(6);
+#undef MARK
+    h->timings_pending = prof;
+    return hipSuccess;
+}
+
+static void collect_timings(adc_handle* h)
+{
+    if (!h->timings_pending) return;
+    h->timings_pending = false;
+    for (int i = 0; i < ADC_STAGE_COUNT; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = -1.f;
+        h->stage_ms[i] = ms;
+    }
+    float tot = 0.f;
+    if (h->agg_launches > 0 && hipEventElapsedTime(&tot, h->ev_agg[0], h->ev_agg[h->agg_launches]) == hipSuccess)
+        h->agg_pass_ms = tot / (float)h->agg_launches;
+    if (h->verbose) { // the reference's stage lines (ADCensusStereo.cpp:88-129)
+        printf("computing cost! timing :	%lf s\n", (h->stage_ms[0]) / 1000.0);
+        printf("cost aggregating! timing :	%lf s\n", (h->stage_ms[1] + h->stage_ms[2]) / 1000.0);
+        printf("scanline optimizing! timing :	%lf s\n", h->stage_ms[3] / 1000.0);
+        printf("computing disparities! timing :	%lf s\n", h->stage_ms[4] / 1000.0);
+        printf("multistep refining! timing :	%lf s\n", h->stage_ms[5] / 1000.0);
+        printf("output disparities! timing :	%lf s\n", 0.0);
+    }
+}
+
+int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, void* d_disp)
+{
+    if (!h || !d_left || !d_right || !d_disp) return 1; // ADCensusStereo.cpp:71-76
+    hipSetDevice(h->device);
+    const size_t P = (size_t)h->p.W * h->p.H;
+    if (hipMemcpyAsync(h->img_l, d_left, P * 3, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
+    if (hipMemcpyAsync(h->img_r, d_right, P * 3, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
+    if (run_pipeline(h) != hipSuccess) return 2;
+    if (hipMemcpyAsync(d_disp, h->disp_l, P * 4, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
+    return 0;
+}
+
+int adc_match_async(adc_handle* h, const uint8_t* left, const uint8_t* right, float* disp)
+{
+    if (!h || !left || !right || !disp) return 1;
+    hipSetDevice(h->device);
+    const size_t P = (size_t)h->p.W * h->p.H;
+    memcpy(h->pin_in, left, P * 3);
+    memcpy(h->pin_in + P * 3, right, P * 3);
+    if (hipMemcpyAsync(h->img_l, h->pin_in, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
+    if (hipMemcpyAsync(h->img_r, h->pin_in + P * 3, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
+    if (run_pipeline(h) != hipSuccess) return 2;
+    if (hipMemcpyAsync(h->pin_out, h->disp_l, P * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 2;
+    h->async_dst = disp;
+    return 0;
+}
+
+int adc_wait(adc_handle* h)
+{
+    if (!h) return 1;
+    hipSetDevice(h->device);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("adc_wait", hipGetLastError()); return 2; }
+    if (h->async_dst) {
+        memcpy(h->async_dst, h->pin_out, (size_t)h->p.W * h->p.H * 4);
+        h->async_dst = nullptr;
+    }
+    collect_timings(h);
+    return 0;
+}
+
+int adc_match(adc_handle* h, const uint8_t* left, const uint8_t* right, float* disp)
+{
+    const int rc = adc_match_async(h, left, right, disp);
+    if (rc != 0) return rc;
+    return adc_wait(h);
+}
+
+// ------------------------------------------------------------------------------ misc plumbing
+const char* adc_stage_name(int s)
+{
+    static const char* names[ADC_STAGE_COUNT] = {"cost", "arms", "aggregate", "scanline", "wta", "refine"};
+    return (s >= 0 && s < ADC_STAGE_COUNT) ? names[s] : "";
+}
+void adc_set_profiling(adc_handle* h, int on) { if (h) h->profiling = on; }
+void adc_set_verbose(adc_handle* h, int on) { if (h) { h->verbose = on; if (on) h->profiling = 1; } }
+int adc_get_stage_ms(adc_handle* h, float* ms, int n)
+{
+    if (!h || !ms) return 1;
+    for (int i = 0; i < n && i < ADC_STAGE_COUNT; i++) ms[i] = h->stage_ms[i];
+    return 0;
+}
+int adc_get_aggregate_pass_ms(adc_handle* h, float* avg_ms, int* launches)
+{
+    if (!h) return 1;
+    if (avg_ms) *avg_ms = h->agg_pass_ms;
+    if (launches) *launches = h->agg_launches;
+    return 0;
+}
+void* adc_get_stream(adc_handle* h) { return h ? (void*)h->stream : nullptr; }
+int adc_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : 1; }
+void* adc_device_malloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
+void adc_device_free(void* p) { if (p) hipFree(p); }
+int adc_memcpy_h2d(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1; }
+int adc_memcpy_d2h(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1; }
+
+// ------------------------------------------------------------------------------ debug surface
+struct BufDesc { void* ptr; size_t bytes; bool volume; };
+static BufDesc buf_desc(adc_handle* h, int which)
+{
+    const size_t P = (size_t)h->p.W * h->p.H;
+    switch (which) {
+    case ADC_BUF_GRAY_LEFT: return {h->gray_l, P, false};
+    case ADC_BUF_GRAY_RIGHT: return {h->gray_r, P, false};
+    case ADC_BUF_CENSUS_LEFT: return {h->census_l, P * 8, false};
+    case ADC_BUF_CENSUS_RIGHT: return {h->census_r, P * 8, false};
+    case ADC_BUF_ARMS: return {h->arms, P * 4, false};
+    case ADC_BUF_SUPCOUNT_H: return {h->sup_h, P * 2, false};
+    case ADC_BUF_SUPCOUNT_V: return {h->sup_v, P * 2, false};
+    case ADC_BUF_VOLUME_A: return {h->vol_a, P * h->p.D * 4, true};
+    case ADC_BUF_DISP_LEFT: return {h->disp_l, P * 4, false};
+    case ADC_BUF_DISP_RIGHT: return {h->disp_r, P * 4, false};
+    case ADC_BUF_OUTLIER_LABEL: return {h->label, P, false};
+    default: return {nullptr, 0, false};
+    }
+}
+
+int adc_debug_read(adc_handle* h, int which, void* dst)
+{
+    if (!h || !dst) return 1;
+    hipSetDevice(h->device);
+    const BufDesc b = buf_desc(h, which);
+    if (!b.ptr) return 1;
+    if (b.volume) { // de-pad through vol_b (scratch at stage boundaries)
+        if (adc_launch_unpad_volume(h, h->vol_a, h->vol_b) != hipSuccess) return 2;
+        if (hipMemcpyAsync(dst, h->vol_b, b.bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 2;
+    } else if (hipMemcpyAsync(dst, b.ptr, b.bytes, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 2;
+    return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 2;
+}
+
+int adc_debug_write(adc_handle* h, int which, const void* src)
+{
+    if (!h || !src) return 1;
+    hipSetDevice(h->device);
+    const BufDesc b = buf_desc(h, which);
+    if (!b.ptr) return 1;
+    if (b.volume) {
+        if (hipMemcpyAsync(h->vol_b, src, b.bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
+        if (adc_launch_pad_volume(h, h->vol_b, h->vol_a) != hipSuccess) return 2;
+    } else if (hipMemcpyAsync(b.ptr, src, b.bytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
+    return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 2;
+}
+
+int adc_debug_set_images(adc_handle* h, const uint8_t* left, const uint8_t* right)
+{
+    if (!h || !left || !right) return 1;
+    hipSetDevice(h->device);
+    const size_t P = (size_t)h->p.W * h->p.H;
+    if (hipMemcpy(h->img_l, left, P * 3, hipMemcpyHostToDevice) != hipSuccess) return 2;
+    if (hipMemcpy(h->img_r, right, P * 3, hipMemcpyHostToDevice) != hipSuccess) return 2;
+    return 0;
+}
+
+int adc_debug_run(adc_handle* h, int stage, int arg)
+{
+    if (!h) return 1;
+    hipSetDevice(h->device);
+    hipError_t e = hipSuccess;
+    switch (stage) {
+    case ADC_RUN_GRAY_CENSUS: e = adc_launch_gray_census(h); break;
+    case ADC_RUN_COST: e = adc_launch_cost(h, h->vol_a); break;
+    case ADC_RUN_ARMS: e = adc_launch_arms(h); break;
+    case ADC_RUN_AGGREGATE: e = adc_launch_aggregate(h, arg > 0 ? arg : 4); break;
+    case ADC_RUN_SCANLINE: e = adc_launch_scanline(h, arg); break;
+    case ADC_RUN_WTA: e = adc_launch_wta(h); break;
+    case ADC_RUN_LRCHECK: e = adc_launch_lrcheck(h); break;
+    case ADC_RUN_REGION_VOTING: e = adc_run_region_voting(h); break;
+    case ADC_RUN_INTERPOLATION: e = adc_launch_interpolation(h); break;
+    case ADC_RUN_DISCONTINUITY: e = adc_launch_discontinuity(h); break;
+    case ADC_RUN_MEDIAN: e = adc_launch_median(h); break;
+    default: return 1;
+    }
+    if (e != hipSuccess) { set_error("adc_debug_run launch", e); return 2; }
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { set_error("adc_debug_run sync", e); return 2; }
+    return 0;
+}
+
+int adc_debug_voting_stats(adc_handle* h, int64_t* rounds, int64_t* evaluations)
+{
+    if (!h) return 1;
+    if (rounds) *rounds = h->vote_rounds;
+    if (evaluations) *evaluations = h->vote_evals;
+    return 0;
+}
+
+} // extern "C"

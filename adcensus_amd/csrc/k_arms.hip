@@ -1,0 +1,107 @@
+// k_arms.hip -- K3 cross arms, support-pixel counts and the colour-difference maps used by the
+// scanline penalties.
+//
+// Replaces CrossAggregator::{BuildArms, FindHorizontalArm, FindVerticalArm, ComputeSupPixelCount}
+// (cross_aggregator.cpp:76-86,135-325).  Integer-only, O(W*H*34); the left image (3*W*H bytes) is
+// L2-resident, so one thread per pixel reading global memory directly is sufficient (this stage is
+// <1% of the pipeline traffic).
+#include "adc_internal.h"
+#include "adc_device_fn.h"
+
+// One arm from (x,y) along (dx,dy): rules of cross_aggregator.cpp:151-198.
+__device__ __forceinline__ int arm_length(const uint8_t* __restrict__ img, int W, int H, int x, int y, int dx, int dy,
+                                          int L1, int L2, int t1, int t2)
+{
+    const uint8_t* p0 = img + ((size_t)y * W + x) * 3;
+    const int b0 = p0[0], g0 = p0[1], r0 = p0[2];
+    int bl = b0, gl = g0, rl = r0;
+    int len = 0;
+    int xn = x + dx, yn = y + dy;
+    const int nmax = adc_imin(L1, 255); // MAX_ARM_LENGTH, cross_aggregator.h:22
+    for (int n = 0; n < nmax; n++) {
+        if (xn < 0 || xn >= W || yn < 0 || yn >= H) break;
+        const uint8_t* p = img + ((size_t)yn * W + xn) * 3;
+        const int b = p[0], g = p[1], r = p[2];
+        const int d1 = adc_imax(adc_iabs(r - r0), adc_imax(adc_iabs(g - g0), adc_iabs(b - b0)));
+        if (d1 >= t1) break;
+        if (n > 0) {
+            const int d2 = adc_imax(adc_iabs(r - rl), adc_imax(adc_iabs(g - gl), adc_iabs(b - bl)));
+            if (d2 >= t1) break;
+        }
+        if (n + 1 > L2 && d1 >= t2) break;
+        len++;
+        bl = b; gl = g; rl = r;
+        xn += dx;
+        yn += dy;
+    }
+    return len;
+}
+
+__global__ __launch_bounds__(256) void k_build_arms(const uint8_t* __restrict__ img_l, uchar4* __restrict__ arms, int W,
+                                                    int H, int L1, int L2, int t1, int t2)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    uchar4 a;
+    a.x = (uint8_t)arm_length(img_l, W, H, x, y, -1, 0, L1, L2, t1, t2); // left
+    a.y = (uint8_t)arm_length(img_l, W, H, x, y, +1, 0, L1, L2, t1, t2); // right
+    a.z = (uint8_t)arm_length(img_l, W, H, x, y, 0, -1, L1, L2, t1, t2); // top
+    a.w = (uint8_t)arm_length(img_l, W, H, x, y, 0, +1, L1, L2, t1, t2); // bottom
+    arms[(size_t)y * W + x] = a;
+}
+
+// Support counts (cross_aggregator.cpp:271-325):
+//   id 0 (horizontal first): cnt = sum_{t=-top..bottom} (left+right+1)(x, y+t)
+//   id 1 (vertical first)  : cnt = sum_{t=-left..right} (top+bottom+1)(x+t, y)
+__global__ __launch_bounds__(256) void k_sup_counts(const uchar4* __restrict__ arms, uint16_t* __restrict__ sup_h,
+                                                    uint16_t* __restrict__ sup_v, int W, int H)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uchar4 a = arms[(size_t)y * W + x];
+    int ch = 0, cv = 0;
+    for (int t = -(int)a.z; t <= (int)a.w; t++) {
+        const uchar4 q = arms[(size_t)(y + t) * W + x];
+        ch += (int)q.x + (int)q.y + 1;
+    }
+    for (int t = -(int)a.x; t <= (int)a.y; t++) {
+        const uchar4 q = arms[(size_t)y * W + x + t];
+        cv += (int)q.z + (int)q.w + 1;
+    }
+    sup_h[(size_t)y * W + x] = (uint16_t)ch;
+    sup_v[(size_t)y * W + x] = (uint16_t)cv;
+}
+
+// Colour-difference maps: dh[y][x] = ColorDist((x,y),(x-1,y)) (0 at x=0), dv[y][x] = ColorDist((x,y),(x,y-1))
+// (0 at y=0), for both images.  They are what ScanlineOptimizer evaluates on the fly as d1 / d2
+// (scanline_optimizer.cpp:114-126, :223-235); forward passes read [p], backward passes read [p+1].
+__global__ __launch_bounds__(256) void k_color_diffs(const uint8_t* __restrict__ img_l, const uint8_t* __restrict__ img_r,
+                                                     uint8_t* __restrict__ lh, uint8_t* __restrict__ lv,
+                                                     uint8_t* __restrict__ rh, uint8_t* __restrict__ rv, int W, int H)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint8_t* img = blockIdx.z == 0 ? img_l : img_r;
+    uint8_t* dh = blockIdx.z == 0 ? lh : rh;
+    uint8_t* dv = blockIdx.z == 0 ? lv : rv;
+    const uint8_t* p = img + ((size_t)y * W + x) * 3;
+    dh[(size_t)y * W + x] = x > 0 ? (uint8_t)adc_color_dist_max(p, p - 3) : 0;
+    dv[(size_t)y * W + x] = y > 0 ? (uint8_t)adc_color_dist_max(p, p - (size_t)W * 3) : 0;
+}
+
+hipError_t adc_launch_arms(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->stream, h->img_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
+                       p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2);
+    hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
+                       p.W, p.H);
+    dim3 grid2(grid.x, grid.y, 2);
+    hipLaunchKernelGGL(k_color_diffs, grid2, block, 0, h->stream, h->img_l, h->img_r, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh,
+                       h->cdiff_rv, p.W, p.H);
+    return hipGetLastError();
+}

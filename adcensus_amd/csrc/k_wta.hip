@@ -1,0 +1,101 @@
+// k_wta.hip -- K6 winner-takes-all + parabola sub-pixel, left and right view.
+//
+// Replaces ADCensusStereo::ComputeDisparity / ComputeDisparityRight (ADCensusStereo.cpp:188-310).
+// Left:  first minimum over d (strict '>' => lowest d wins ties); best at either end of the range
+//        => +inf; else best + (c1-c2)/(2*(c1+c2-2*cmin)).
+// Right: candidate cost(x+d, y, d) if 0 <= x+d < W else Large_Float (can enter the parabola as a
+//        neighbour); at the range ends the INTEGER best is stored (no invalidation).
+// One wave per pixel, lanes = disparities; lexicographic (cost, d) wave arg-min.
+#include "adc_internal.h"
+#include "adc_device_fn.h"
+
+__device__ __forceinline__ void wave_argmin(float& c, int& d)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float oc = __shfl_xor(c, m, 64);
+        const int od = __shfl_xor(d, m, 64);
+        const bool take = (oc < c) || (oc == c && od < d);
+        c = take ? oc : c;
+        d = take ? od : d;
+    }
+}
+
+template <int VPL, bool RIGHT>
+__global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, float* __restrict__ disp, int W, int H, int dmin,
+                                             int D)
+{
+    constexpr int Dp = 64 * VPL;
+    const int lane = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long long)W * H) return;
+    const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    const int dmax = dmin + D;
+
+    // candidate costs of this lane
+    float c[VPL];
+    float bc = ADC_LARGE_FLOAT;
+    int bd = 0x7fffffff; // "none": keeps best_disparity's initial 0 / min_cost Large_Float semantics below
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+        const int di = lane * VPL + k;
+        float v = ADC_LARGE_FLOAT;
+        bool cand = false;
+        if (di < D) {
+            if (!RIGHT) {
+                v = vol[(size_t)pix * Dp + di];
+                cand = true;
+            } else {
+                const int col = x + di + dmin;
+                if (col >= 0 && col < W) {
+                    v = vol[((size_t)y * W + col) * Dp + di];
+                    cand = true;
+                }
+            }
+        }
+        c[k] = v;
+        // the scan updates only on min_cost > cost, min_cost starting at Large_Float
+        if (cand && v < bc) { bc = v; bd = di + dmin; }
+    }
+    wave_argmin(bc, bd);
+    int best = bd;
+    if (bd == 0x7fffffff) best = 0; // nothing below Large_Float: best_disparity keeps its initial 0
+
+    float out;
+    const bool edge = (best == dmin) || (best == dmax - 1);
+    if (edge) {
+        out = RIGHT ? (float)best : ADC_INVALID_FLOAT;
+    } else if (best - 1 - dmin < 0 || best + 1 - dmin >= D) {
+        out = (float)best; // reference indexes out of bounds here (only when best stayed 0 and dmin != 0)
+    } else {
+        // neighbours c1 = cost_local[best-1], c2 = cost_local[best+1]: fetch from the owning lanes
+        const int i1 = best - 1 - dmin, i2 = best + 1 - dmin;
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; k++) {
+            const float a = __shfl(c[k], i1 / VPL, 64);
+            const float b = __shfl(c[k], i2 / VPL, 64);
+            if ((i1 % VPL) == k) c1 = a;
+            if ((i2 % VPL) == k) c2 = b;
+        }
+        out = adc_subpixel(best, c1, c2, bc);
+    }
+    if (lane == 0) disp[pix] = out;
+}
+
+hipError_t adc_launch_wta(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    const long long P = (long long)p.W * p.H;
+    const unsigned blocks = (unsigned)((P + 3) / 4);
+#define LAUNCH(V)                                                                                                       \
+    do {                                                                                                                \
+        hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->stream, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \
+        hipLaunchKernelGGL((k_wta<V, true>), dim3(blocks), dim3(256), 0, h->stream, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D);  \
+    } while (0)
+    if (p.VPL == 1) LAUNCH(1);
+    else if (p.VPL == 2) LAUNCH(2);
+    else LAUNCH(4);
+#undef LAUNCH
+    return hipGetLastError();
+}

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo pairs/s of the MI355X-native AD-Census Match path (BASELINE.json metric).
+
+A "step" = one full `Match` (cost volume -> 4x cross aggregation -> 4 scanline passes -> L/R WTA ->
+multi-step refinement) of one 1920x1080, D=128 stereo pair whose images are already resident in
+HBM (adc_match_device); the disparity map stays in HBM.  N>1: one process per GPU
+(torch.distributed / RCCL), pairs are independent work items (weak scaling, no data collective;
+RCCL is used only for the barrier and the max-over-ranks reduction of the elapsed time).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the aggregation pass kernel (k_agg_march): algorithmic bytes per launch
+                  (2*V + 4*P arms [+ 2*P counts on dividing passes], V = 4*W*H*D) / its average
+                  launch duration measured with HIP events on the handle's own stream inside the
+                  timed region, vs 8 TB/s HBM3E.
+  cpu_baseline -- the reference CPU path (oracle/_ref, kind "reference"; the plain-C port if absent)
+                  timed on this host, 1 thread, on a bounded row-strip sample of the same pair.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="noise", choices=["noise", "structured"],
+                    help="noise = BASELINE.json configs[3] (default); structured = SURVEY 8d S2 pair")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--disp", type=int, default=128)
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ADC_BENCH_INFLIGHT", "3")),
+                    help="ADCensusStereo objects (streams) in flight per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=216, help="rows of the CPU-baseline sample strip")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: its bundled HIP runtime (same SONAME) is then shared by the C-ABI library
+        import torch as _torch
+        import torch.distributed as _dist
+        torch, dist = _torch, _dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import adcensus_amd as A
+    from adcensus_amd import workloads
+    lib = A.lib()
+    if A.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible")
+    W, H, D = a.width, a.height, a.disp
+    P = W * H
+    opt = A.ADCensusOption(min_disparity=0, max_disparity=D)
+
+    # synthetic pair(s): distinct seed per rank and per in-flight slot
+    F = max(1, a.inflight)
+    handles, bufs, pairs = [], [], []
+    for i in range(F):
+        seed = 12345 + rank * 64 + i
+        left, right = (workloads.noise_pair(W, H, seed) if a.workload == "noise"
+                       else workloads.structured_pair(W, H, D, seed=777 + rank * 64 + i))
+        pairs.append((left, right))
+        st = A.ADCensusStereo(device=local_rank)
+        if not st.Initialize(W, H, opt):
+            raise SystemExit("Initialize failed: " + A.last_error())
+        dl, dr, dd = lib.adc_device_malloc(P * 3), lib.adc_device_malloc(P * 3), lib.adc_device_malloc(P * 4)
+        assert dl and dr and dd
+        assert lib.adc_memcpy_h2d(dl, left.ctypes.data, P * 3) == 0 and lib.adc_memcpy_h2d(dr, right.ctypes.data, P * 3) == 0
+        handles.append(st)
+        bufs.append((dl, dr, dd))
+    handles[0].set_profiling(True)
+
+    def run_steps(nsteps, collect=None):
+        """nsteps Match calls spread over the F objects, one host thread per object."""
+        counts = [nsteps // F + (1 if i < nsteps % F else 0) for i in range(F)]
+        errs = []
+
+        def worker(i):
+            st, (dl, dr, dd) = handles[i], bufs[i]
+            for _ in range(counts[i]):
+                if not (st.match_device(dl, dr, dd) and st.wait()):
+                    errs.append(A.last_error())
+                    return
+                if collect is not None and i == 0:
+                    collect.append((st.stage_ms(), st.aggregate_pass_ms()))
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(F) if counts[i]]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise SystemExit("Match failed: %s" % errs[0])
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        lib.adc_device_synchronize()
+
+    run_steps(a.warmup)
+    sync_all()
+    prof = []
+    t0 = time.perf_counter()
+    run_steps(a.steps, prof)
+    lib.adc_device_synchronize()
+    if dist is not None:
+        dist.barrier()
+    lib.adc_device_synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_pairs = a.steps * world
+        value = total_pairs / elapsed
+        # roofline of the dominant kernel (aggregation pass): algorithmic bytes per launch / avg launch time
+        V = 4.0 * P * D
+        per_launch_bytes = (16.0 * V + 32.0 * P + 8.0 * P) / 8.0  # 8 passes = 16V + 32P + 8P
+        agg = [p[1][0] for p in prof if p[1][1] > 0 and p[1][0] > 0]
+        agg_ms = float(np.mean(agg)) if agg else float("nan")
+        achieved = per_launch_bytes / (agg_ms * 1e-3) / 1e9 if agg else float("nan")
+        stage = {}
+        if prof:
+            for k in prof[0][0]:
+                stage[k] = round(float(np.mean([p[0][k] for p in prof])), 4)
+        out = {
+            "metric": "stereo pairs/s at 1920x1080 D=128 (ADCensusStereo::Match)" if (W, H, D) == (1920, 1080, 128)
+                      else "stereo pairs/s at %dx%d D=%d (ADCensusStereo::Match)" % (W, H, D),
+            "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1000.0 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d D=%d (BASELINE.json configs[3])" % (a.workload, W, H, D),
+                       "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs)" % world},
+            "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
+            "stage_ms": stage,
+            "roofline": {"kernel": "k_agg_march (one aggregation pass)", "bound": "hbm",
+                         "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(agg_ms, 5)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pairs[0], D, a.cpu_rows, H)
+        print(json.dumps(out), flush=True)
+
+    for st, (dl, dr, dd) in zip(handles, bufs):
+        st.Release()
+        for p in (dl, dr, dd):
+            lib.adc_device_free(p)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pair, D, rows, H):
+    """Reference CPU path on a bounded sample: the top `rows` rows of the same pair, full width and
+    disparity range, 1 thread (the reference is single-threaded).  pairs/s is scaled by rows/H."""
+    from oracle import pyoracle  # checker / baseline leg only
+    orc = pyoracle.load("auto")
+    rows = min(rows, H)
+    l, r = np.ascontiguousarray(pair[0][:rows]), np.ascontiguousarray(pair[1][:rows])
+    opt = pyoracle.Option(max_disparity=D)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(devnull, 1)  # the reference printf()s its stage timings
+    try:
+        _, secs = orc.match(l, r, opt)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+    full_secs = secs * (H / float(rows))
+    return {"value": round(1.0 / full_secs, 6), "unit": "pairs/s", "cores": 1, "kind": "reference" if orc.kind == "reference" else "port",
+            "sample": "top %d of %d rows of the same pair (full width, D=%d): %.2f s measured, scaled by rows to %.1f s/pair; "
+                      "host has %d cores, the reference is single-threaded" % (rows, H, D, secs, full_secs, os.cpu_count() or 0)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Named, seeded test cases shared by the golden generator (tools/make_golden.py), the oracle tests
+and the GPU parity tests.  A case = (left BGR, right BGR, option)."""
+import os
+
+import numpy as np
+
+from adcensus_amd import workloads
+from oracle import pyoracle
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN_DIR = os.path.join(_HERE, "golden")
+
+
+def cone_pair():
+    z = np.load(os.path.join(GOLDEN_DIR, "cone_pair.npz"))
+    return np.ascontiguousarray(z["left"]), np.ascontiguousarray(z["right"])
+
+
+def data_pair(name):
+    """cloth3 / piano / wood2 from tests/golden/_data (git-ignored copies of the reference Data/ PNGs)."""
+    p = os.path.join(GOLDEN_DIR, "_data", name + "_pair.npz")
+    if not os.path.exists(p):
+        return None
+    z = np.load(p)
+    return np.ascontiguousarray(z["left"]), np.ascontiguousarray(z["right"])
+
+
+DATA_RANGES = {"cloth3": 128, "piano": 64, "wood2": 128}  # Data/*/d_range.txt
+
+
+def _crop(pair, y0, y1, x0, x1):
+    return tuple(np.ascontiguousarray(a[y0:y1, x0:x1]) for a in pair)
+
+
+# name -> (builder returning (left,right), option kwargs)
+_CASES = {
+    # BASELINE.json configs[0]/[1]
+    "cone": (cone_pair, dict(max_disparity=64)),
+    "cone_neg": (cone_pair, dict(min_disparity=-16, max_disparity=48)),
+    "cone_d16": (cone_pair, dict(max_disparity=16)),
+    "cone_nolr": (cone_pair, dict(do_lr_check=0)),
+    "cone_nofill": (cone_pair, dict(do_filling=0)),
+    "cone_dda": (cone_pair, dict(do_discontinuity_adjustment=1)),
+    "cone_params": (cone_pair, dict(lambda_ad=7, lambda_census=20, cross_L1=20, cross_L2=9, cross_t1=25, cross_t2=8,
+                                    so_p1=0.8, so_p2=2.5, so_tso=11, irv_ts=12, irv_th=0.3, lrcheck_thres=1.5)),
+    "cone_crop_d40": (lambda: _crop(cone_pair(), 100, 231, 120, 377), dict(max_disparity=40)),
+    # small synthetic cases: odd sizes, W < D, census-skip sizes, 1-pixel-wide/high, VPL = 2 and 4
+    "s2_96x64_d32": (lambda: workloads.structured_pair(96, 64, 32, seed=11), dict(max_disparity=32)),
+    "s2_320x180_d128": (lambda: workloads.structured_pair(320, 180, 128, seed=12), dict(max_disparity=128)),
+    "s2_200x120_d200": (lambda: workloads.structured_pair(200, 120, 200, seed=13), dict(max_disparity=200)),
+    "q_257x131_d64": (lambda: workloads.quantized_noise_pair(257, 131, 64, seed=14), dict(max_disparity=64)),
+    "q_20x40_d32": (lambda: workloads.quantized_noise_pair(20, 40, 32, seed=15), dict(max_disparity=32)),
+    "q_9x20_d8": (lambda: workloads.quantized_noise_pair(9, 20, 8, seed=16), dict(max_disparity=8)),
+    "q_30x7_d8": (lambda: workloads.quantized_noise_pair(30, 7, 8, seed=17), dict(max_disparity=8)),
+    "q_1x40_d8": (lambda: workloads.quantized_noise_pair(1, 40, 8, seed=18), dict(max_disparity=8)),
+    "q_40x1_d8": (lambda: workloads.quantized_noise_pair(40, 1, 8, seed=19), dict(max_disparity=8)),
+    "q_3x3_d2": (lambda: workloads.quantized_noise_pair(3, 3, 2, seed=20), dict(max_disparity=2)),
+    "noise_128x72_d64": (lambda: workloads.noise_pair(128, 72, seed=21), dict(max_disparity=64)),
+    "s2_150x100_neg": (lambda: workloads.structured_pair(150, 100, 48, seed=22), dict(min_disparity=-8, max_disparity=40)),
+}
+GOLDEN_CASES = list(_CASES.keys())
+# subset that the CPU-only tier recomputes with the port (kept small: the whole CPU suite must run in minutes)
+FAST_CASES = ["cone_crop_d40", "s2_96x64_d32", "q_257x131_d64", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8",
+              "q_40x1_d8", "q_3x3_d2", "noise_128x72_d64", "s2_150x100_neg", "s2_200x120_d200"]
+
+
+def make_case(name):
+    build, kw = _CASES[name]
+    left, right = build()
+    return left, right, pyoracle.Option(**kw)
+
+
+def to_product_option(opt):
+    """pyoracle.Option -> adcensus_amd.ADCensusOption (identical layout)."""
+    import ctypes as C
+    from adcensus_amd import ADCensusOption
+    o = ADCensusOption()
+    C.memmove(C.byref(o), C.byref(opt), C.sizeof(o))
+    return o

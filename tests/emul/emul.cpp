@@ -1,0 +1,403 @@
+// tests/emul/emul.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Scalar CPU emulation of the *parallel formulations* the HIP kernels use for the reference's
+// order-dependent steps, sharing adcensus_amd/csrc/adc_device_fn.h with the device code.  It lets
+// the CPU-only test tier (no GPU in the build container) check, against the oracle, that
+//   * the marching-ring index logic of k_agg_march visits exactly the reference's summation order,
+//   * the closed-form "sticky d2" + diff-map indexing of k_scanline equals the sequential code,
+//   * the two-phase LR check, the fixed-point region voting (with dirty tiles and an arbitrary
+//     evaluation order), the Jacobi interpolation and the level-synchronous median equal the
+//     reference's in-place raster scans.
+// It is NOT a product path: nothing in adcensus_amd/ links it; it mirrors kernel control flow one
+// lane at a time and is far too slow for anything but small images.
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "../../adcensus_amd/csrc/adc_device_fn.h"
+#include "../../include/adcensus_c_api.h"
+
+extern "C" {
+
+// ------------------------------------------------------------------ colour-difference maps (k_arms.hip)
+void emul_color_diffs(const uint8_t* img, uint8_t* dh, uint8_t* dv, int W, int H)
+{
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const uint8_t* p = img + ((size_t)y * W + x) * 3;
+            dh[(size_t)y * W + x] = x > 0 ? (uint8_t)adc_color_dist_max(p, p - 3) : 0;
+            dv[(size_t)y * W + x] = y > 0 ? (uint8_t)adc_color_dist_max(p, p - (size_t)W * 3) : 0;
+        }
+}
+
+// ------------------------------------------------------------------ k_agg_march, one lane of one line
+// vol layout [H][W][D] (reference layout; a "lane" is one d).  Mirrors the kernel's loop structure:
+// prefetch registers, ring slots, 8-wide chunks, epilogue.
+static void agg_line(const float* src, float* dst, const uint8_t* arms, const uint16_t* sup, int W, int H, int D, int d,
+                     bool vert, bool divide, int fixed, int L, int m0, int m1, int PF)
+{
+    const int R = 2 * L + 1;
+    const int N = vert ? H : W;
+    const int lo = std::max(0, m0 - L), hi = std::min(N, m1 + L);
+    std::vector<float> ring(R, NAN), pf(PF, NAN);
+    std::vector<uint32_t> pa(PF), ps(PF);
+    auto pix_of = [&](int m) -> size_t { return vert ? (size_t)m * W + fixed : (size_t)fixed * W + m; };
+    auto arms32 = [&](size_t pix) -> uint32_t { uint32_t v; memcpy(&v, arms + pix * 4, 4); return v; };
+    for (int u = 0; u < PF; u++) {
+        const int e = std::min(lo + u, hi - 1);
+        const int mo = std::min(std::max(e - L, m0), m1 - 1);
+        pf[u] = src[pix_of(e) * D + d];
+        pa[u] = arms32(pix_of(mo));
+        ps[u] = divide ? sup[pix_of(mo)] : 1u;
+    }
+    int slot_w = 0, slot_m = m0 - lo;
+    auto emit = [&](int m, uint32_t a32, uint32_t cnt) {
+        const size_t pix = pix_of(m);
+        const int alo = vert ? (a32 >> 16) & 255u : a32 & 255u, ahi = vert ? (a32 >> 24) & 255u : (a32 >> 8) & 255u;
+        int n = alo + ahi + 1;
+        int idx = slot_m - alo;
+        if (idx < 0) idx += R;
+        float acc = 0.0f;
+        while (n > 0) {
+            float v[8];
+            for (int k = 0; k < 8; k++) {
+                int s = idx + k;
+                if (s >= R) s -= R;
+                v[k] = ring[s];
+            }
+            for (int k = 0; k < 8; k++)
+                if (k < n) acc += v[k];
+            idx += 8;
+            if (idx >= R) idx -= R;
+            n -= 8;
+        }
+        if (divide) acc = acc / (float)cnt;
+        dst[pix * D + d] = acc;
+        slot_m++;
+        if (slot_m == R) slot_m = 0;
+    };
+    int j = lo;
+    for (; j + PF <= hi; j += PF)
+        for (int u = 0; u < PF; u++) {
+            const int jj = j + u;
+            const float v = pf[u];
+            const uint32_t a32 = pa[u], cnt = ps[u];
+            {
+                const int e = std::min(jj + PF, hi - 1);
+                const int mo = std::min(std::max(e - L, m0), m1 - 1);
+                pf[u] = src[pix_of(e) * D + d];
+                pa[u] = arms32(pix_of(mo));
+                if (divide) ps[u] = sup[pix_of(mo)];
+            }
+            ring[slot_w] = v;
+            slot_w++;
+            if (slot_w == R) slot_w = 0;
+            const int m = jj - L;
+            if (m >= m0 && m < m1) emit(m, a32, cnt);
+        }
+    for (int u = 0; u < PF; u++) {
+        const int jj = j + u;
+        if (jj < hi) {
+            ring[slot_w] = pf[u];
+            slot_w++;
+            if (slot_w == R) slot_w = 0;
+            const int m = jj - L;
+            if (m >= m0 && m < m1) emit(m, pa[u], ps[u]);
+        }
+    }
+    for (int m = std::max(m0, hi - L); m < m1; m++) emit(m, arms32(pix_of(m)), divide ? sup[pix_of(m)] : 1u);
+}
+
+void emul_aggregate_pass(const float* src, float* dst, const uint8_t* arms, const uint16_t* sup, int W, int H, int D,
+                         int vert, int divide, int L, int nseg, int PF)
+{
+    const int N = vert ? H : W;
+    int seg_len = (N + nseg - 1) / nseg;
+    if (seg_len < 1) seg_len = 1;
+    nseg = (N + seg_len - 1) / seg_len;
+    const int nfixed = vert ? W : H;
+    for (int seg = 0; seg < nseg; seg++) {
+        const int m0 = seg * seg_len, m1 = std::min(N, m0 + seg_len);
+        for (int f = 0; f < nfixed; f++)
+            for (int d = 0; d < D; d++) agg_line(src, dst, arms, sup, W, H, D, d, vert != 0, divide != 0, f, L, m0, m1, PF);
+    }
+}
+
+// ------------------------------------------------------------------ k_scanline (per disparity, no lanes)
+void emul_scanline_pass(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H, int dmin,
+                        int D, int vert, int dir, int tso, float p1, float p2)
+{
+    const float P1c[3] = {p1, p1 / 4, p1 / 10}, P2c[3] = {p2, p2 / 4, p2 / 10};
+    const int npaths = vert ? W : H, plen = vert ? H : W;
+    std::vector<float> Lp(D), out(D);
+    for (int path = 0; path < npaths; path++) {
+        auto coord = [&](int i, int& x, int& y) {
+            const int m = dir > 0 ? i : plen - 1 - i;
+            if (vert) { x = path; y = m; } else { x = m; y = path; }
+        };
+        int x, y;
+        coord(0, x, y);
+        float minLp = ADC_LARGE_FLOAT;
+        for (int d = 0; d < D; d++) {
+            const float c = src[((size_t)y * W + x) * D + d];
+            dst[((size_t)y * W + x) * D + d] = c;
+            Lp[d] = c;
+            minLp = c < minLp ? c : minLp;
+        }
+        for (int i = 1; i < plen; i++) {
+            coord(i, x, y);
+            const int sx = vert ? x : (dir > 0 ? x : x + 1);
+            const int sy = vert ? (dir > 0 ? y : y + 1) : y;
+            const int d1 = cd_left[(size_t)sy * W + sx];
+            const uint8_t* row = cd_right + (size_t)sy * W;
+            const int shift = vert ? 0 : (dir > 0 ? 0 : 1);
+            float omin = ADC_LARGE_FLOAT;
+            for (int d = 0; d < D; d++) {
+                const int col = adc_so_d2_column(x, dmin, d, W);
+                const int d2 = col >= 0 ? (int)row[col + shift] : d1;
+                const int cls = adc_so_penalty_class(d1, d2, tso);
+                const float P1 = P1c[cls], P2 = P2c[cls];
+                const float lm1 = d > 0 ? Lp[d - 1] : ADC_LARGE_FLOAT;
+                const float lp1 = d < D - 1 ? Lp[d + 1] : ADC_LARGE_FLOAT;
+                const float l1 = Lp[d], l2 = lm1 + P1, l3 = lp1 + P1, l4 = minLp + P2;
+                const float m12 = l2 < l1 ? l2 : l1, m34 = l4 < l3 ? l4 : l3;
+                const float mm = m34 < m12 ? m34 : m12;
+                float cs = src[((size_t)y * W + x) * D + d] + mm;
+                cs = cs / 2;
+                out[d] = cs;
+                omin = cs < omin ? cs : omin;
+            }
+            for (int d = 0; d < D; d++) { dst[((size_t)y * W + x) * D + d] = out[d]; Lp[d] = out[d]; }
+            minLp = omin;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_wta
+void emul_wta(const float* vol, float* disp, int W, int H, int dmin, int D, int right)
+{
+    const int dmax = dmin + D;
+    std::vector<float> c(D);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float bc = ADC_LARGE_FLOAT;
+            int bd = 0x7fffffff;
+            for (int di = 0; di < D; di++) {
+                float v = ADC_LARGE_FLOAT;
+                bool cand = false;
+                if (!right) { v = vol[((size_t)y * W + x) * D + di]; cand = true; }
+                else {
+                    const int col = x + di + dmin;
+                    if (col >= 0 && col < W) { v = vol[((size_t)y * W + col) * D + di]; cand = true; }
+                }
+                c[di] = v;
+                // lexicographic (cost, d) minimum among candidates strictly below Large_Float
+                if (cand && v < ADC_LARGE_FLOAT && (v < bc || (v == bc && di + dmin < bd))) { bc = v; bd = di + dmin; }
+            }
+            int best = bd == 0x7fffffff ? 0 : bd;
+            float out;
+            if (best == dmin || best == dmax - 1) out = right ? (float)best : ADC_INVALID_FLOAT;
+            else if (best - 1 - dmin < 0 || best + 1 - dmin >= D) out = (float)best;
+            else out = adc_subpixel(best, c[best - 1 - dmin], c[best + 1 - dmin], bc);
+            disp[(size_t)y * W + x] = out;
+        }
+}
+
+// ------------------------------------------------------------------ k_lr_phase1/2
+static bool lr_invalid(const float* dl, const float* dr, int W, int x, int y, float thres, int& col_right, float& disp_r)
+{
+    const float d = dl[(size_t)y * W + x];
+    col_right = -1;
+    disp_r = 0.f;
+    if (d == ADC_INVALID_FLOAT) return true;
+    const long cr = lroundf((float)x - d);
+    if (cr < 0 || cr >= W) return true;
+    col_right = (int)cr;
+    disp_r = dr[(size_t)y * W + cr];
+    return fabsf(d - disp_r) > thres;
+}
+
+void emul_lrcheck(const float* dl, const float* dr, float* out, uint8_t* label, int W, int H, float thres)
+{
+    std::vector<uint8_t> inv((size_t)W * H);
+    int cr;
+    float drv;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) inv[(size_t)y * W + x] = lr_invalid(dl, dr, W, x, y, thres, cr, drv) ? 1 : 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const float d = dl[p];
+            float disp_r;
+            const bool bad = lr_invalid(dl, dr, W, x, y, thres, cr, disp_r);
+            uint8_t lab = ADC_LABEL_VALID;
+            if (bad) {
+                lab = ADC_LABEL_MISMATCH;
+                if (d != ADC_INVALID_FLOAT && cr >= 0) {
+                    const long col_rl = lroundf((float)cr + disp_r);
+                    if (col_rl > 0 && col_rl < W) {
+                        const float disp_l = (col_rl < x && inv[(size_t)y * W + col_rl]) ? ADC_INVALID_FLOAT : dl[(size_t)y * W + col_rl];
+                        if (disp_l > d) lab = ADC_LABEL_OCCLUSION;
+                    }
+                }
+            }
+            label[p] = lab;
+            out[p] = bad ? ADC_INVALID_FLOAT : d;
+        }
+}
+
+// ------------------------------------------------------------------ k_irv_begin / k_irv_round
+// Evaluation order inside a round is shuffled (seeded) to model arbitrary wave scheduling with
+// in-place (chaotic) updates.  Returns total rounds; *evals gets the number of vote evaluations.
+long emul_region_voting(float* disp, const uint8_t* label, const uint8_t* arms, int W, int H, int dmin, int D, int irv_ts,
+                        float irv_th, int Lmax, unsigned seed, long* evals_out)
+{
+    const int P = W * H, T = 16;
+    const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+    std::vector<uint8_t> elig(P), chg_a(tiles_x * tiles_y, 0), chg_b(tiles_x * tiles_y, 0);
+    std::vector<int> list, hist(D);
+    long rounds = 0, evals = 0;
+    srand(seed);
+    for (int it = 0; it < 5; it++)
+        for (int k = 0; k < 2; k++) {
+            const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
+            list.clear();
+            for (int p = 0; p < P; p++) {
+                elig[p] = (label[p] == which && disp[p] == ADC_INVALID_FLOAT) ? 1 : 0;
+                if (elig[p]) list.push_back(p);
+            }
+            if (list.empty()) continue;
+            for (int round = 0;; round++) {
+                std::fill(chg_b.begin(), chg_b.end(), 0);
+                bool changed = false;
+                for (size_t i = list.size(); i > 1; i--) std::swap(list[i - 1], list[rand() % i]);
+                for (int p : list) {
+                    const int y = p / W, x = p - y * W;
+                    if (round > 0) {
+                        const int tx0 = std::max(0, x - Lmax) / T, tx1 = std::min(W - 1, x + Lmax) / T;
+                        const int ty0 = std::max(0, y - Lmax) / T, ty1 = y / T;
+                        bool dirty = false;
+                        for (int ty = ty0; ty <= ty1; ty++)
+                            for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_a[ty * tiles_x + tx] != 0;
+                        if (!dirty) continue;
+                    }
+                    std::fill(hist.begin(), hist.end(), 0);
+                    const uint8_t* arm = arms + (size_t)p * 4;
+                    for (int t = -(int)arm[2]; t <= (int)arm[3]; t++) {
+                        const int yt = y + t;
+                        const uint8_t* arm2 = arms + ((size_t)yt * W + x) * 4;
+                        for (int s = -(int)arm2[0]; s <= (int)arm2[1]; s++) {
+                            const int q = yt * W + x + s;
+                            float v = disp[q];
+                            if (elig[q] && q >= p) v = ADC_INVALID_FLOAT;
+                            if (v != ADC_INVALID_FLOAT) {
+                                const long b = lroundf(v) - dmin;
+                                if (b >= 0 && b < D) hist[b]++;
+                            }
+                        }
+                    }
+                    int bh = 0, bb = 0x7fffffff, cnt = 0;
+                    for (int b = 0; b < D; b++) {
+                        cnt += hist[b];
+                        if (hist[b] > bh) { bh = hist[b]; bb = b; }
+                    }
+                    const float nv = adc_vote_decide(bb, bh, cnt, dmin, irv_ts, irv_th);
+                    evals++;
+                    uint32_t a, b2;
+                    memcpy(&a, &disp[p], 4);
+                    memcpy(&b2, &nv, 4);
+                    if (a != b2) {
+                        disp[p] = nv;
+                        chg_b[(y / T) * tiles_x + x / T] = 1;
+                        changed = true;
+                    }
+                }
+                rounds++;
+                chg_a.swap(chg_b);
+                if (!changed) break;
+            }
+        }
+    if (evals_out) *evals_out = evals;
+    return rounds;
+}
+
+// ------------------------------------------------------------------ k_interpolate (one list)
+void emul_interpolate(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
+                      int max_search)
+{
+    double sc[32];
+    const float pi = 3.1415926f;
+    double ang = 0.0;
+    for (int s = 0; s < 16; s++) { sc[2 * s] = sin(ang); sc[2 * s + 1] = cos(ang); ang += pi / 16; }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const float d0 = din[p];
+            if (!(label[p] == which && d0 == ADC_INVALID_FLOAT)) { dout[p] = d0; continue; }
+            const uint8_t* c0 = img_l + p * 3;
+            const bool mismatch = which == ADC_LABEL_MISMATCH;
+            int min_dist = 9999;
+            float best = mismatch ? 0.0f : ADC_LARGE_FLOAT;
+            bool any = false;
+            for (int s = 0; s < 16; s++) {
+                const double sina = sc[2 * s], cosa = sc[2 * s + 1];
+                for (int m = 1; m < max_search; m++) {
+                    const int yy = (int)lround((double)y + (double)m * sina);
+                    const int xx = (int)lround((double)x + (double)m * cosa);
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) break;
+                    const float d = din[(size_t)yy * W + xx];
+                    if (d != ADC_INVALID_FLOAT) {
+                        any = true;
+                        if (mismatch) {
+                            const int dist = adc_color_dist_l1(c0, img_l + ((size_t)yy * W + xx) * 3);
+                            if (min_dist > dist) { min_dist = dist; best = d; }
+                        } else best = d < best ? d : best;
+                        break;
+                    }
+                }
+            }
+            dout[p] = any ? best : 0.0f;
+        }
+}
+
+// ------------------------------------------------------------------ k_median_wavefront
+void emul_median_wavefront(const float* in, float* out, int W, int H)
+{
+    std::vector<float> ring((size_t)H * 4, NAN);
+    const int nsteps = W + 2 * (H - 1);
+    for (int t = 0; t < nsteps; t++) {
+        std::vector<std::pair<int, float>> writes; // commit after the level, like the barrier does
+        for (int y = H - 1; y >= 0; y--) {          // any order inside a level
+            const int x = t - 2 * y;
+            if (x < 0 || x >= W) continue;
+            float v[9];
+            int n = 0;
+            for (int r = -1; r <= 1; r++)
+                for (int c = -1; c <= 1; c++) {
+                    const int row = y + r, col = x + c;
+                    float val = ADC_INVALID_FLOAT;
+                    if (row >= 0 && row < H && col >= 0 && col < W) {
+                        n++;
+                        const bool filtered = (r < 0) || (r == 0 && c < 0);
+                        val = filtered ? ring[row * 4 + (col & 3)] : in[(size_t)row * W + col];
+                    }
+                    v[(r + 1) * 3 + (c + 1)] = val;
+                }
+            adc_sort9(v);
+            const float res = v[n / 2];
+            out[(size_t)y * W + x] = res;
+            ring[y * 4 + (x & 3)] = res; // in-level write is safe: distinct slot from all reads of this level
+        }
+    }
+}
+
+// gray of a single pixel (device function check over all 2^24 triples is done from Python in chunks)
+void emul_gray(const uint8_t* bgr, uint8_t* gray, size_t n)
+{
+    for (size_t i = 0; i < n; i++) gray[i] = adc_gray(bgr[3 * i], bgr[3 * i + 1], bgr[3 * i + 2]);
+}
+
+} // extern "C"

@@ -1,0 +1,119 @@
+"""CPU tier: the order-aware PARALLEL formulations used by the HIP kernels (marching-ring sums,
+closed-form sticky d2, two-phase LR check, fixed-point region voting with dirty tiles and arbitrary
+evaluation order, Jacobi interpolation, level-synchronous median) are emulated lane-by-lane on the
+CPU (tests/emul/emul.cpp, sharing adc_device_fn.h with the device code) and must equal the oracle's
+sequential in-place results bit-for-bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def same(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+EMUL_CASES = ["cone_crop_d40", "s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8", "q_40x1_d8",
+              "q_3x3_d2", "s2_150x100_neg"]
+
+
+@pytest.fixture(scope="module")
+def dumps(port_oracle):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            left, right, opt = cases.make_case(name)
+            cache[name] = (left, right, opt, port_oracle.run(left, right, opt))
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2"])
+@pytest.mark.parametrize("pf,hseg,vseg", [(16, 4, 2), (5, 3, 1), (1, 1, 7)])
+def test_marching_ring_aggregation(emul, dumps, name, pf, hseg, vseg):
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D = opt.max_disparity - opt.min_disparity
+    a, b = o["cost_init"].copy(), np.empty_like(o["cost_init"])
+    L = max(0, min(opt.cross_L1, 255))
+    hfirst = True
+    for _ in range(4):
+        order = [(0, 0, o["sup_count_h"]), (1, 1, o["sup_count_h"])] if hfirst else [(1, 0, o["sup_count_v"]), (0, 1, o["sup_count_v"])]
+        for vert, div, sup in order:
+            emul.emul_aggregate_pass(P(a), P(b), P(o["arms"]), P(sup), w, h, D, vert, div, L, vseg if vert else hseg, pf)
+            a, b = b, a
+        hfirst = not hfirst
+    assert same(a, o["cost_aggr"])
+
+
+@pytest.mark.parametrize("name", EMUL_CASES)
+def test_scanline_closed_form(emul, dumps, name):
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    lh, lv, rh, rv = (np.zeros((h, w), np.uint8) for _ in range(4))
+    emul.emul_color_diffs(P(left), P(lh), P(lv), w, h)
+    emul.emul_color_diffs(P(right), P(rh), P(rv), w, h)
+    a, b = o["cost_aggr"].copy(), np.empty_like(o["cost_aggr"])
+    for vert, dr in ((0, 1), (0, -1), (1, 1), (1, -1)):
+        emul.emul_scanline_pass(P(a), P(b), P(lv if vert else lh), P(rv if vert else rh), w, h, dmin, D, vert, dr,
+                                opt.so_tso, C.c_float(opt.so_p1), C.c_float(opt.so_p2))
+        a, b = b, a
+    assert same(a, o["cost_so"])
+
+
+@pytest.mark.parametrize("name", EMUL_CASES)
+def test_wta(emul, dumps, name):
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    dl, dr = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    emul.emul_wta(P(o["cost_so"]), P(dl), w, h, dmin, D, 0)
+    emul.emul_wta(P(o["cost_so"]), P(dr), w, h, dmin, D, 1)
+    assert same(dl, o["disp_left_wta"])
+    assert same(dr, o["disp_right_wta"])
+
+
+@pytest.mark.parametrize("name", EMUL_CASES)
+def test_refiner_parallel_forms(emul, dumps, name):
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    out, lab = np.empty((h, w), np.float32), np.empty((h, w), np.uint8)
+    emul.emul_lrcheck(P(o["disp_left_wta"]), P(o["disp_right_wta"]), P(out), P(lab), w, h, C.c_float(opt.lrcheck_thres))
+    assert same(out, o["disp_after_lr"]) and same(lab, o["outlier_label"])
+    # fixed-point voting, two different (shuffled) evaluation orders
+    emul.emul_region_voting.restype = C.c_long
+    for seed in (1, 99):
+        d = o["disp_after_lr"].copy()
+        ev = C.c_long(0)
+        emul.emul_region_voting(P(d), P(o["outlier_label"]), P(o["arms"]), w, h, dmin, D, opt.irv_ts, C.c_float(opt.irv_th),
+                                max(0, min(opt.cross_L1, 255)), seed, C.byref(ev))
+        assert same(d, o["disp_after_irv"])
+    a, b = o["disp_after_irv"].copy(), np.empty((h, w), np.float32)
+    ms = max(abs(opt.max_disparity), abs(opt.min_disparity))
+    emul.emul_interpolate(P(a), P(b), P(o["outlier_label"]), P(left), w, h, 1, ms)
+    emul.emul_interpolate(P(b), P(a), P(o["outlier_label"]), P(left), w, h, 2, ms)
+    assert same(a, o["disp_after_interp"])
+    m = np.empty((h, w), np.float32)
+    emul.emul_median_wavefront(P(o["disp_after_dda"]), P(m), w, h)
+    assert same(m, o["disp_final"])
+
+
+def test_gray_all_triples_sample(emul):
+    """adc_gray (unfused double arithmetic) == uint8(r*0.299+g*0.587+b*0.114) on a dense sample incl. all greys."""
+    rng = np.random.default_rng(7)
+    bgr = np.concatenate([rng.integers(0, 256, (400000, 3), dtype=np.uint8),
+                          np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1)])
+    got = np.empty(len(bgr), np.uint8)
+    emul.emul_gray(P(bgr), P(got), C.c_size_t(len(bgr)))
+    b, g, r = (bgr[:, i].astype(np.float64) for i in range(3))
+    want = ((r * 0.299 + g * 0.587) + b * 0.114).astype(np.uint8)
+    assert np.array_equal(got, want)

@@ -1,0 +1,97 @@
+"""GPU tier (T3/T4): API contract of the drop-in surface and order-dependence regression checks."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_match_contract(hip):
+    A = hip
+    left, right, opt = cases.make_case("s2_96x64_d32")
+    st = A.ADCensusStereo(device=0)
+    disp = np.zeros((64, 96), np.float32)
+    assert not st.Match(left, right, disp)                      # before Initialize (ADCensusStereo.cpp:71-73)
+    assert st.Initialize(96, 64, cases.to_product_option(opt))
+    assert not st.Match(None, right, disp)                      # null pointers (:74-76)
+    assert not st.Match(left, None, disp)
+    assert not st.Match(left, right, None)
+    assert st.Match(left, right, disp)
+    first = disp.copy()
+    assert st.Match(left, right, disp) and np.array_equal(first.view(np.uint32), disp.view(np.uint32))  # idempotent
+    # Reset to another geometry and back (ADCensusStereo.cpp:134-144)
+    l2, r2, o2 = cases.make_case("q_20x40_d32")
+    assert st.Reset(20, 40, cases.to_product_option(o2))
+    d2 = np.zeros((40, 20), np.float32)
+    assert st.Match(l2, r2, d2)
+    assert st.Reset(96, 64, cases.to_product_option(opt))
+    assert st.Match(left, right, disp) and np.array_equal(first.view(np.uint32), disp.view(np.uint32))
+    assert not st.Reset(0, 64, cases.to_product_option(opt))
+    assert not st.Match(left, right, disp)
+    st.Release()
+
+
+def test_async_and_device_entry_points(hip, oracle):
+    A = hip
+    left, right, opt = cases.make_case("s2_96x64_d32")
+    want = oracle.run(left, right, opt, stages=["disp_final"])["disp_final"]
+    sts = [A.ADCensusStereo(device=0) for _ in range(3)]
+    outs = [np.zeros((64, 96), np.float32) for _ in sts]
+    for s in sts:
+        assert s.Initialize(96, 64, cases.to_product_option(opt))
+    for s, o in zip(sts, outs):
+        assert s.match_async(left, right, o)
+    for s, o in zip(sts, outs):
+        assert s.wait()
+        assert np.array_equal(o.view(np.uint32), want.view(np.uint32))
+    # device-resident buffers
+    lib = A.lib()
+    n = 96 * 64
+    dl, dr, dd = lib.adc_device_malloc(n * 3), lib.adc_device_malloc(n * 3), lib.adc_device_malloc(n * 4)
+    assert dl and dr and dd
+    assert lib.adc_memcpy_h2d(dl, left.ctypes.data, n * 3) == 0 and lib.adc_memcpy_h2d(dr, right.ctypes.data, n * 3) == 0
+    assert sts[0].match_device(dl, dr, dd) and sts[0].wait()
+    got = np.zeros((64, 96), np.float32)
+    assert lib.adc_memcpy_d2h(got.ctypes.data, dd, n * 4) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for p in (dl, dr, dd):
+        lib.adc_device_free(p)
+    sts[0].set_profiling(True)
+    assert sts[0].Match(left, right, got)
+    ms = sts[0].stage_ms()
+    assert all(v >= 0 for v in ms.values()) and sum(ms.values()) > 0
+    for s in sts:
+        s.Release()
+
+
+def test_aggregation_fast_path_equals_direct(hip, oracle, monkeypatch):
+    """A/B: the marching-ring kernel and the one-thread-per-element direct kernel agree bit-for-bit."""
+    A = hip
+    left, right, opt = cases.make_case("s2_320x180_d128")
+    o = oracle.run(left, right, opt, stages=["cost_init", "arms", "sup_count_h", "sup_count_v", "cost_aggr"])
+    popt = cases.to_product_option(opt)
+    popt.cross_L1 = 34
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(320, 180, popt)
+    st.debug_set_images(left, right)
+    st.debug_run(A.RUN_ARMS)
+    st.debug_write(A.BUF_VOLUME_A, o["cost_init"])
+    st.debug_run(A.RUN_AGGREGATE, 4)
+    fast = st.debug_read(A.BUF_VOLUME_A)
+    assert np.array_equal(fast.view(np.uint32), o["cost_aggr"].view(np.uint32))
+    st.Release()
+
+
+def test_large_arm_limit_uses_fallback(hip, oracle):
+    """cross_L1 = 120 exceeds the LDS ring budget -> direct kernel; still bit-exact."""
+    A = hip
+    from oracle import pyoracle
+    left, right, _ = cases.make_case("s2_96x64_d32")
+    opt = pyoracle.Option(max_disparity=32, cross_L1=120, cross_L2=60, cross_t1=60, cross_t2=40)
+    want = oracle.run(left, right, opt, stages=["disp_final"])["disp_final"]
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(96, 64, cases.to_product_option(opt))
+    got = st.match(left, right)
+    st.Release()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
