@@ -42,7 +42,9 @@ struct adc_handle {
     uint64_t *census_l, *census_r;
     uint8_t* arms;
     uint16_t *sup_h, *sup_v;
+    uint32_t *rec_h, *rec_v; // packed {arm_lo, arm_hi, divisor} per pixel, line-major (rec_v transposed)
     uint8_t *cdiff_lh, *cdiff_lv, *cdiff_rh, *cdiff_rv;
+    uint8_t* so_cls; // [4 passes][H][W][64] packed 2-bit scanline penalty classes per lane
     // volumes
     float *vol_a, *vol_b;
     // host-built tables: same libm as the CPU reference
@@ -55,6 +57,7 @@ struct adc_handle {
     uint8_t* label;
     uint8_t* elig;       // region voting: eligible mask of the current pass
     int32_t* vote_list;  // compact list of eligible pixels
+    int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
     int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...
     uint8_t *chg_a, *chg_b; // changed-tile maps (previous / next round)
     uint8_t* edge;       // discontinuity adjustment edge mask
@@ -80,7 +83,9 @@ struct adc_handle {
 hipError_t adc_launch_gray_census(adc_handle* h);
 hipError_t adc_launch_cost(adc_handle* h, float* vol_out);
 hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps
+hipError_t adc_launch_records(adc_handle* h); // arms + counts -> packed aggregation records
 hipError_t adc_launch_aggregate(adc_handle* h, int iterations); // vol_a -> vol_a via vol_b
+hipError_t adc_launch_so_classes(adc_handle* h);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_lrcheck(adc_handle* h);

@@ -65,10 +65,13 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->arms, P * 4));
     HIP_OK(hipMalloc(&h->sup_h, P * 2));
     HIP_OK(hipMalloc(&h->sup_v, P * 2));
+    HIP_OK(hipMalloc(&h->rec_h, P * 4));
+    HIP_OK(hipMalloc(&h->rec_v, P * 4));
     HIP_OK(hipMalloc(&h->cdiff_lh, P));
     HIP_OK(hipMalloc(&h->cdiff_lv, P));
     HIP_OK(hipMalloc(&h->cdiff_rh, P));
     HIP_OK(hipMalloc(&h->cdiff_rv, P));
+    HIP_OK(hipMalloc(&h->so_cls, P * 64 * 4));
     HIP_OK(hipMalloc(&h->vol_a, VB));
     HIP_OK(hipMalloc(&h->vol_b, VB));
     HIP_OK(hipMalloc(&h->lut_ad, 768 * sizeof(float)));
@@ -80,10 +83,11 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->label, P));
     HIP_OK(hipMalloc(&h->elig, P));
     HIP_OK(hipMalloc(&h->vote_list, P * 4));
-    HIP_OK(hipMalloc(&h->vote_counters, 16 * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&h->vote_dirty, P * 4));
+    HIP_OK(hipMalloc(&h->vote_counters, 256 * sizeof(int32_t)));
     const size_t tiles = (size_t)((p.W + 15) / 16) * ((p.H + 15) / 16);
-    HIP_OK(hipMalloc(&h->chg_a, tiles));
-    HIP_OK(hipMalloc(&h->chg_b, tiles));
+    HIP_OK(hipMalloc(&h->chg_a, tiles * 4));
+    HIP_OK(hipMalloc(&h->chg_b, tiles * 4));
     HIP_OK(hipMalloc(&h->edge, P));
     HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
@@ -171,8 +175,8 @@ void adc_destroy(adc_handle* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
-                    h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->vote_list, h->vote_counters,
+                    h->rec_h, h->rec_v, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
+                    h->ray_sincos, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->vote_list, h->vote_dirty, h->vote_counters,
                     h->chg_a, h->chg_b, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
@@ -211,6 +215,7 @@ static hipError_t run_pipeline(adc_handle* h)
     MARK(1);
     HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
     MARK(2);
+    HIP_OK(adc_launch_records(h));
     HIP_OK(adc_launch_aggregate(h, 4));          // aggregator_.Aggregate(4), :164
     MARK(3);
     HIP_OK(adc_launch_scanline(h, 4));           // ScanlineOptimize, :100
@@ -387,7 +392,10 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     case ADC_RUN_GRAY_CENSUS: e = adc_launch_gray_census(h); break;
     case ADC_RUN_COST: e = adc_launch_cost(h, h->vol_a); break;
     case ADC_RUN_ARMS: e = adc_launch_arms(h); break;
-    case ADC_RUN_AGGREGATE: e = adc_launch_aggregate(h, arg > 0 ? arg : 4); break;
+    case ADC_RUN_AGGREGATE:
+        e = adc_launch_records(h);
+        if (e == hipSuccess) e = adc_launch_aggregate(h, arg > 0 ? arg : 4);
+        break;
     case ADC_RUN_SCANLINE: e = adc_launch_scanline(h, arg); break;
     case ADC_RUN_WTA: e = adc_launch_wta(h); break;
     case ADC_RUN_LRCHECK: e = adc_launch_lrcheck(h); break;

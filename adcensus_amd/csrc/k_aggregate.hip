@@ -18,8 +18,6 @@
 #include "adc_internal.h"
 #include "adc_device_fn.h"
 
-#define AGG_PF 16  // loads in flight per wave (x 256 B)
-
 // ------------------------------------------------------------------------------- direct (fallback)
 // One thread per volume element reading its arm span straight from global memory.  Used when the
 // LDS ring does not fit (cross_L1 > 79) and as an A/B cross-check of the marching kernel in tests.
@@ -43,22 +41,61 @@ __global__ __launch_bounds__(256) void k_agg_direct(const float* __restrict__ sr
 }
 
 // ---------------------------------------------------------------------------------- marching ring
+// One 64-lane workgroup (= one wave) per line segment.
+//   * LDS per wave = (2L+1) x 256 B (17.25 KiB at L = 34) => 9 waves per CU, 2304 chip-wide: all 2160
+//     H-lines of a 1080p / D=128 volume run in ONE round;
+//   * the next AGG_PF entries and their packed {arm_lo, arm_hi, count} records are in flight in
+//     registers.  These prefetch loads are issued from inline asm and waited for with a hand-counted
+//     s_waitcnt vmcnt: hipcc's loop-carried vmcnt model otherwise drains the queue to a depth of ~3 steps
+//     (tools/ubench/agg_lean.hip vs agg_asm.hip).  VMEM ops per steady-state step, in program order:
+//     [data load][record load] ... [output store]; vmcnt retires in order on gfx9-family hardware.
+// Measured (tools/ubench): the same load/store structure without the ordered sum streams at the
+// float4-copy rate (4.8-5.4 TB/s on MI355X); the full step is bound by its dependent chain
+// (LDS write -> LDS reads -> ordered adds -> store) at 9 waves per CU.
+#define AGG_PF 8
+
+// ordered partial sum over cnt consecutive ring entries starting at q (lane-private column, stride 64 floats)
+__device__ __forceinline__ float agg_run(float acc, const float* q, int cnt)
+{
+    while (cnt >= 8) {
+        const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192], t4 = q[256], t5 = q[320], t6 = q[384], t7 = q[448];
+        acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; acc += t6; acc += t7;
+        q += 512;
+        cnt -= 8;
+    }
+    switch (cnt) { // exact-length tail (reads only what it adds)
+    case 7: { const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192], t4 = q[256], t5 = q[320], t6 = q[384];
+              acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; acc += t6; } break;
+    case 6: { const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192], t4 = q[256], t5 = q[320];
+              acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; } break;
+    case 5: { const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192], t4 = q[256];
+              acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; } break;
+    case 4: { const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192]; acc += t0; acc += t1; acc += t2; acc += t3; } break;
+    case 3: { const float t0 = q[0], t1 = q[64], t2 = q[128]; acc += t0; acc += t1; acc += t2; } break;
+    case 2: { const float t0 = q[0], t1 = q[64]; acc += t0; acc += t1; } break;
+    case 1: acc += q[0]; break;
+    default: break;
+    }
+    return acc;
+}
+
 template <bool VERT, bool DIVIDE>
-__global__ __launch_bounds__(256) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
-                                                   const uchar4* __restrict__ arms, const uint16_t* __restrict__ sup,
-                                                   int W, int H, int Dp, int L, int seg_len, int nseg)
+__global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
+                                                  const uint32_t* __restrict__ rec, // {lo, hi, count16} per pixel, line-major
+                                                  int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd)
 {
     extern __shared__ __attribute__((aligned(16))) float ring_all[];
     const int R = 2 * L + 1;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    float* ring = ring_all + (size_t)wave * R * 64 + lane; // entry s at ring[s*64]
+    const int lane = threadIdx.x;
+    float* ring = ring_all + lane; // entry s at ring[s*64]; each lane only reads what it wrote
 
     const int chunks = Dp >> 6;                 // 64-float chunks per pixel
     const int N = VERT ? H : W;                 // length of a line
     const int nlines = (VERT ? W : H) * chunks; // independent lines
-    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
-    if (gw >= nlines * nseg) return;
+    // XCD-aware mapping: hardware places block b on XCD b % 8; give each XCD a contiguous band of lines
+    const int b = (int)blockIdx.x;
+    const int gw = (b & 7) * per_xcd + (b >> 3);
+    if ((b >> 3) >= per_xcd || gw >= nlines * nseg) return;
     const int seg = gw / nlines;
     const int line = gw - seg * nlines;
     const int fixed = line / chunks; // x (V pass) or y (H pass)
@@ -70,97 +107,132 @@ __global__ __launch_bounds__(256) void k_agg_march(const float* __restrict__ src
     const int lo = adc_imax(0, m0 - L);
     const int hi = adc_imin(N, m1 + L);
 
-    // element (m) of this line: pixel index and float offset
+    // element m of this line
     const long long pix_step = VERT ? (long long)W : 1LL;
     const long long pix0 = VERT ? (long long)fixed : (long long)fixed * W;
     const long long fstep = pix_step * Dp;
     const float* sp = src + pix0 * Dp + chunk * 64 + lane;
     float* dp = dst + pix0 * Dp + chunk * 64 + lane;
+    const uint32_t* rp = rec + (long long)fixed * N; // records of this line, contiguous along m
 
-    // Software prefetch: the next AGG_PF line entries (and the arms / counts of the outputs they will
-    // trigger) are in flight in registers.  All prefetch loads are UNCONDITIONAL (index clamped into
-    // the segment) -- a load under a branch makes the compiler drain vmcnt at the join.
-    auto pix_of = [&](int m) __attribute__((always_inline)) -> long long { return pix0 + (long long)m * pix_step; };
-    float pf[AGG_PF];
-    uint32_t pa[AGG_PF]; // arms (uchar4 as u32) of output m = entry - L
-    uint32_t ps[AGG_PF]; // support count of that output (DIVIDE passes)
-    const uint32_t* arms32 = reinterpret_cast<const uint32_t*>(arms);
+    int slot_w = 0;          // ring slot of the next entry to be written
+    int slot_m = m0 - lo;    // ring slot of entry m0 (<= L < R)
+
+#define AGG_PUSH(V)                                \
+    do {                                           \
+        ring[slot_w * 64] = (V);                   \
+        slot_w = slot_w + 1 == R ? 0 : slot_w + 1; \
+    } while (0)
+
+#define AGG_EMIT(M, REC)                                                                          \
+    do {                                                                                          \
+        const uint32_t r_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(REC));                \
+        const int a_lo_ = (int)(r_ & 255u), a_hi_ = (int)((r_ >> 8) & 255u);                      \
+        int idx_ = slot_m - a_lo_;                                                                \
+        if (idx_ < 0) idx_ += R;                                                                  \
+        const int n_ = a_lo_ + a_hi_ + 1;                                                         \
+        const int n1_ = adc_imin(n_, R - idx_);                                                   \
+        float acc_ = agg_run(0.0f, ring + idx_ * 64, n1_); /* order t = -arm .. +arm */          \
+        if (n_ > n1_) acc_ = agg_run(acc_, ring, n_ - n1_); /* wrapped part of the ring */       \
+        if (DIVIDE) {                                                                             \
+            const uint32_t c_ = r_ >> 16;                                                         \
+            if (c_ != 1u) acc_ = acc_ / (float)c_; /* cross_aggregator.cpp:389 (x/1 == x) */     \
+        }                                                                                         \
+        dp[(long long)(M)*fstep] = acc_;                                                          \
+        slot_m = slot_m + 1 == R ? 0 : slot_m + 1;                                                \
+    } while (0)
+
+    // ---- phase A: entries lo .. jB-1 that precede the first output's look-ahead (no output yet)
+    const int jB = adc_imin(hi, m0 + L);
+    for (int j = lo; j < jB; j += AGG_PF) {
+        float t[AGG_PF];
 #pragma unroll
-    for (int u = 0; u < AGG_PF; u++) {
-        const int e = adc_imin(lo + u, hi - 1);
-        const int mo = adc_imin(adc_imax(e - L, m0), m1 - 1);
-        pf[u] = sp[(long long)e * fstep];
-        pa[u] = arms32[pix_of(mo)];
-        ps[u] = DIVIDE ? (uint32_t)sup[pix_of(mo)] : 1u;
+        for (int u = 0; u < AGG_PF; u++) t[u] = sp[(long long)adc_imin(j + u, jB - 1) * fstep];
+#pragma unroll
+        for (int u = 0; u < AGG_PF; u++)
+            if (j + u < jB) AGG_PUSH(t[u]);
     }
 
-    int slot_w = 0;                 // ring slot of the next entry to be written
-    int slot_m = (m0 - lo);         // ring slot of entry m0 (m0 - lo <= L < R)
-
-    auto emit = [&](int m, uint32_t a32, uint32_t cnt) __attribute__((always_inline)) {
-        const int a_lo = __builtin_amdgcn_readfirstlane((int)(VERT ? (a32 >> 16) & 255u : a32 & 255u));
-        const int a_hi = __builtin_amdgcn_readfirstlane((int)(VERT ? (a32 >> 24) & 255u : (a32 >> 8) & 255u));
-        int n = a_lo + a_hi + 1;
-        int idx = slot_m - a_lo;
-        if (idx < 0) idx += R;
-        float acc = 0.0f;
-        while (n > 0) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                int s = idx + k;
-                if (s >= R) s -= R;
-                v[k] = ring[s * 64];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k < n) acc += v[k]; // sequential order t = -arm .. +arm
-            idx += 8;
-            if (idx >= R) idx -= R;
-            n -= 8;
-        }
-        if (DIVIDE) acc = acc / (float)cnt; // cross_aggregator.cpp:389
-        dp[(long long)m * fstep] = acc;
-        slot_m++;
-        if (slot_m == R) slot_m = 0;
-    };
-
-    int j = lo;
-    for (; j + AGG_PF <= hi; j += AGG_PF) {
+    // ---- phase B (steady state): entry jj arrives, output m = jj - L leaves.
+    // All compiler-tracked VMEM traffic of phase A is drained first, so the manual vmcnt bookkeeping
+    // below starts from an empty queue.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float pf[AGG_PF];
+    uint32_t pr[AGG_PF];
+    int j = jB;
+    // The asm-prefetch loop needs every refill index valid without clamping: j + 2*AGG_PF <= hi.
+    if (j + 2 * AGG_PF <= hi) {
+        const float* spn = sp + (long long)j * fstep;       // next entry to prefetch
+        const uint32_t* rpn = rp + (j - L);                 // record of the output that entry triggers (>= m0)
 #pragma unroll
         for (int u = 0; u < AGG_PF; u++) {
-            const int jj = j + u;
-            const float v = pf[u];
-            const uint32_t a32 = pa[u], cnt = ps[u];
-            {
-                const int e = adc_imin(jj + AGG_PF, hi - 1);
-                const int mo = adc_imin(adc_imax(e - L, m0), m1 - 1);
-                pf[u] = sp[(long long)e * fstep];
-                pa[u] = arms32[pix_of(mo)];
-                if (DIVIDE) ps[u] = (uint32_t)sup[pix_of(mo)];
-            }
-            ring[slot_w * 64] = v;
-            slot_w++;
-            if (slot_w == R) slot_w = 0;
-            const int m = jj - L;
-            if (m >= m0 && m < m1) emit(m, a32, cnt);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf[u]) : "v"(spn) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pr[u]) : "v"(rpn) : "memory");
+            spn += fstep;
+            rpn += 1;
         }
-    }
-    // remainder (< AGG_PF entries): their values / arms are already in the registers
+// one steady-state step; WAITN = number of VMEM ops younger than slot U's two loads that may stay in flight
+#define AGG_STEP(U, WAITN)                                                                                       \
+    do {                                                                                                         \
+        float v_;                                                                                                \
+        uint32_t rr_;                                                                                            \
+        /* wait and read the landed registers in ONE statement: a separate "+v" wait lets hipcc copy the      */ \
+        /* (not yet landed) registers ABOVE the wait (tied-operand copies), i.e. read garbage                 */ \
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                              \
+                     : "=&v"(v_), "=&v"(rr_) : "v"(pf[U]), "v"(pr[U]), "n"(WAITN) : "memory");                   \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf[U]) : "v"(spn) : "memory");                       \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pr[U]) : "v"(rpn) : "memory");                       \
+        spn += fstep;                                                                                            \
+        rpn += 1;                                                                                                \
+        AGG_PUSH(v_);                                                                                            \
+        AGG_EMIT(j + (U)-L, rr_); /* exactly one compiler-issued VMEM op (the store) */                          \
+    } while (0)
+        // first iteration: the younger ops are the prologue loads of slots U+1.. (2 each) and the U steps
+        // already done (3 each): 2*(AGG_PF-1-U) + 3*U = 2*AGG_PF - 2 + U
+        static_assert(AGG_PF == 8, "the peeled first iteration below is written for AGG_PF == 8");
+        AGG_STEP(0, 14); AGG_STEP(1, 15); AGG_STEP(2, 16); AGG_STEP(3, 17);
+        AGG_STEP(4, 18); AGG_STEP(5, 19); AGG_STEP(6, 20); AGG_STEP(7, 21);
+        j += AGG_PF;
+        // steady state: younger ops = this slot's own store + 3 per younger step = 3*(AGG_PF-1)+1; we wait for
+        // <= 3*(AGG_PF-1) outstanding (one stricter).  vmcnt retires in order (loads and stores) on gfx9-family.
+        for (; j + 2 * AGG_PF <= hi; j += AGG_PF) {
 #pragma unroll
-    for (int u = 0; u < AGG_PF; u++) {
-        const int jj = j + u;
-        if (jj < hi) {
-            ring[slot_w * 64] = pf[u];
-            slot_w++;
-            if (slot_w == R) slot_w = 0;
-            const int m = jj - L;
-            if (m >= m0 && m < m1) emit(m, pa[u], ps[u]);
+            for (int u = 0; u < AGG_PF; u++) AGG_STEP(u, 3 * (AGG_PF - 1));
         }
+#undef AGG_STEP
+        // the AGG_PF entries still in flight are entries j .. j+AGG_PF-1 (all < hi)
+        // drain: the AGG_PF entries still in flight are entries j .. j+AGG_PF-1 (all < hi); read them inside the
+        // same statement as the wait (see AGG_STEP)
+        float df[AGG_PF];
+        uint32_t dr[AGG_PF];
+        asm volatile("s_waitcnt vmcnt(0)\n\t"
+                     "v_mov_b32 %0, %16\n\tv_mov_b32 %1, %17\n\tv_mov_b32 %2, %18\n\tv_mov_b32 %3, %19\n\t"
+                     "v_mov_b32 %4, %20\n\tv_mov_b32 %5, %21\n\tv_mov_b32 %6, %22\n\tv_mov_b32 %7, %23\n\t"
+                     "v_mov_b32 %8, %24\n\tv_mov_b32 %9, %25\n\tv_mov_b32 %10, %26\n\tv_mov_b32 %11, %27\n\t"
+                     "v_mov_b32 %12, %28\n\tv_mov_b32 %13, %29\n\tv_mov_b32 %14, %30\n\tv_mov_b32 %15, %31"
+                     : "=&v"(df[0]), "=&v"(df[1]), "=&v"(df[2]), "=&v"(df[3]), "=&v"(df[4]), "=&v"(df[5]), "=&v"(df[6]), "=&v"(df[7]),
+                       "=&v"(dr[0]), "=&v"(dr[1]), "=&v"(dr[2]), "=&v"(dr[3]), "=&v"(dr[4]), "=&v"(dr[5]), "=&v"(dr[6]), "=&v"(dr[7])
+                     : "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]), "v"(pf[7]),
+                       "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(pr[4]), "v"(pr[5]), "v"(pr[6]), "v"(pr[7])
+                     : "memory");
+#pragma unroll
+        for (int u = 0; u < AGG_PF; u++) {
+            AGG_PUSH(df[u]);
+            AGG_EMIT(j + u - L, dr[u]);
+        }
+        j += AGG_PF;
     }
-    // outputs whose +L look-ahead ends beyond the last loaded entry (image end): arms loaded directly
-    for (int m = adc_imax(m0, hi - L); m < m1; m++)
-        emit(m, arms32[pix_of(m)], DIVIDE ? (uint32_t)sup[pix_of(m)] : 1u);
+    // ---- tail of phase B (< 2*AGG_PF entries): plain compiler-scheduled loads
+    for (; j < hi; j++) {
+        const float v = sp[(long long)j * fstep];
+        AGG_PUSH(v);
+        const int m = j - L;
+        if (m >= m0) AGG_EMIT(m, rp[m]);
+    }
+    // ---- phase C: outputs whose +L look-ahead ends beyond the last entry (image end)
+    for (int m = adc_imax(m0, hi - L); m < m1; m++) AGG_EMIT(m, rp[m]);
+#undef AGG_PUSH
+#undef AGG_EMIT
 }
 
 static int env_int(const char* name, int dflt)
@@ -169,28 +241,45 @@ static int env_int(const char* name, int dflt)
     return s ? atoi(s) : dflt;
 }
 
+// Picks the number of line segments: all waves of a "round" run concurrently (9 per CU), a pass costs
+// rounds x (segment length + halo) steps.
+static int pick_nseg(long long nlines, int N, int L, int slots)
+{
+    int best = 1;
+    long long best_cost = -1;
+    for (int ns = 1; ns <= 16; ns++) {
+        const int seg = (N + ns - 1) / ns;
+        if (ns > 1 && seg < 2 * L) break;
+        const long long rounds = (nlines * ns + slots - 1) / slots;
+        const long long cost = rounds * (seg + (ns > 1 ? 2 * L : 0));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+    }
+    return best;
+}
+
 template <bool VERT, bool DIVIDE>
-static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, const uint16_t* sup, bool direct)
+static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool direct)
 {
     const AdcParams& p = h->p;
     const int L = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
-    const size_t lds = (size_t)4 * (2 * L + 1) * 64 * sizeof(float);
+    const size_t lds = (size_t)(2 * L + 1) * 64 * sizeof(float);
     if (direct || lds > 150 * 1024) {
         hipLaunchKernelGGL((k_agg_direct<VERT, DIVIDE>), dim3(256 * 16), dim3(256), 0, h->stream, src, dst,
-                           reinterpret_cast<const uchar4*>(h->arms), sup, p.W, p.H, p.Dp);
+                           reinterpret_cast<const uchar4*>(h->arms), VERT ? h->sup_h : h->sup_v, p.W, p.H, p.Dp);
         return hipGetLastError();
     }
     const int N = VERT ? p.H : p.W;
-    int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", VERT ? 2 : 4);
-    if (nseg < 1) nseg = 1;
+    const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / 64);
+    const int waves_per_cu = adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((lds + 511) / 512 * 512))));
+    int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
+    if (nseg < 1) nseg = pick_nseg(nlines, N, L, 256 * waves_per_cu);
     int seg_len = (N + nseg - 1) / nseg;
     if (seg_len < 1) seg_len = 1;
     nseg = (N + seg_len - 1) / seg_len;
-    const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / 64);
     const long long waves = nlines * nseg;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
-    hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE>), dim3(blocks), dim3(256), lds, h->stream, src, dst,
-                       reinterpret_cast<const uchar4*>(h->arms), sup, p.W, p.H, p.Dp, L, seg_len, nseg);
+    const int per_xcd = (int)((waves + 7) / 8);
+    hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), lds, h->stream, src, dst,
+                       VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, L, seg_len, nseg, per_xcd);
     return hipGetLastError();
 }
 
@@ -200,7 +289,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
     static bool attr_set = false;
     if (!attr_set) {
-        // allow > 64 KiB dynamic LDS for the ring
+        // allow > 64 KiB dynamic LDS for the ring (large cross_L1)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -213,15 +302,15 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     for (int k = 0; k < iterations && e == hipSuccess; k++) {
         if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->stream);
         if (horizontal_first) {
-            e = launch_pass<false, false>(h, h->vol_a, h->vol_b, nullptr, direct);
+            e = launch_pass<false, false>(h, h->vol_a, h->vol_b, direct);
             launch++;
             if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->stream);
-            if (e == hipSuccess) e = launch_pass<true, true>(h, h->vol_b, h->vol_a, h->sup_h, direct);
+            if (e == hipSuccess) e = launch_pass<true, true>(h, h->vol_b, h->vol_a, direct); // / sup_h
         } else {
-            e = launch_pass<true, false>(h, h->vol_a, h->vol_b, nullptr, direct);
+            e = launch_pass<true, false>(h, h->vol_a, h->vol_b, direct);
             launch++;
             if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->stream);
-            if (e == hipSuccess) e = launch_pass<false, true>(h, h->vol_b, h->vol_a, h->sup_v, direct);
+            if (e == hipSuccess) e = launch_pass<false, true>(h, h->vol_b, h->vol_a, direct); // / sup_v
         }
         launch++;
         horizontal_first = !horizontal_first;

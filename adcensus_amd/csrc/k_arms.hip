@@ -92,6 +92,32 @@ __global__ __launch_bounds__(256) void k_color_diffs(const uint8_t* __restrict__
     dv[(size_t)y * W + x] = y > 0 ? (uint8_t)adc_color_dist_max(p, p - (size_t)W * 3) : 0;
 }
 
+// Packed per-pixel records for the aggregation passes: {arm_lo, arm_hi, divisor(u16)}.
+//   rec_h[y][x]  = {left, right, sup_v}   (H passes march along x; the dividing H pass is the 2nd pass of a
+//                                          vertical-first iteration -> vec_sup_count_[1])
+//   rec_v[x][y]  = {top, bottom, sup_h}   (V passes march along y: stored TRANSPOSED so a line is contiguous)
+__global__ __launch_bounds__(256) void k_make_records(const uchar4* __restrict__ arms, const uint16_t* __restrict__ sup_h,
+                                                      const uint16_t* __restrict__ sup_v, uint32_t* __restrict__ rec_h,
+                                                      uint32_t* __restrict__ rec_v, int W, int H)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t p = (size_t)y * W + x;
+    const uchar4 a = arms[p];
+    rec_h[p] = (uint32_t)a.x | ((uint32_t)a.y << 8) | ((uint32_t)sup_v[p] << 16);
+    rec_v[(size_t)x * H + y] = (uint32_t)a.z | ((uint32_t)a.w << 8) | ((uint32_t)sup_h[p] << 16);
+}
+
+hipError_t adc_launch_records(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(k_make_records, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
+                       h->rec_h, h->rec_v, p.W, p.H);
+    return hipGetLastError();
+}
+
 hipError_t adc_launch_arms(adc_handle* h)
 {
     const AdcParams& p = h->p;

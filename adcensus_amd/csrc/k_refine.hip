@@ -88,24 +88,97 @@ hipError_t adc_launch_lrcheck(adc_handle* h)
 // ------------------------------------------------------------------------------ K8 region voting
 #define IRV_TILE 16
 
+// Pass set-up: elig = pixels of this list that are still invalid (the ordering mask of the pass);
+// the work list only keeps those that CAN be filled: the vote needs count > irv_ts and count <= region
+// size == horizontal-first support count, so pixels with sup_h <= irv_ts stay invalid whatever happens.
+// Block-aggregated compaction (one atomic per 256 pixels).
 __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ label, const float* __restrict__ disp,
-                                                   uint8_t* __restrict__ elig, int32_t* __restrict__ list,
-                                                   int32_t* __restrict__ counters, int which, int P)
+                                                   const uint16_t* __restrict__ sup_h, uint8_t* __restrict__ elig,
+                                                   int32_t* __restrict__ list, int32_t* __restrict__ counters, int which,
+                                                   int P, int min_region)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const bool e = (label[p] == which) && (disp[p] == ADC_INVALID_FLOAT);
-    elig[p] = e ? 1 : 0;
-    if (e) list[atomicAdd(&counters[0], 1)] = p;
+    __shared__ int wcnt[4];
+    __shared__ int base;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    bool e = false, listed = false;
+    if (p < P) {
+        e = (label[p] == which) && (disp[p] == ADC_INVALID_FLOAT);
+        elig[p] = e ? 1 : 0;
+        listed = e && ((int)sup_h[p] > min_region);
+    }
+    const unsigned long long m = __ballot(listed);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        base = tot ? atomicAdd(&counters[0], tot) : 0;
+    }
+    __syncthreads();
+    if (listed) {
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wcnt[w];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        list[off] = p;
+    }
 }
 
-// One wave evaluates the vote of one eligible pixel per loop trip.
-__global__ __launch_bounds__(256) void k_irv_round(const int32_t* __restrict__ list, int n, float* disp,
-                                                   const uint8_t* __restrict__ elig, const uchar4* __restrict__ arms,
-                                                   const uint8_t* __restrict__ chg_prev, uint8_t* __restrict__ chg_next,
-                                                   int32_t* __restrict__ counters, int W, int H, int dmin, int D, int irv_ts,
-                                                   float irv_th, int round, int Lmax)
+// counters layout (int32): [0] list length  [2] evaluations  [8 + (r&63)] "round r changed something"
+//                           [72 + (r&63)] number of dirty entries of round r
+// chg[tile] = r + 1 when a pixel of the tile changed in round r (cleared once per pass).
+#define IRV_FLAG(r) (8 + ((r)&63))
+#define IRV_NDIRTY(r) (72 + ((r)&63))
+
+// Round r > 0, step 1: one thread per list entry decides whether the entry must be re-evaluated: some pixel
+// of its dependency box (rows y-L..y, cols x-L..x+L) changed in round r-1.  Dirty entries are compacted.
+__global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ list, int n, const int32_t* __restrict__ chg,
+                                                   int32_t* __restrict__ dlist, int32_t* __restrict__ counters, int W, int H,
+                                                   int round, int Lmax)
 {
+    if (counters[IRV_FLAG(round - 1)] == 0) return; // previous round changed nothing: converged
+    __shared__ int wcnt[4];
+    __shared__ int base;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tiles_x = (W + IRV_TILE - 1) / IRV_TILE;
+    bool dirty = false;
+    int p = -1;
+    if (i < n) {
+        p = list[i];
+        const int y = p / W, x = p - y * W;
+        const int tx0 = adc_imax(0, x - Lmax) / IRV_TILE, tx1 = adc_imin(W - 1, x + Lmax) / IRV_TILE;
+        const int ty0 = adc_imax(0, y - Lmax) / IRV_TILE, ty1 = y / IRV_TILE;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) dirty |= chg[ty * tiles_x + tx] == round; // changed in round-1
+    }
+    const unsigned long long m = __ballot(dirty);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        base = tot ? atomicAdd(&counters[IRV_NDIRTY(round)], tot) : 0;
+    }
+    __syncthreads();
+    if (dirty) {
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wcnt[w];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        dlist[off] = p;
+    }
+}
+
+// Step 2: one wave per entry to evaluate: all 64 lanes sweep the cross region (4 region rows x 16 columns
+// per trip) into an LDS histogram, wave arg-max with lowest-bin tie-break, in-place (chaotic) update.
+__global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ work, int n_full, float* disp,
+                                                  const uint8_t* __restrict__ elig, const uchar4* __restrict__ arms,
+                                                  int32_t* __restrict__ chg, int32_t* __restrict__ counters, int W, int H, int dmin,
+                                                  int D, int irv_ts, float irv_th, int round)
+{
+    int n = n_full; // round 0 evaluates the whole list
+    if (round > 0) {
+        if (counters[IRV_FLAG(round - 1)] == 0) return;
+        n = counters[IRV_NDIRTY(round)];
+    }
     __shared__ int hist_all[4][ADC_MAX_DISP_RANGE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int* hist = hist_all[wave];
@@ -113,17 +186,8 @@ __global__ __launch_bounds__(256) void k_irv_round(const int32_t* __restrict__ l
     const int nwaves = gridDim.x * 4;
     int evals = 0;
     for (int e = blockIdx.x * 4 + wave; e < n; e += nwaves) {
-        const int p = list[e];
+        const int p = work[e];
         const int y = p / W, x = p - y * W;
-        if (round > 0) {
-            // re-evaluate only if a pixel of the dependency box (rows y-L..y, cols x-L..x+L) changed last round
-            const int tx0 = adc_imax(0, x - Lmax) / IRV_TILE, tx1 = adc_imin(W - 1, x + Lmax) / IRV_TILE;
-            const int ty0 = adc_imax(0, y - Lmax) / IRV_TILE, ty1 = y / IRV_TILE;
-            const int ntx = tx1 - tx0 + 1, nt = ntx * (ty1 - ty0 + 1);
-            bool dirty = false;
-            for (int i = lane; i < nt; i += 64) dirty |= chg_prev[(ty0 + i / ntx) * tiles_x + tx0 + i % ntx] != 0;
-            if (__ballot(dirty) == 0ull) continue;
-        }
         for (int b = lane; b < D; b += 64) hist[b] = 0;
         const uchar4 arm = arms[p];
         const int sub = lane >> 4, sl = lane & 15;
@@ -134,7 +198,10 @@ __global__ __launch_bounds__(256) void k_irv_round(const int32_t* __restrict__ l
                 const uchar4 arm2 = arms[yt * W + x];
                 for (int s = -(int)arm2.x + sl; s <= (int)arm2.y; s += 16) {
                     const int q = yt * W + x + s;
-                    float v = disp[q];
+                    // agent-scope load: fills made earlier in THIS launch by other CUs / XCDs become visible, so a
+                    // sweep in (roughly) raster order propagates like the sequential scan (speed only: staleness
+                    // can never change the fixed point, the confirming round runs after a kernel boundary)
+                    float v = __hip_atomic_load(&disp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // eligible pixels of this pass: visible only if they precede p in raster order
                     // (already processed by the sequential scan), otherwise still invalid
                     if (elig[q] && q >= p) v = ADC_INVALID_FLOAT;
@@ -163,11 +230,11 @@ __global__ __launch_bounds__(256) void k_irv_round(const int32_t* __restrict__ l
         const float nv = adc_vote_decide(bb, bh, cnt, dmin, irv_ts, irv_th);
         evals++;
         if (lane == 0) {
-            const float cur = disp[p];
+            const float cur = __hip_atomic_load(&disp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__float_as_uint(cur) != __float_as_uint(nv)) {
-                disp[p] = nv;
-                chg_next[(y / IRV_TILE) * tiles_x + x / IRV_TILE] = 1;
-                counters[1] = 1;
+                __hip_atomic_store(&disp[p], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                chg[(y / IRV_TILE) * tiles_x + x / IRV_TILE] = round + 1;
+                counters[IRV_FLAG(round)] = 1;
             }
         }
     }
@@ -180,37 +247,51 @@ hipError_t adc_run_region_voting(adc_handle* h)
     const int P = p.W * p.H;
     const int tiles = ((p.W + IRV_TILE - 1) / IRV_TILE) * ((p.H + IRV_TILE - 1) / IRV_TILE);
     const int Lmax = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
+    const int min_region = Lmax <= 127 ? p.opt.irv_ts : -1; // u16 support counts cannot wrap for L <= 127
+    const int BATCH = 8; // rounds launched per host check (a converged pass turns the rest into no-ops)
     h->vote_rounds = 0;
     h->vote_evals = 0;
     hipError_t e = hipSuccess;
-    int32_t host_cnt[4];
+    int32_t host_cnt[136];
+    int32_t* chg = reinterpret_cast<int32_t*>(h->chg_a);
     for (int it = 0; it < 5; it++) {         // multistep_refiner.cpp:167
         for (int k = 0; k < 2; k++) {        // mismatches, then occlusions (:170-171)
-            if ((e = hipMemsetAsync(h->vote_counters, 0, 4 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->elig,
-                               h->vote_list, h->vote_counters, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, P);
+            if ((e = hipMemsetAsync(h->vote_counters, 0, 136 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
+                               h->vote_list, h->vote_counters, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, P, min_region);
             if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
             const int n = host_cnt[0];
             if (n == 0) continue;
-            const unsigned blocks = (unsigned)adc_imin((n + 3) / 4, 256 * 8);
-            for (int round = 0;; round++) {
-                hipMemsetAsync(h->chg_b, 0, tiles, h->stream);
-                hipMemsetAsync(h->vote_counters + 1, 0, sizeof(int32_t), h->stream);
-                hipLaunchKernelGGL(k_irv_round, dim3(blocks), dim3(256), 0, h->stream, h->vote_list, n, h->disp_l, h->elig,
-                                   reinterpret_cast<const uchar4*>(h->arms), h->chg_a, h->chg_b, h->vote_counters, p.W, p.H,
-                                   p.dmin, p.D, p.opt.irv_ts, p.opt.irv_th, round, Lmax);
-                if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(chg, 0, (size_t)tiles * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+            const unsigned vote_blocks_full = (unsigned)adc_imin((n + 3) / 4, 256 * 8);
+            const unsigned vote_blocks = (unsigned)adc_imin((n + 3) / 4, 256 * 4);
+            const unsigned check_blocks = (unsigned)((n + 255) / 256);
+            bool done = false;
+            for (int r0 = 0; !done; r0 += BATCH) {
+                if (r0 > 0) { // recycle the flag / count rings for this batch (the previous round's flag must stay)
+                    // BATCH divides 64 and r0 is a multiple of BATCH: the batch's ring entries are contiguous
+                    hipMemsetAsync(h->vote_counters + IRV_FLAG(r0), 0, BATCH * sizeof(int32_t), h->stream);
+                    hipMemsetAsync(h->vote_counters + IRV_NDIRTY(r0), 0, BATCH * sizeof(int32_t), h->stream);
+                }
+                for (int round = r0; round < r0 + BATCH; round++) {
+                    if (round > 0)
+                        hipLaunchKernelGGL(k_irv_check, dim3(check_blocks), dim3(256), 0, h->stream, h->vote_list, n, chg,
+                                           h->vote_dirty, h->vote_counters, p.W, p.H, round, Lmax);
+                    hipLaunchKernelGGL(k_irv_vote, dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), 0, h->stream,
+                                       round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,
+                                       reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,
+                                       p.opt.irv_ts, p.opt.irv_th, round);
+                }
+                if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 136 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
                 if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
-                h->vote_rounds++;
-                h->vote_evals += host_cnt[2];
-                hipMemsetAsync(h->vote_counters + 2, 0, sizeof(int32_t), h->stream);
-                uint8_t* t = h->chg_a;
-                h->chg_a = h->chg_b;
-                h->chg_b = t;
-                if (host_cnt[1] == 0) break; // a full round without any change: fixed point == sequential result
-                if (round > n + 8) return hipErrorUnknown; // cannot happen (triangular system converges in <= n rounds)
+                for (int round = r0; round < r0 + BATCH; round++) {
+                    h->vote_rounds++;
+                    if (host_cnt[IRV_FLAG(round)] == 0) { done = true; break; } // full round without change: fixed point
+                }
+                if (r0 > n + 16) return hipErrorUnknown; // cannot happen: the triangular system converges in <= n rounds
             }
+            h->vote_evals += host_cnt[2];
         }
     }
     return hipGetLastError();
@@ -332,42 +413,96 @@ hipError_t adc_launch_discontinuity(adc_handle* h)
 
 // ------------------------------------------------------------------------------------- K11 median
 // In-place raster 3x3 median == recursive filter: the window of (x,y) holds already-filtered values
-// at (x-1..x+1, y-1) and (x-1, y).  All pixels with equal t = x + 2y are independent; one workgroup
-// walks t = 0 .. W-1+2(H-1) with one barrier per level.  Filtered values travel through a 4-deep LDS
-// ring per row (ring[y][x&3]); unfiltered values are read from the (unmodified) input map.
+// at (x-1..x+1, y-1) and (x-1, y).  All pixels with equal t = x + 2y are independent; ONE workgroup
+// walks t = 0 .. W-1+2(H-1) with one barrier per level.  Thread i owns RPT consecutive rows.
+//   * filtered values travel through a 4-deep LDS ring per row (ring[y][x&3]); a row reads 1 new
+//     filtered value of the row above per level and shifts the other two in registers;
+//   * unfiltered values (rows y and y+1, never modified: the output goes to a second buffer) slide
+//     through registers; the 2 new ones per level are prefetched MED_K levels ahead, so no global
+//     load sits on the per-level critical path.
+#define MED_K 4
+
+template <int RPT>
 __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restrict__ in, float* __restrict__ out, int W, int H)
 {
     extern __shared__ __attribute__((aligned(16))) float mring[]; // [H][4]
     const int tid = threadIdx.x;
     const int nsteps = W + 2 * (H - 1);
-    for (int t = 0; t < nsteps; t++) {
-        for (int y = tid; y < H; y += 1024) {
-            const int x = t - 2 * y;
-            if (x < 0 || x >= W) continue;
-            float v[9];
-            int n = 0;
+    auto clampc = [&](int c) __attribute__((always_inline)) { return c < 0 ? 0 : (c >= W ? W - 1 : c); };
+
+    // per owned row r: y = tid*RPT + r.  Column of row y at level t: x = t - 2y.
+    float A0[RPT], A1[RPT];          // in[y][x], in[y][x+1]
+    float Bm[RPT], B0[RPT], B1[RPT]; // in[y+1][x-1], [x], [x+1]
+    float Fm[RPT], F0[RPT];          // filtered out[y-1][x-1], out[y-1][x]
+    float Pv[RPT];                   // filtered out[y][x-1]
+    float fa[RPT][MED_K], fb[RPT][MED_K]; // prefetched columns x+2 .. x+1+MED_K of rows y, y+1
+    const float* rowA[RPT];
+    const float* rowB[RPT];
 #pragma unroll
-            for (int r = -1; r <= 1; r++)
+    for (int r = 0; r < RPT; r++) {
+        const int y = tid * RPT + r;
+        const int ya = y < H ? y : H - 1, yb = y + 1 < H ? y + 1 : H - 1;
+        rowA[r] = in + (size_t)ya * W;
+        rowB[r] = in + (size_t)yb * W;
+        const int x0 = -2 * y; // column at level 0
+        A0[r] = rowA[r][clampc(x0)];
+        A1[r] = rowA[r][clampc(x0 + 1)];
+        Bm[r] = rowB[r][clampc(x0 - 1)];
+        B0[r] = rowB[r][clampc(x0)];
+        B1[r] = rowB[r][clampc(x0 + 1)];
+        Fm[r] = F0[r] = Pv[r] = 0.0f; // columns < 0: never used (validity is decided by index)
 #pragma unroll
-                for (int c = -1; c <= 1; c++) {
-                    const int row = y + r, col = x + c;
-                    float val = ADC_INVALID_FLOAT; // padding sorts to the end
-                    if (row >= 0 && row < H && col >= 0 && col < W) {
-                        n++;
-                        const bool filtered = (r < 0) || (r == 0 && c < 0);
-                        val = filtered ? mring[row * 4 + (col & 3)] : in[(size_t)row * W + col];
-                    }
-                    v[(r + 1) * 3 + (c + 1)] = val;
-                }
-            adc_sort9(v);
-            const int sel = n / 2; // wnd_data[size/2], adcensus_util.cpp:77
-            float res = v[0];
-#pragma unroll
-            for (int i = 1; i < 9; i++) res = (i == sel) ? v[i] : res;
-            out[(size_t)y * W + x] = res;
-            mring[y * 4 + (x & 3)] = res;
+        for (int k = 0; k < MED_K; k++) {
+            fa[r][k] = rowA[r][clampc(x0 + 2 + k)];
+            fb[r][k] = rowB[r][clampc(x0 + 2 + k)];
         }
-        __syncthreads();
+    }
+
+    for (int t0 = 0; t0 < nsteps; t0 += MED_K) {
+#pragma unroll
+        for (int k = 0; k < MED_K; k++) {
+            const int t = t0 + k;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int y = tid * RPT + r;
+                const int x = t - 2 * y;
+                // next level's new unfiltered column (x+2) was prefetched MED_K levels ago; refill the slot
+                const float na = fa[r][k], nb = fb[r][k];
+                fa[r][k] = rowA[r][clampc(x + 2 + MED_K)];
+                fb[r][k] = rowB[r][clampc(x + 2 + MED_K)];
+                const bool active = (t < nsteps) && (y < H) && (x >= 0) && (x < W);
+                // newest filtered value of the row above: out[y-1][x+1] was produced at level t-1
+                float F1 = 0.0f;
+                if (y > 0 && y < H && x + 1 >= 0 && x + 1 < W) F1 = mring[(y - 1) * 4 + ((x + 1) & 3)];
+                if (active) {
+                    const bool up = y > 0, dn = y + 1 < H, lf = x > 0, rt = x + 1 < W;
+                    float v[9];
+                    int n = 1;
+                    v[0] = (up && lf) ? Fm[r] : ADC_INVALID_FLOAT; n += (up && lf);
+                    v[1] = up ? F0[r] : ADC_INVALID_FLOAT;          n += up;
+                    v[2] = (up && rt) ? F1 : ADC_INVALID_FLOAT;     n += (up && rt);
+                    v[3] = lf ? Pv[r] : ADC_INVALID_FLOAT;          n += lf;
+                    v[4] = A0[r];
+                    v[5] = rt ? A1[r] : ADC_INVALID_FLOAT;          n += rt;
+                    v[6] = (dn && lf) ? Bm[r] : ADC_INVALID_FLOAT;  n += (dn && lf);
+                    v[7] = dn ? B0[r] : ADC_INVALID_FLOAT;          n += dn;
+                    v[8] = (dn && rt) ? B1[r] : ADC_INVALID_FLOAT;  n += (dn && rt);
+                    adc_sort9(v); // +inf padding sorts to the end
+                    const int sel = n / 2; // wnd_data[size/2], adcensus_util.cpp:77
+                    float res = v[0];
+#pragma unroll
+                    for (int i = 1; i < 9; i++) res = (i == sel) ? v[i] : res;
+                    out[(size_t)y * W + x] = res;
+                    mring[y * 4 + (x & 3)] = res;
+                    Pv[r] = res;
+                }
+                // slide the register windows one column to the right
+                Fm[r] = F0[r]; F0[r] = F1;
+                A0[r] = A1[r]; A1[r] = na;
+                Bm[r] = B0[r]; B0[r] = B1[r]; B1[r] = nb;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -376,11 +511,19 @@ hipError_t adc_launch_median(adc_handle* h)
     const AdcParams& p = h->p;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const size_t lds = (size_t)p.H * 4 * sizeof(float);
-    hipLaunchKernelGGL(k_median_wavefront, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
+    if (p.H > 8192) return hipErrorInvalidValue; // LDS ring of H*16 B and <= 8 rows per thread
+    const int rpt = (p.H + 1023) / 1024;
+    if (rpt <= 1) hipLaunchKernelGGL(k_median_wavefront<1>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
+    else if (rpt <= 2) hipLaunchKernelGGL(k_median_wavefront<2>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
+    else if (rpt <= 4) hipLaunchKernelGGL(k_median_wavefront<4>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
+    else hipLaunchKernelGGL(k_median_wavefront<8>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
     float* t = h->disp_l;
     h->disp_l = h->disp_tmp;
     h->disp_tmp = t;

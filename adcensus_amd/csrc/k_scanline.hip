@@ -16,27 +16,53 @@
 #include "adc_internal.h"
 #include "adc_device_fn.h"
 
-#define SO_PF 8
+// Cross-lane primitives.  DPP=true: data-parallel-primitive moves (no LDS crossbar round trip):
+// wave_shr:1 / wave_shl:1 for the d-1 / d+1 neighbours, row_ror butterflies + 4 readlanes for the
+// wave minimum.  DPP=false: ds_bpermute based __shfl (kept as a cross-check, ADC_SO_DPP=0).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
 
+template <bool DPP>
 __device__ __forceinline__ float wave_min_f32(float v)
 {
+    if constexpr (DPP) {
+        float o;
+        o = dpp_mov<0x121>(v, v); v = o < v ? o : v; // row_ror:1
+        o = dpp_mov<0x122>(v, v); v = o < v ? o : v; // row_ror:2
+        o = dpp_mov<0x124>(v, v); v = o < v ? o : v; // row_ror:4
+        o = dpp_mov<0x128>(v, v); v = o < v ? o : v; // row_ror:8  -> every lane holds its 16-lane row minimum
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+        const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+        const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+        const float a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
+        return b < a ? b : a;
+    } else {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float o = __shfl_xor(v, m, 64);
-        v = o < v ? o : v;
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float o = __shfl_xor(v, m, 64);
+            v = o < v ? o : v;
+        }
+        return v;
     }
-    return v;
 }
 
 // lane l gets lane l-1's value (lane 0: fill)
+template <bool DPP>
 __device__ __forceinline__ float lane_up(float v, float fill, int lane)
 {
+    if constexpr (DPP) return dpp_mov<0x138>(fill, v); // wave_shr:1, lane 0 keeps `old` = fill
     const float o = __shfl_up(v, 1, 64);
     return lane == 0 ? fill : o;
 }
 // lane l gets lane l+1's value (lane 63: fill)
+template <bool DPP>
 __device__ __forceinline__ float lane_down(float v, float fill, int lane)
 {
+    if constexpr (DPP) return dpp_mov<0x130>(fill, v); // wave_shl:1, lane 63 keeps `old` = fill
     const float o = __shfl_down(v, 1, 64);
     return lane == 63 ? fill : o;
 }
@@ -65,105 +91,151 @@ __device__ __forceinline__ void vstore(float* p, const float* r)
     else *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
-// Inputs of one path element: data term c[], d1 (wave-uniform) and the per-lane d2 of each of the VPL
-// disparities (raw diff-map byte; whether d1 is used instead is decided at consumption).
+// ------------------------------------------------------------------------------ penalty-class maps
+// The (P1,P2) class of (pixel, disparity) depends only on the two images: it is precomputed once per
+// Match for the four pass types into cls[pass][pixel][lane] (one byte per lane holding the 2-bit classes
+// of its VPL disparities), so the DP kernel's per-step inputs are two fully coalesced loads (512 B data
+// + 64 B classes per pixel at D=128) and the sticky-d2 logic (adc_so_d2_column) runs in a massively
+// parallel kernel instead of on the sequential critical path.
+//   pass 0: L->R   d1 = dh_left[y][x]      d2 = dh_right[y][col]
+//   pass 1: R->L   d1 = dh_left[y][x+1]    d2 = dh_right[y][col+1]
+//   pass 2: T->B   d1 = dv_left[y][x]      d2 = dv_right[y][col]
+//   pass 3: B->T   d1 = dv_left[y+1][x]    d2 = dv_right[y+1][col]
+// with col = adc_so_d2_column(x, dmin, d, W) (or "use d1" when it returns -1).
+// One thread produces the class bytes of 4 consecutive lanes of one pixel for all four passes
+// (dword stores: a wave writes 4 pixels x 64 B contiguous per pass).
+template <int VPL>
+__global__ __launch_bounds__(256) void k_so_classes(const uint8_t* __restrict__ lh, const uint8_t* __restrict__ lv,
+                                                    const uint8_t* __restrict__ rh, const uint8_t* __restrict__ rv,
+                                                    uint8_t* __restrict__ cls, int W, int H, int dmin, int D, int tso)
+{
+    const long long P = (long long)W * H;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pix = gid >> 4;
+    if (pix >= P) return;
+    const int quad = (int)(gid & 15); // lanes 4*quad .. 4*quad+3
+    const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    int col[4 * VPL];
+#pragma unroll
+    for (int j = 0; j < 4 * VPL; j++) col[j] = adc_so_d2_column(x, dmin, quad * 4 * VPL + j, W);
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const bool vert = pass >= 2, bwd = (pass & 1) != 0;
+        const bool has_pred = vert ? (bwd ? y + 1 < H : y > 0) : (bwd ? x + 1 < W : x > 0);
+        uint32_t word = 0;
+        if (has_pred) {
+            const int sx = vert ? x : (bwd ? x + 1 : x);
+            const int sy = vert ? (bwd ? y + 1 : y) : y;
+            const uint8_t* dl = vert ? lv : lh;
+            const uint8_t* dr = (vert ? rv : rh) + (size_t)sy * W;
+            const int shift = (!vert && bwd) ? 1 : 0;
+            const int d1 = dl[(size_t)sy * W + sx];
+            int d2[4 * VPL];
+#pragma unroll
+            for (int j = 0; j < 4 * VPL; j++) d2[j] = (int)dr[(col[j] >= 0 ? col[j] : 0) + shift];
+#pragma unroll
+            for (int j = 0; j < 4 * VPL; j++) {
+                const int dd2 = col[j] >= 0 ? d2[j] : d1;
+                const int l = j / VPL, k = j % VPL; // lane within the quad, disparity within the lane
+                word |= (uint32_t)adc_so_penalty_class(d1, dd2, tso) << (8 * l + 2 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(cls + ((size_t)pass * P + pix) * 64 + quad * 4) = word;
+    }
+}
+
+hipError_t adc_launch_so_classes(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    const long long P = (long long)p.W * p.H;
+    const unsigned blocks = (unsigned)((P * 16 + 255) / 256);
+#define CLS_LAUNCH(V)                                                                                                    \
+    hipLaunchKernelGGL(k_so_classes<V>, dim3(blocks), dim3(256), 0, h->stream, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, \
+                       h->cdiff_rv, h->so_cls, p.W, p.H, p.dmin, p.D, p.opt.so_tso)
+    if (p.VPL == 1) CLS_LAUNCH(1);
+    else if (p.VPL == 2) CLS_LAUNCH(2);
+    else CLS_LAUNCH(4);
+#undef CLS_LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- DP kernel
+#define SO_PF 16
+
 template <int VPL>
 struct SoElem {
-    float c[VPL];
-    int d2[VPL];
-    int d1;
+    float c[VPL]; // data term
+    int cls;      // packed 2-bit penalty classes of this lane's VPL disparities
 };
 
 struct SoGeom {
-    int W, H, dmin, dir, path, plen, d0;
-    int vzero; // per-lane zero the compiler cannot see through (prevents an early readfirstlane + wait on d1)
+    int W, H, dir, path, plen, d0, lane;
 };
 
 template <bool VERT>
-__device__ __forceinline__ void so_coord(const SoGeom& g, int i, int& x, int& y)
+__device__ __forceinline__ size_t so_pixel(const SoGeom& g, int i)
 {
     const int m = g.dir > 0 ? i : g.plen - 1 - i;
-    if (VERT) { x = g.path; y = m; } else { x = m; y = g.path; }
+    return VERT ? (size_t)m * g.W + g.path : (size_t)g.path * g.W + m;
 }
 
-// diff maps: forward pass reads [p], backward pass reads [p + one step] (see k_arms.hip)
 template <int VPL, bool VERT>
-__device__ __forceinline__ SoElem<VPL> so_load(const SoGeom& g, const float* __restrict__ src,
-                                                const uint8_t* __restrict__ cd_left, const uint8_t* __restrict__ cd_right,
-                                                int i)
+__device__ __forceinline__ SoElem<VPL> so_load(const SoGeom& g, const float* __restrict__ src, const uint8_t* __restrict__ cls, int i)
 {
     constexpr int Dp = 64 * VPL;
-    int x, y;
-    so_coord<VERT>(g, i, x, y);
+    const size_t pix = so_pixel<VERT>(g, i);
     SoElem<VPL> e;
-    vload<VPL>(src + ((size_t)y * g.W + x) * Dp + g.d0, e.c);
-    const int sx = VERT ? x : (g.dir > 0 ? x : x + 1);
-    const int sy = VERT ? (g.dir > 0 ? y : y + 1) : y;
-    e.d1 = cd_left[(size_t)sy * g.W + sx + g.vzero]; // vzero: opaque per-lane 0 keeps this a plain VMEM load
-    const uint8_t* row = cd_right + (size_t)sy * g.W; // row of the right-image diff map
-    const int shift = VERT ? 0 : (g.dir > 0 ? 0 : 1);
-#pragma unroll
-    for (int k = 0; k < VPL; k++) {
-        const int col = adc_so_d2_column(x, g.dmin, g.d0 + k, g.W);
-        // unconditional load of the raw byte (a branch, or any ALU on the loaded value here, would make the
-        // compiler wait for it at issue time); "use d1 instead" is resolved when the element is consumed
-        e.d2[k] = (int)row[(col >= 0 ? col : 0) + shift];
-    }
+    vload<VPL>(src + pix * Dp + g.d0, e.c);
+    e.cls = cls[pix * 64 + g.lane];
     return e;
 }
 
 // VERT=false: path = image row `path`, marching in x.  VERT=true: path = column, marching in y.
-// dir=+1 forward, -1 backward.
-template <int VPL, bool VERT>
+// dir=+1 forward, -1 backward.  cls = class map of this pass type.
+template <int VPL, bool VERT, bool DPP>
 __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src, float* __restrict__ dst,
-                                                  const uint8_t* __restrict__ cd_left,  // left-image diff map (h or v)
-                                                  const uint8_t* __restrict__ cd_right, // right-image diff map (h or v)
-                                                  int W, int H, int dmin, int D, int dir, int tso, float P1a, float P1b,
-                                                  float P1c, float P2a, float P2b, float P2c)
+                                                  const uint8_t* __restrict__ cls, int W, int H, int D, int dir, float P1a,
+                                                  float P1b, float P1c, float P2a, float P2b, float P2c)
 {
     constexpr int Dp = 64 * VPL;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int npaths = VERT ? W : H;
     SoGeom g;
-    g.W = W; g.H = H; g.dmin = dmin; g.dir = dir;
+    g.W = W; g.H = H; g.dir = dir; g.lane = lane;
     g.path = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
     if (g.path >= npaths) return;
     g.plen = VERT ? H : W;
     g.d0 = lane * VPL; // first disparity index of this lane
-    asm volatile("v_mov_b32 %0, 0" : "=v"(g.vzero));
 
     float Lp[VPL]; // previous path element's costs; padding lanes (d >= D) hold the sentinel
     float minLp;
     {
-        int x, y;
-        so_coord<VERT>(g, 0, x, y);
+        const size_t pix = so_pixel<VERT>(g, 0);
         float c[VPL];
-        vload<VPL>(src + ((size_t)y * W + x) * Dp + g.d0, c);
-        vstore<VPL>(dst + ((size_t)y * W + x) * Dp + g.d0, c); // first pixel: dst = src (scanline_optimizer.cpp:99,208)
+        vload<VPL>(src + pix * Dp + g.d0, c);
+        vstore<VPL>(dst + pix * Dp + g.d0, c); // first pixel: dst = src (scanline_optimizer.cpp:99,208)
         float lmin = ADC_LARGE_FLOAT; // sentinels take part in the first minimum (scanline_optimizer.cpp:107-110)
 #pragma unroll
         for (int k = 0; k < VPL; k++) {
             Lp[k] = (g.d0 + k) < D ? c[k] : ADC_LARGE_FLOAT;
             lmin = Lp[k] < lmin ? Lp[k] : lmin;
         }
-        minLp = wave_min_f32(lmin);
+        minLp = wave_min_f32<DPP>(lmin);
     }
     if (g.plen <= 1) return;
 
 // one DP step for path element I with inputs E (a macro keeps every array in registers)
 #define SO_STEP(I, E)                                                                                      \
     do {                                                                                                   \
-        int sx_, sy_;                                                                                      \
-        so_coord<VERT>(g, (I), sx_, sy_);                                                                  \
-        const float up_ = lane_up(Lp[VPL - 1], ADC_LARGE_FLOAT, lane); /* L(q, d0-1), sentinel at d=-1 */  \
-        const float dn_ = lane_down(Lp[0], ADC_LARGE_FLOAT, lane);    /* L(q, d0+VPL), sentinel at d=D */ \
+        const size_t pix_ = so_pixel<VERT>(g, (I));                                                        \
+        const float up_ = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane); /* L(q, d0-1), sentinel at d=-1 */ \
+        const float dn_ = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane); /* L(q, d0+VPL), sentinel at d=D */ \
         float out_[VPL];                                                                                   \
         float omin_ = ADC_LARGE_FLOAT;                                                                     \
         _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
         {                                                                                                  \
-            const int dd2_ = adc_so_d2_column(sx_, dmin, g.d0 + k, W) >= 0 ? (E).d2[k] : (E).d1;           \
-            const int cls_ = adc_so_penalty_class((E).d1, dd2_, tso);                                      \
+            const int cls_ = ((E).cls >> (2 * k)) & 3;                                                     \
             const float P1_ = cls_ == 0 ? P1a : (cls_ == 1 ? P1b : P1c);                                   \
             const float P2_ = cls_ == 0 ? P2a : (cls_ == 1 ? P2b : P2c);                                   \
             const float lm1_ = k == 0 ? up_ : Lp[k == 0 ? 0 : k - 1];                                      \
@@ -173,33 +245,33 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
             const float l3_ = lp1_ + P1_;                                                                  \
             const float l4_ = minLp + P2_;                                                                 \
             const float m12_ = l2_ < l1_ ? l2_ : l1_;                                                      \
-            const float m34_ = l4_ < l3_ ? l4_ : l3_;                                                      \
-            const float mm_ = m34_ < m12_ ? m34_ : m12_;                                                   \
+            const float m123_ = l3_ < m12_ ? l3_ : m12_; /* independent of the wave minimum */             \
+            const float mm_ = l4_ < m123_ ? l4_ : m123_; /* == min(min(l1,l2),min(l3,l4)) */               \
             float cs_ = (E).c[k] + mm_;                                                                    \
             cs_ = cs_ / 2; /* scanline_optimizer.cpp:151 */                                                \
             out_[k] = cs_;                                                                                 \
         }                                                                                                  \
-        vstore<VPL>(dst + ((size_t)sy_ * W + sx_) * Dp + g.d0, out_);                                      \
+        vstore<VPL>(dst + pix_ * Dp + g.d0, out_);                                                         \
         _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
         {                                                                                                  \
             Lp[k] = (g.d0 + k) < D ? out_[k] : ADC_LARGE_FLOAT;                                            \
             omin_ = Lp[k] < omin_ ? Lp[k] : omin_;                                                         \
         }                                                                                                  \
-        minLp = wave_min_f32(omin_);                                                                       \
+        minLp = wave_min_f32<DPP>(omin_);                                                                  \
     } while (0)
 
     // software prefetch ring: the inputs of the next SO_PF path elements stay in flight in registers.
-    // Prefetch loads are unconditional (index clamped to the path end).
+    // Prefetch loads are unconditional (index clamped to the path end) and carry no ALU work.
     SoElem<VPL> pre[SO_PF];
 #pragma unroll
-    for (int u = 0; u < SO_PF; u++) pre[u] = so_load<VPL, VERT>(g, src, cd_left, cd_right, adc_imin(1 + u, g.plen - 1));
+    for (int u = 0; u < SO_PF; u++) pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(1 + u, g.plen - 1));
 
     int i = 1;
     for (; i + SO_PF <= g.plen; i += SO_PF) {
 #pragma unroll
         for (int u = 0; u < SO_PF; u++) {
             const SoElem<VPL> cur = pre[u];
-            pre[u] = so_load<VPL, VERT>(g, src, cd_left, cd_right, adc_imin(i + u + SO_PF, g.plen - 1));
+            pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(i + u + SO_PF, g.plen - 1));
             __builtin_amdgcn_sched_barrier(0); // keep the refill loads ahead of the dependent chain, in program order
             SO_STEP(i + u, cur);
             __builtin_amdgcn_sched_barrier(0);
@@ -212,22 +284,27 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
 #undef SO_STEP
 }
 
+static bool so_use_dpp()
+{
+    static const bool v = [] { const char* e = getenv("ADC_SO_DPP"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+
 template <int VPL>
 static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool vert, int dir)
 {
     const AdcParams& p = h->p;
     const int npaths = vert ? p.W : p.H;
     const unsigned blocks = (unsigned)((npaths + 3) / 4);
-    const uint8_t* cdl = vert ? h->cdiff_lv : h->cdiff_lh;
-    const uint8_t* cdr = vert ? h->cdiff_rv : h->cdiff_rh;
-    if (vert)
-        hipLaunchKernelGGL((k_scanline<VPL, true>), dim3(blocks), dim3(256), 0, h->stream, src, dst, cdl, cdr, p.W, p.H,
-                           p.dmin, p.D, dir, p.opt.so_tso, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1],
-                           h->so_P2[2]);
-    else
-        hipLaunchKernelGGL((k_scanline<VPL, false>), dim3(blocks), dim3(256), 0, h->stream, src, dst, cdl, cdr, p.W, p.H,
-                           p.dmin, p.D, dir, p.opt.so_tso, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1],
-                           h->so_P2[2]);
+    const int pass = (vert ? 2 : 0) + (dir > 0 ? 0 : 1);
+    const uint8_t* cls = h->so_cls + (size_t)pass * p.W * p.H * 64;
+#define SO_LAUNCH(VERT_, DPP_)                                                                                         \
+    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_>), dim3(blocks), dim3(256), 0, h->stream, src, dst, cls, p.W, p.H, \
+                       p.D, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2])
+    const bool dpp = so_use_dpp();
+    if (vert) { if (dpp) SO_LAUNCH(true, true); else SO_LAUNCH(true, false); }
+    else { if (dpp) SO_LAUNCH(false, true); else SO_LAUNCH(false, false); }
+#undef SO_LAUNCH
     return hipGetLastError();
 }
 
@@ -235,7 +312,8 @@ template <int VPL>
 static hipError_t run_so(adc_handle* h, int passes)
 {
     // scanline_optimizer.cpp:54-60 (cost_aggr_ == vol_a, cost_init_ == vol_b)
-    hipError_t e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1);
+    hipError_t e = adc_launch_so_classes(h);
+    if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1);
     if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1);
     if (e == hipSuccess && passes >= 3) e = launch_so<VPL>(h, h->vol_a, h->vol_b, true, +1);
     if (e == hipSuccess && passes >= 4) e = launch_so<VPL>(h, h->vol_b, h->vol_a, true, -1);

@@ -21,73 +21,78 @@ __device__ __forceinline__ void wave_argmin(float& c, int& d)
     }
 }
 
+#define WTA_PPW 8 // pixels per wave: their loads are all issued before the first reduction
+
 template <int VPL, bool RIGHT>
 __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, float* __restrict__ disp, int W, int H, int dmin,
                                              int D)
 {
     constexpr int Dp = 64 * VPL;
     const int lane = threadIdx.x & 63;
-    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= (long long)W * H) return;
-    const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
+    const long long P = (long long)W * H;
+    const long long pix0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * WTA_PPW;
+    if (pix0 >= P) return;
     const int dmax = dmin + D;
 
-    // candidate costs of this lane
-    float c[VPL];
-    float bc = ADC_LARGE_FLOAT;
-    int bd = 0x7fffffff; // "none": keeps best_disparity's initial 0 / min_cost Large_Float semantics below
+    float c[WTA_PPW][VPL];
 #pragma unroll
-    for (int k = 0; k < VPL; k++) {
-        const int di = lane * VPL + k;
-        float v = ADC_LARGE_FLOAT;
-        bool cand = false;
-        if (di < D) {
-            if (!RIGHT) {
-                v = vol[(size_t)pix * Dp + di];
-                cand = true;
-            } else {
-                const int col = x + di + dmin;
-                if (col >= 0 && col < W) {
-                    v = vol[((size_t)y * W + col) * Dp + di];
-                    cand = true;
-                }
-            }
-        }
-        c[k] = v;
-        // the scan updates only on min_cost > cost, min_cost starting at Large_Float
-        if (cand && v < bc) { bc = v; bd = di + dmin; }
-    }
-    wave_argmin(bc, bd);
-    int best = bd;
-    if (bd == 0x7fffffff) best = 0; // nothing below Large_Float: best_disparity keeps its initial 0
-
-    float out;
-    const bool edge = (best == dmin) || (best == dmax - 1);
-    if (edge) {
-        out = RIGHT ? (float)best : ADC_INVALID_FLOAT;
-    } else if (best - 1 - dmin < 0 || best + 1 - dmin >= D) {
-        out = (float)best; // reference indexes out of bounds here (only when best stayed 0 and dmin != 0)
-    } else {
-        // neighbours c1 = cost_local[best-1], c2 = cost_local[best+1]: fetch from the owning lanes
-        const int i1 = best - 1 - dmin, i2 = best + 1 - dmin;
-        float c1 = 0.f, c2 = 0.f;
+    for (int i = 0; i < WTA_PPW; i++) {
+        const long long pix = pix0 + i < P ? pix0 + i : P - 1; // clamped: loads stay unconditional
+        const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
 #pragma unroll
         for (int k = 0; k < VPL; k++) {
-            const float a = __shfl(c[k], i1 / VPL, 64);
-            const float b = __shfl(c[k], i2 / VPL, 64);
-            if ((i1 % VPL) == k) c1 = a;
-            if ((i2 % VPL) == k) c2 = b;
+            const int di = lane * VPL + k;
+            float v = ADC_LARGE_FLOAT;
+            if (!RIGHT) {
+                v = vol[(size_t)pix * Dp + di]; // padding lanes (di >= D) are masked below
+            } else {
+                const int col = x + di + dmin; // cost(xr, yr, d) = cost(xr + d, yl, d)
+                const int cc = col < 0 ? 0 : (col >= W ? W - 1 : col);
+                v = vol[((size_t)y * W + cc) * Dp + (di < Dp ? di : 0)];
+                if (col < 0 || col >= W) v = ADC_LARGE_FLOAT; // ADCensusStereo.cpp:281-283
+            }
+            c[i][k] = di < D ? v : ADC_LARGE_FLOAT;
         }
-        out = adc_subpixel(best, c1, c2, bc);
     }
-    if (lane == 0) disp[pix] = out;
+#pragma unroll
+    for (int i = 0; i < WTA_PPW; i++) {
+        if (pix0 + i >= P) break;
+        // the scan updates only on min_cost > cost, min_cost starting at Large_Float; lowest d wins ties
+        float bc = ADC_LARGE_FLOAT;
+        int bd = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < VPL; k++)
+            if (c[i][k] < bc) { bc = c[i][k]; bd = lane * VPL + k + dmin; }
+        wave_argmin(bc, bd);
+        const int best = bd == 0x7fffffff ? 0 : bd; // nothing below Large_Float: best_disparity keeps its initial 0
+        float out;
+        const bool edge = (best == dmin) || (best == dmax - 1);
+        if (edge) {
+            out = RIGHT ? (float)best : ADC_INVALID_FLOAT;
+        } else if (best - 1 - dmin < 0 || best + 1 - dmin >= D) {
+            out = (float)best; // reference indexes out of bounds here (only when best stayed 0 and dmin != 0)
+        } else {
+            // neighbours c1 = cost_local[best-1], c2 = cost_local[best+1]: fetch from the owning lanes
+            const int i1 = best - 1 - dmin, i2 = best + 1 - dmin;
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; k++) {
+                const float a = __shfl(c[i][k], i1 / VPL, 64);
+                const float b = __shfl(c[i][k], i2 / VPL, 64);
+                if ((i1 % VPL) == k) c1 = a;
+                if ((i2 % VPL) == k) c2 = b;
+            }
+            out = adc_subpixel(best, c1, c2, bc);
+        }
+        if (lane == 0) disp[pix0 + i] = out;
+    }
 }
 
 hipError_t adc_launch_wta(adc_handle* h)
 {
     const AdcParams& p = h->p;
     const long long P = (long long)p.W * p.H;
-    const unsigned blocks = (unsigned)((P + 3) / 4);
+    const unsigned blocks = (unsigned)((P + 4 * WTA_PPW - 1) / (4 * WTA_PPW));
 #define LAUNCH(V)                                                                                                       \
     do {                                                                                                                \
         hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->stream, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \

@@ -36,79 +36,84 @@ void emul_color_diffs(const uint8_t* img, uint8_t* dh, uint8_t* dv, int W, int H
 // ------------------------------------------------------------------ k_agg_march, one lane of one line
 // vol layout [H][W][D] (reference layout; a "lane" is one d).  Mirrors the kernel's loop structure:
 // prefetch registers, ring slots, 8-wide chunks, epilogue.
-static void agg_line(const float* src, float* dst, const uint8_t* arms, const uint16_t* sup, int W, int H, int D, int d,
-                     bool vert, bool divide, int fixed, int L, int m0, int m1, int PF)
+// ordered partial sum over cnt consecutive ring entries starting at p (8 / 4 / <4 wide chunks)
+static float agg_run(float acc, const float* p, int cnt)
+{
+    while (cnt >= 8) {
+        for (int k = 0; k < 8; k++) acc += p[k];
+        p += 8;
+        cnt -= 8;
+    }
+    if (cnt >= 4) {
+        for (int k = 0; k < 4; k++) acc += p[k];
+        p += 4;
+        cnt -= 4;
+    }
+    if (cnt > 0) {
+        acc += p[0];
+        if (cnt > 1) acc += p[1];
+        if (cnt > 2) acc += p[2];
+    }
+    return acc;
+}
+
+// rec = packed {lo, hi, count16} records of this line (contiguous along m).  Mirrors k_agg_march:
+// phase A (warm-up pushes), phase B steady state (register prefetch of PF entries + records, unclamped
+// refills while j + 2*PF <= hi), plain tail, phase C (outputs at the image end).
+static void agg_line(const float* src, float* dst, const uint32_t* rp, int W, int H, int D, int d, bool vert, bool divide,
+                     int fixed, int L, int m0, int m1, int PF)
 {
     const int R = 2 * L + 1;
     const int N = vert ? H : W;
     const int lo = std::max(0, m0 - L), hi = std::min(N, m1 + L);
-    std::vector<float> ring(R, NAN), pf(PF, NAN);
-    std::vector<uint32_t> pa(PF), ps(PF);
+    std::vector<float> ring(R, NAN), pf(PF, NAN), t(PF, NAN);
+    std::vector<uint32_t> pr(PF);
     auto pix_of = [&](int m) -> size_t { return vert ? (size_t)m * W + fixed : (size_t)fixed * W + m; };
-    auto arms32 = [&](size_t pix) -> uint32_t { uint32_t v; memcpy(&v, arms + pix * 4, 4); return v; };
-    for (int u = 0; u < PF; u++) {
-        const int e = std::min(lo + u, hi - 1);
-        const int mo = std::min(std::max(e - L, m0), m1 - 1);
-        pf[u] = src[pix_of(e) * D + d];
-        pa[u] = arms32(pix_of(mo));
-        ps[u] = divide ? sup[pix_of(mo)] : 1u;
-    }
     int slot_w = 0, slot_m = m0 - lo;
-    auto emit = [&](int m, uint32_t a32, uint32_t cnt) {
-        const size_t pix = pix_of(m);
-        const int alo = vert ? (a32 >> 16) & 255u : a32 & 255u, ahi = vert ? (a32 >> 24) & 255u : (a32 >> 8) & 255u;
-        int n = alo + ahi + 1;
-        int idx = slot_m - alo;
+    auto push = [&](float v) { ring[slot_w] = v; slot_w = slot_w + 1 == R ? 0 : slot_w + 1; };
+    auto emit = [&](int m, uint32_t r) {
+        const int a_lo = r & 255u, a_hi = (r >> 8) & 255u;
+        int idx = slot_m - a_lo;
         if (idx < 0) idx += R;
-        float acc = 0.0f;
-        while (n > 0) {
-            float v[8];
-            for (int k = 0; k < 8; k++) {
-                int s = idx + k;
-                if (s >= R) s -= R;
-                v[k] = ring[s];
-            }
-            for (int k = 0; k < 8; k++)
-                if (k < n) acc += v[k];
-            idx += 8;
-            if (idx >= R) idx -= R;
-            n -= 8;
+        const int n = a_lo + a_hi + 1;
+        const int n1 = std::min(n, R - idx);
+        float acc = agg_run(0.0f, ring.data() + idx, n1);
+        if (n > n1) acc = agg_run(acc, ring.data(), n - n1);
+        if (divide) {
+            const uint32_t c = r >> 16;
+            if (c != 1u) acc = acc / (float)c;
         }
-        if (divide) acc = acc / (float)cnt;
-        dst[pix * D + d] = acc;
-        slot_m++;
-        if (slot_m == R) slot_m = 0;
+        dst[pix_of(m) * D + d] = acc;
+        slot_m = slot_m + 1 == R ? 0 : slot_m + 1;
     };
-    int j = lo;
-    for (; j + PF <= hi; j += PF)
-        for (int u = 0; u < PF; u++) {
-            const int jj = j + u;
-            const float v = pf[u];
-            const uint32_t a32 = pa[u], cnt = ps[u];
-            {
-                const int e = std::min(jj + PF, hi - 1);
-                const int mo = std::min(std::max(e - L, m0), m1 - 1);
-                pf[u] = src[pix_of(e) * D + d];
-                pa[u] = arms32(pix_of(mo));
-                if (divide) ps[u] = sup[pix_of(mo)];
-            }
-            ring[slot_w] = v;
-            slot_w++;
-            if (slot_w == R) slot_w = 0;
-            const int m = jj - L;
-            if (m >= m0 && m < m1) emit(m, a32, cnt);
-        }
-    for (int u = 0; u < PF; u++) {
-        const int jj = j + u;
-        if (jj < hi) {
-            ring[slot_w] = pf[u];
-            slot_w++;
-            if (slot_w == R) slot_w = 0;
-            const int m = jj - L;
-            if (m >= m0 && m < m1) emit(m, pa[u], ps[u]);
-        }
+    const int jB = std::min(hi, m0 + L);
+    for (int j = lo; j < jB; j += PF) {
+        for (int u = 0; u < PF; u++) t[u] = src[pix_of(std::min(j + u, jB - 1)) * D + d];
+        for (int u = 0; u < PF; u++)
+            if (j + u < jB) push(t[u]);
     }
-    for (int m = std::max(m0, hi - L); m < m1; m++) emit(m, arms32(pix_of(m)), divide ? sup[pix_of(m)] : 1u);
+    int j = jB;
+    if (j + 2 * PF <= hi) {
+        int nxt = j;
+        for (int u = 0; u < PF; u++, nxt++) { pf[u] = src[pix_of(nxt) * D + d]; pr[u] = rp[nxt - L]; }
+        for (; j + 2 * PF <= hi; j += PF)
+            for (int u = 0; u < PF; u++, nxt++) {
+                const float v = pf[u];
+                const uint32_t r = pr[u];
+                pf[u] = src[pix_of(nxt) * D + d];
+                pr[u] = rp[nxt - L];
+                push(v);
+                emit(j + u - L, r);
+            }
+        for (int u = 0; u < PF; u++) { push(pf[u]); emit(j + u - L, pr[u]); }
+        j += PF;
+    }
+    for (; j < hi; j++) {
+        push(src[pix_of(j) * D + d]);
+        const int m = j - L;
+        if (m >= m0) emit(m, rp[m]);
+    }
+    for (int m = std::max(m0, hi - L); m < m1; m++) emit(m, rp[m]);
 }
 
 void emul_aggregate_pass(const float* src, float* dst, const uint8_t* arms, const uint16_t* sup, int W, int H, int D,
@@ -119,10 +124,20 @@ void emul_aggregate_pass(const float* src, float* dst, const uint8_t* arms, cons
     if (seg_len < 1) seg_len = 1;
     nseg = (N + seg_len - 1) / seg_len;
     const int nfixed = vert ? W : H;
+    // packed records as k_make_records builds them (`sup` = the divisor map of this pass)
+    std::vector<uint32_t> rec((size_t)W * H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const uint8_t* a = arms + p * 4;
+            if (vert) rec[(size_t)x * H + y] = (uint32_t)a[2] | ((uint32_t)a[3] << 8) | ((uint32_t)sup[p] << 16);
+            else rec[p] = (uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)sup[p] << 16);
+        }
     for (int seg = 0; seg < nseg; seg++) {
         const int m0 = seg * seg_len, m1 = std::min(N, m0 + seg_len);
         for (int f = 0; f < nfixed; f++)
-            for (int d = 0; d < D; d++) agg_line(src, dst, arms, sup, W, H, D, d, vert != 0, divide != 0, f, L, m0, m1, PF);
+            for (int d = 0; d < D; d++)
+                agg_line(src, dst, rec.data() + (size_t)f * N, W, H, D, d, vert != 0, divide != 0, f, L, m0, m1, PF);
     }
 }
 

@@ -36,7 +36,7 @@ def dumps(port_oracle):
 
 
 @pytest.mark.parametrize("name", ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2"])
-@pytest.mark.parametrize("pf,hseg,vseg", [(16, 4, 2), (5, 3, 1), (1, 1, 7)])
+@pytest.mark.parametrize("pf,hseg,vseg", [(8, 1, 1), (8, 4, 2), (5, 3, 1), (2, 1, 7)])
 def test_marching_ring_aggregation(emul, dumps, name, pf, hseg, vseg):
     left, right, opt, o = dumps(name)
     h, w = left.shape[:2]
