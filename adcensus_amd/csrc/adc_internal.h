@@ -33,7 +33,11 @@ struct AdcParams {
 struct adc_handle {
     AdcParams p;
     int device;
-    hipStream_t stream;
+    hipStream_t stream; // per-object stream: uploads, refinement (latency-bound kernels), downloads
+    hipStream_t heavy;  // bandwidth lane: cost/arms/aggregate/scanline/WTA kernels.  Shared by all objects of a
+                        // device (FIFO), so the streaming kernels of different pairs never fight for HBM while
+                        // the latency-bound refinement of one pair overlaps the streaming phase of the next
+    hipEvent_t ev_in, ev_heavy_done;
     bool own_stream;
 
     // images + per-pixel maps

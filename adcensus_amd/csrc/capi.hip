@@ -10,6 +10,7 @@
 #include <string.h>
 #include <string>
 #include <new>
+#include <mutex>
 
 static thread_local std::string g_last_error;
 
@@ -84,7 +85,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->elig, P));
     HIP_OK(hipMalloc(&h->vote_list, P * 4));
     HIP_OK(hipMalloc(&h->vote_dirty, P * 4));
-    HIP_OK(hipMalloc(&h->vote_counters, 256 * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
     const size_t tiles = (size_t)((p.W + 15) / 16) * ((p.H + 15) / 16);
     HIP_OK(hipMalloc(&h->chg_a, tiles * 4));
     HIP_OK(hipMalloc(&h->chg_b, tiles * 4));
@@ -131,6 +132,20 @@ static hipError_t upload_tables(adc_handle* h)
     return hipSuccess;
 }
 
+// One "bandwidth lane" stream per device, shared by every object on it (never destroyed).  ADC_SHARED_HEAVY=0
+// makes every object use its own stream for everything.
+static hipStream_t shared_heavy_stream(int dev, hipStream_t own)
+{
+    static const bool shared = [] { const char* e = getenv("ADC_SHARED_HEAVY"); return e ? atoi(e) != 0 : false; }();
+    if (!shared) return own;
+    static std::mutex mu;
+    static hipStream_t lanes[64] = {nullptr};
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64) return own;
+    if (!lanes[dev] && hipStreamCreateWithFlags(&lanes[dev], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return lanes[dev];
+}
+
 adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int device)
 {
     g_last_error.clear();
@@ -155,6 +170,9 @@ adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int
     h->p.opt = *opt;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
     h->own_stream = ok;
+    if (ok) ok = (h->heavy = shared_heavy_stream(dev, h->stream)) != nullptr;
+    if (ok) ok = hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
+    if (ok) ok = hipEventCreateWithFlags(&h->ev_heavy_done, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i <= ADC_STAGE_COUNT; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
     for (int i = 0; ok && i < 9; i++) ok = hipEventCreate(&h->ev_agg[i]) == hipSuccess;
     if (ok) ok = alloc_all(h) == hipSuccess;
@@ -174,6 +192,7 @@ void adc_destroy(adc_handle* h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->rec_h, h->rec_v, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->vote_list, h->vote_dirty, h->vote_counters,
@@ -183,6 +202,8 @@ void adc_destroy(adc_handle* h)
     if (h->pin_out) hipHostFree(h->pin_out);
     for (int i = 0; i <= ADC_STAGE_COUNT; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 9; i++) if (h->ev_agg[i]) hipEventDestroy(h->ev_agg[i]);
+    if (h->ev_in) hipEventDestroy(h->ev_in);
+    if (h->ev_heavy_done) hipEventDestroy(h->ev_heavy_done);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -205,27 +226,61 @@ static hipError_t run_refine(adc_handle* h)
     return hipSuccess;
 }
 
-static hipError_t run_pipeline(adc_handle* h)
+// The streaming phase (cost .. WTA, ~26 passes over the volume) of different objects on one device is
+// made mutually exclusive with a host lock: bandwidth-bound kernels of two pairs only fight for HBM/L2,
+// while the latency-bound refinement (one-CU median, voting rounds) of one pair overlaps the streaming
+// phase of the next.  ADC_HEAVY_EXCLUSIVE=0 lets everything overlap freely.
+static std::mutex& heavy_lock(int dev)
+{
+    static std::mutex locks[64];
+    return locks[(dev >= 0 && dev < 64) ? dev : 0];
+}
+static bool heavy_exclusive()
+{
+    static const bool v = [] { const char* e = getenv("ADC_HEAVY_EXCLUSIVE"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+
+static hipError_t run_heavy(adc_handle* h)
 {
     const bool prof = h->profiling != 0;
-#define MARK(i) do { if (prof) HIP_OK(hipEventRecord(h->ev[i], h->stream)); } while (0)
-    MARK(0);
+#define MARK(i, s) do { if (prof) HIP_OK(hipEventRecord(h->ev[i], s)); } while (0)
+    if (h->heavy != h->stream) {
+        HIP_OK(hipEventRecord(h->ev_in, h->stream));
+        HIP_OK(hipStreamWaitEvent(h->heavy, h->ev_in, 0));
+    }
+    MARK(0, h->heavy);
     HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
     HIP_OK(adc_launch_cost(h, h->vol_a));
-    MARK(1);
+    MARK(1, h->heavy);
     HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
-    MARK(2);
+    MARK(2, h->heavy);
     HIP_OK(adc_launch_records(h));
     HIP_OK(adc_launch_aggregate(h, 4));          // aggregator_.Aggregate(4), :164
-    MARK(3);
+    MARK(3, h->heavy);
     HIP_OK(adc_launch_scanline(h, 4));           // ScanlineOptimize, :100
-    MARK(4);
+    MARK(4, h->heavy);
     HIP_OK(adc_launch_wta(h));                   // ComputeDisparity + ComputeDisparityRight, :108-109
-    MARK(5);
-    HIP_OK(run_refine(h));                       // MultiStepRefine, :117
-    MARK(6);
+    MARK(5, h->heavy);
+    HIP_OK(hipEventRecord(h->ev_heavy_done, h->heavy));
+    if (h->heavy != h->stream) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_heavy_done, 0));
 #undef MARK
-    h->timings_pending = prof;
+    return hipSuccess;
+}
+
+static hipError_t run_pipeline(adc_handle* h)
+{
+    if (heavy_exclusive()) {
+        // the uploads of this pair (already queued on the object's stream) run before the lock is taken
+        std::lock_guard<std::mutex> lk(heavy_lock(h->device));
+        HIP_OK(run_heavy(h));
+        HIP_OK(hipEventSynchronize(h->ev_heavy_done)); // hold the lane until the streaming phase has drained
+    } else {
+        HIP_OK(run_heavy(h));
+    }
+    HIP_OK(run_refine(h));                       // MultiStepRefine, :117 (object stream)
+    if (h->profiling) HIP_OK(hipEventRecord(h->ev[6], h->stream));
+    h->timings_pending = h->profiling != 0;
     return hipSuccess;
 }
 
@@ -406,7 +461,8 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     default: return 1;
     }
     if (e != hipSuccess) { set_error("adc_debug_run launch", e); return 2; }
-    e = hipStreamSynchronize(h->stream);
+    e = hipStreamSynchronize(h->heavy);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { set_error("adc_debug_run sync", e); return 2; }
     return 0;
 }

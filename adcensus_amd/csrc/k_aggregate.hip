@@ -264,7 +264,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     const int L = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
     const size_t lds = (size_t)(2 * L + 1) * 64 * sizeof(float);
     if (direct || lds > 150 * 1024) {
-        hipLaunchKernelGGL((k_agg_direct<VERT, DIVIDE>), dim3(256 * 16), dim3(256), 0, h->stream, src, dst,
+        hipLaunchKernelGGL((k_agg_direct<VERT, DIVIDE>), dim3(256 * 16), dim3(256), 0, h->heavy, src, dst,
                            reinterpret_cast<const uchar4*>(h->arms), VERT ? h->sup_h : h->sup_v, p.W, p.H, p.Dp);
         return hipGetLastError();
     }
@@ -278,7 +278,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     nseg = (N + seg_len - 1) / seg_len;
     const long long waves = nlines * nseg;
     const int per_xcd = (int)((waves + 7) / 8);
-    hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), lds, h->stream, src, dst,
+    hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), lds, h->heavy, src, dst,
                        VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, L, seg_len, nseg, per_xcd);
     return hipGetLastError();
 }
@@ -300,22 +300,22 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     bool horizontal_first = true; // cross_aggregator.cpp:100
     int launch = 0;
     for (int k = 0; k < iterations && e == hipSuccess; k++) {
-        if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->stream);
+        if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
         if (horizontal_first) {
             e = launch_pass<false, false>(h, h->vol_a, h->vol_b, direct);
             launch++;
-            if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->stream);
+            if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
             if (e == hipSuccess) e = launch_pass<true, true>(h, h->vol_b, h->vol_a, direct); // / sup_h
         } else {
             e = launch_pass<true, false>(h, h->vol_a, h->vol_b, direct);
             launch++;
-            if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->stream);
+            if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
             if (e == hipSuccess) e = launch_pass<false, true>(h, h->vol_b, h->vol_a, direct); // / sup_v
         }
         launch++;
         horizontal_first = !horizontal_first;
     }
-    if (h->profiling) hipEventRecord(h->ev_agg[launch < 8 ? launch : 8], h->stream);
+    if (h->profiling) hipEventRecord(h->ev_agg[launch < 8 ? launch : 8], h->heavy);
     h->agg_launches = launch < 8 ? launch : 8;
     return e;
 }

@@ -113,7 +113,7 @@ hipError_t adc_launch_records(adc_handle* h)
 {
     const AdcParams& p = h->p;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(k_make_records, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
+    hipLaunchKernelGGL(k_make_records, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
                        h->rec_h, h->rec_v, p.W, p.H);
     return hipGetLastError();
 }
@@ -122,12 +122,12 @@ hipError_t adc_launch_arms(adc_handle* h)
 {
     const AdcParams& p = h->p;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->stream, h->img_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
+    hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->img_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
                        p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2);
-    hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
+    hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
                        p.W, p.H);
     dim3 grid2(grid.x, grid.y, 2);
-    hipLaunchKernelGGL(k_color_diffs, grid2, block, 0, h->stream, h->img_l, h->img_r, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh,
+    hipLaunchKernelGGL(k_color_diffs, grid2, block, 0, h->heavy, h->img_l, h->img_r, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh,
                        h->cdiff_rv, p.W, p.H);
     return hipGetLastError();
 }

@@ -63,7 +63,7 @@ hipError_t adc_launch_gray_census(adc_handle* h)
 {
     const AdcParams& p = h->p;
     dim3 grid((p.W + CT_W - 1) / CT_W, (p.H + CT_H - 1) / CT_H, 2), block(CT_W, CT_H, 1);
-    hipLaunchKernelGGL(k_gray_census, grid, block, 0, h->stream, h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l,
+    hipLaunchKernelGGL(k_gray_census, grid, block, 0, h->heavy, h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l,
                        h->census_r, p.W, p.H);
     return hipGetLastError();
 }
@@ -145,7 +145,7 @@ hipError_t adc_launch_cost(adc_handle* h, float* vol_out)
     const AdcParams& p = h->p;
     dim3 grid((p.W + COST_TX - 1) / COST_TX, p.H, 1), block(256, 1, 1);
 #define LAUNCH(V)                                                                                                     \
-    hipLaunchKernelGGL(k_cost<V>, grid, block, 0, h->stream, h->img_l, h->img_r, h->census_l, h->census_r, h->lut_ad, \
+    hipLaunchKernelGGL(k_cost<V>, grid, block, 0, h->heavy, h->img_l, h->img_r, h->census_l, h->census_r, h->lut_ad, \
                        h->lut_census, vol_out, p.W, p.H, p.dmin, p.D)
     if (p.VPL == 1) LAUNCH(1);
     else if (p.VPL == 2) LAUNCH(2);

@@ -255,6 +255,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
     int32_t host_cnt[136];
     int32_t* chg = reinterpret_cast<int32_t*>(h->chg_a);
     for (int it = 0; it < 5; it++) {         // multistep_refiner.cpp:167
+        bool filled_any = false; // an iteration that fills nothing leaves the map unchanged: the remaining ones are no-ops
         for (int k = 0; k < 2; k++) {        // mismatches, then occlusions (:170-171)
             if ((e = hipMemsetAsync(h->vote_counters, 0, 136 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
@@ -285,6 +286,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
                 }
                 if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 136 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
                 if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
+                if (r0 == 0 && host_cnt[IRV_FLAG(0)] != 0) filled_any = true;
                 for (int round = r0; round < r0 + BATCH; round++) {
                     h->vote_rounds++;
                     if (host_cnt[IRV_FLAG(round)] == 0) { done = true; break; } // full round without change: fixed point
@@ -293,6 +295,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
             }
             h->vote_evals += host_cnt[2];
         }
+        if (!filled_any) break;
     }
     return hipGetLastError();
 }
@@ -339,15 +342,93 @@ __global__ __launch_bounds__(256) void k_interpolate(const float* __restrict__ d
     dout[p] = any ? best : 0.0f; // no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
 }
 
+// Ray-parallel variant: the target pixels of the list are compacted first (k_irv_begin), then 16 lanes
+// work on one pixel, one ray each (4 pixels per wave); the 16 first-hits are combined with a 16-lane
+// butterfly: mismatch -> lexicographic min of (L1 colour distance, ray index) == "first minimum" of the
+// sequential scan over s; occlusion -> smallest disparity.
+__global__ __launch_bounds__(256) void k_interpolate_rays(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
+                                                          const float* __restrict__ din, float* __restrict__ dout,
+                                                          const uint8_t* __restrict__ img_l, const double* __restrict__ sincos,
+                                                          int W, int H, int which, int max_search)
+{
+    const int n = counters[0];
+    const int lane = threadIdx.x & 63;
+    const int s = lane & 15;                       // ray index
+    const int grp = (blockIdx.x * 256 + threadIdx.x) >> 4; // pixel slot
+    const int ngrp = (gridDim.x * 256) >> 4;
+    const double sina = sincos[2 * s], cosa = sincos[2 * s + 1];
+    const bool mismatch = which == ADC_LABEL_MISMATCH;
+    for (int e = grp; e < ((n + 3) & ~3); e += ngrp) { // whole waves iterate together (4 pixels per wave)
+        const bool live = e < n;
+        const int p = live ? list[e] : 0;
+        const int y = p / W, x = p - y * W;
+        float hit = ADC_INVALID_FLOAT; // first valid disparity along this ray
+        int dist = 0x3fffffff;
+        if (live) {
+            for (int m = 1; m < max_search; m++) {
+                const int yy = (int)lround((double)y + (double)m * sina); // multistep_refiner.cpp:259-260
+                const int xx = (int)lround((double)x + (double)m * cosa);
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) break;
+                const float d = din[(size_t)yy * W + xx];
+                if (d != ADC_INVALID_FLOAT) {
+                    hit = d;
+                    if (mismatch) dist = adc_color_dist_l1(img_l + (size_t)p * 3, img_l + ((size_t)yy * W + xx) * 3);
+                    break;
+                }
+            }
+        }
+        // combine the 16 rays of this pixel
+        float best;
+        bool any;
+        if (mismatch) { // colour-nearest, first minimum in ray order (multistep_refiner.cpp:276-289; min_dist starts at 9999)
+            int key = (hit != ADC_INVALID_FLOAT && dist < 9999) ? dist * 16 + s : 0x7fffffff;
+            float val = hit;
+#pragma unroll
+            for (int msk = 8; msk >= 1; msk >>= 1) {
+                const int ok = __shfl_xor(key, msk, 64);
+                const float ov = __shfl_xor(val, msk, 64);
+                if (ok < key) { key = ok; val = ov; }
+            }
+            // the reference keeps d = 0.0f when every collected distance is >= 9999 (impossible: max 765)
+            unsigned long long hb = __ballot(hit != ADC_INVALID_FLOAT);
+            any = ((hb >> (lane & 48)) & 0xffffull) != 0;
+            best = key != 0x7fffffff ? val : 0.0f;
+        } else { // smallest disparity (multistep_refiner.cpp:290-296)
+            float val = hit;
+#pragma unroll
+            for (int msk = 8; msk >= 1; msk >>= 1) {
+                const float ov = __shfl_xor(val, msk, 64);
+                val = ov < val ? ov : val;
+            }
+            any = val != ADC_INVALID_FLOAT;
+            best = val;
+        }
+        if (live && s == 0) dout[p] = any ? best : 0.0f; // no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
+    }
+}
+
 hipError_t adc_launch_interpolation(adc_handle* h)
 {
     const AdcParams& p = h->p;
+    const int P = p.W * p.H;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     const int dmaxa = p.dmax < 0 ? -p.dmax : p.dmax, dmina = p.dmin < 0 ? -p.dmin : p.dmin;
     const int max_search = dmaxa > dmina ? dmaxa : dmina; // multistep_refiner.cpp:236
+    static const bool rays = [] { const char* e = getenv("ADC_INTERP_RAYS"); return e ? atoi(e) != 0 : true; }();
     for (int k = 0; k < 2; k++) {
-        hipLaunchKernelGGL(k_interpolate, grid, block, 0, h->stream, h->disp_l, h->disp_tmp, h->label, h->img_l, h->ray_sincos,
-                           p.W, p.H, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, max_search);
+        const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
+        if (rays) {
+            hipError_t e;
+            if ((e = hipMemsetAsync(h->vote_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
+                               h->vote_list, h->vote_counters, which, P, -1);
+            if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
+                               h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
+        } else {
+            hipLaunchKernelGGL(k_interpolate, grid, block, 0, h->stream, h->disp_l, h->disp_tmp, h->label, h->img_l, h->ray_sincos,
+                               p.W, p.H, which, max_search);
+        }
         float* t = h->disp_l;
         h->disp_l = h->disp_tmp;
         h->disp_tmp = t;
@@ -506,6 +587,117 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
     }
 }
 
+// ---- multi-workgroup variant: bands of MEDB_ROWS rows, one workgroup (one thread per row) per band.
+// Band b's first row needs the filtered last row of band b-1 one level later; to keep that cross-CU
+// hand-off off the per-level critical path, band b runs >= MEDB_K levels behind band b-1: the upstream
+// band publishes its level counter every MEDB_K levels (write-through row stores, drained, then an
+// agent-scope counter store -- cdna guide G16 recipe R1), the downstream band polls it once per
+// MEDB_K levels and reads the row with agent-scope loads.  Dependencies only point upstream, all
+// bands are co-resident (<= 80 workgroups), spins are bounded (error word + bail out).
+#define MEDB_ROWS 128
+#define MEDB_K 16
+
+__global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* out, int W, int H,
+                                                             int* progress, int* error_word)
+{
+    __shared__ float mring[MEDB_ROWS * 4];
+    const int tid = threadIdx.x;
+    const int band = blockIdx.x;
+    const int y = band * MEDB_ROWS + tid;
+    const int nsteps = W + 2 * (H - 1);
+    const bool row_ok = y < H;
+    const bool first_row = tid == 0 && band > 0;                      // reads the upstream band's last row
+    const bool last_row = row_ok && (tid == MEDB_ROWS - 1 || y == H - 1) && (y + 1 < H); // feeds the downstream band
+    auto clampc = [&](int c) __attribute__((always_inline)) { return c < 0 ? 0 : (c >= W ? W - 1 : c); };
+    const int ya = row_ok ? y : H - 1, yb = y + 1 < H ? y + 1 : H - 1;
+    const float* rowA = in + (size_t)ya * W;
+    const float* rowB = in + (size_t)yb * W;
+    const float* rowUp = out + (size_t)(y > 0 ? y - 1 : 0) * W; // upstream band's last row (first_row only)
+    int x0 = -2 * y; // column at level 0
+    float A0 = rowA[clampc(x0)], A1 = rowA[clampc(x0 + 1)];
+    float Bm = rowB[clampc(x0 - 1)], B0 = rowB[clampc(x0)], B1 = rowB[clampc(x0 + 1)];
+    float Fm = 0.f, F0 = 0.f, Pv = 0.f;
+    float fa[MED_K], fb[MED_K];
+    float fu[MED_K]; // first_row only: upstream row values for the next MED_K levels (prefetched, agent-scope loads)
+#pragma unroll
+    for (int k = 0; k < MED_K; k++) {
+        fa[k] = rowA[clampc(x0 + 2 + k)];
+        fb[k] = rowB[clampc(x0 + 2 + k)];
+        fu[k] = 0.0f; // levels 0..MED_K-1 of a band > 0 are idle for its first row (x < 0): never used
+    }
+    __shared__ int bail;
+    if (tid == 0) bail = 0;
+    __syncthreads();
+
+    for (int t0 = 0; t0 < nsteps; t0 += MED_K) {
+        if ((t0 % MEDB_K) == 0 && band > 0) {
+            // stay >= MEDB_K levels behind the upstream band (checked once per MEDB_K levels)
+            if (tid == 0) {
+                // levels t0 .. t0+MEDB_K-1 prefetch upstream values up to MED_K levels ahead
+                const int need = t0 + MEDB_K + MED_K < nsteps ? t0 + MEDB_K + MED_K : nsteps;
+                int spins = 0;
+                while (__hip_atomic_load(&progress[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) { bail = 1; atomicExch(error_word, 1); break; }
+                }
+            }
+            __syncthreads();
+            if (bail) return;
+        }
+#pragma unroll
+        for (int k = 0; k < MED_K; k++) {
+            const int t = t0 + k;
+            const int x = t - 2 * y;
+            const float na = fa[k], nb = fb[k];
+            fa[k] = rowA[clampc(x + 2 + MED_K)];
+            fb[k] = rowB[clampc(x + 2 + MED_K)];
+            const bool active = (t < nsteps) && row_ok && (x >= 0) && (x < W);
+            // newest filtered value of the row above: out[y-1][x+1] was produced at level t-1
+            float F1 = 0.0f;
+            if (first_row) {
+                // out[y-1][x+1] of level t was prefetched at level t-MED_K; refill the slot for level t+MED_K
+                F1 = fu[k];
+                fu[k] = __hip_atomic_load(rowUp + clampc(x + 1 + MED_K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (row_ok && tid > 0 && x + 1 >= 0 && x + 1 < W) {
+                F1 = mring[(tid - 1) * 4 + ((x + 1) & 3)];
+            }
+            if (active) {
+                const bool up = y > 0, dn = y + 1 < H, lf = x > 0, rt = x + 1 < W;
+                float v[9];
+                int n = 1;
+                v[0] = (up && lf) ? Fm : ADC_INVALID_FLOAT; n += (up && lf);
+                v[1] = up ? F0 : ADC_INVALID_FLOAT;          n += up;
+                v[2] = (up && rt) ? F1 : ADC_INVALID_FLOAT;  n += (up && rt);
+                v[3] = lf ? Pv : ADC_INVALID_FLOAT;          n += lf;
+                v[4] = A0;
+                v[5] = rt ? A1 : ADC_INVALID_FLOAT;          n += rt;
+                v[6] = (dn && lf) ? Bm : ADC_INVALID_FLOAT;  n += (dn && lf);
+                v[7] = dn ? B0 : ADC_INVALID_FLOAT;          n += dn;
+                v[8] = (dn && rt) ? B1 : ADC_INVALID_FLOAT;  n += (dn && rt);
+                adc_sort9(v);
+                const int sel = n / 2; // wnd_data[size/2], adcensus_util.cpp:77
+                float res = v[0];
+#pragma unroll
+                for (int i = 1; i < 9; i++) res = (i == sel) ? v[i] : res;
+                if (last_row) __hip_atomic_store(out + (size_t)y * W + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through
+                else out[(size_t)y * W + x] = res;
+                mring[tid * 4 + (x & 3)] = res;
+                Pv = res;
+            }
+            Fm = F0; F0 = F1;
+            A0 = A1; A1 = na;
+            Bm = B0; B0 = B1; B1 = nb;
+            __syncthreads();
+            // publish "levels completed" every MEDB_K levels (and at the end): the thread that stores the
+            // band's last row drains ITS stores first, then stores the counter
+            if (last_row && (((t + 1) % MEDB_K) == 0 || t + 1 >= nsteps) && t < nsteps) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&progress[band], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 hipError_t adc_launch_median(adc_handle* h)
 {
     const AdcParams& p = h->p;
@@ -516,6 +708,19 @@ hipError_t adc_launch_median(adc_handle* h)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    static const bool banded = [] { const char* e = getenv("ADC_MEDIAN_BANDED"); return e ? atoi(e) != 0 : true; }();
+    const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
+    if (banded && nbands > 1 && nbands <= 80) {
+        // progress counters + error word live in vote_counters[160..]; zeroed on the stream before every launch
+        int* prog = h->vote_counters + 160;
+        hipMemsetAsync(prog, 0, 96 * sizeof(int32_t), h->stream);
+        hipLaunchKernelGGL(k_median_banded, dim3(nbands), dim3(MEDB_ROWS), 0, h->stream, h->disp_l, h->disp_tmp, p.W, p.H, prog,
+                           prog + 88);
+        float* t = h->disp_l;
+        h->disp_l = h->disp_tmp;
+        h->disp_tmp = t;
+        return hipGetLastError();
     }
     const size_t lds = (size_t)p.H * 4 * sizeof(float);
     if (p.H > 8192) return hipErrorInvalidValue; // LDS ring of H*16 B and <= 8 rows per thread

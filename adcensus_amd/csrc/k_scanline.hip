@@ -150,7 +150,7 @@ hipError_t adc_launch_so_classes(adc_handle* h)
     const long long P = (long long)p.W * p.H;
     const unsigned blocks = (unsigned)((P * 16 + 255) / 256);
 #define CLS_LAUNCH(V)                                                                                                    \
-    hipLaunchKernelGGL(k_so_classes<V>, dim3(blocks), dim3(256), 0, h->stream, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, \
+    hipLaunchKernelGGL(k_so_classes<V>, dim3(blocks), dim3(256), 0, h->heavy, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, \
                        h->cdiff_rv, h->so_cls, p.W, p.H, p.dmin, p.D, p.opt.so_tso)
     if (p.VPL == 1) CLS_LAUNCH(1);
     else if (p.VPL == 2) CLS_LAUNCH(2);
@@ -299,7 +299,7 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
     const int pass = (vert ? 2 : 0) + (dir > 0 ? 0 : 1);
     const uint8_t* cls = h->so_cls + (size_t)pass * p.W * p.H * 64;
 #define SO_LAUNCH(VERT_, DPP_)                                                                                         \
-    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_>), dim3(blocks), dim3(256), 0, h->stream, src, dst, cls, p.W, p.H, \
+    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_>), dim3(blocks), dim3(256), 0, h->heavy, src, dst, cls, p.W, p.H, \
                        p.D, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2])
     const bool dpp = so_use_dpp();
     if (vert) { if (dpp) SO_LAUNCH(true, true); else SO_LAUNCH(true, false); }
@@ -319,7 +319,7 @@ static hipError_t run_so(adc_handle* h, int passes)
     if (e == hipSuccess && passes >= 4) e = launch_so<VPL>(h, h->vol_b, h->vol_a, true, -1);
     if (e == hipSuccess && (passes == 1 || passes == 3)) // debug: leave the partial result in vol_a
         e = hipMemcpyAsync(h->vol_a, h->vol_b, (size_t)h->p.W * h->p.H * h->p.Dp * sizeof(float), hipMemcpyDeviceToDevice,
-                           h->stream);
+                           h->heavy);
     return e;
 }
 

@@ -95,8 +95,8 @@ hipError_t adc_launch_wta(adc_handle* h)
     const unsigned blocks = (unsigned)((P + 4 * WTA_PPW - 1) / (4 * WTA_PPW));
 #define LAUNCH(V)                                                                                                       \
     do {                                                                                                                \
-        hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->stream, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \
-        hipLaunchKernelGGL((k_wta<V, true>), dim3(blocks), dim3(256), 0, h->stream, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D);  \
+        hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \
+        hipLaunchKernelGGL((k_wta<V, true>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D);  \
     } while (0)
     if (p.VPL == 1) LAUNCH(1);
     else if (p.VPL == 2) LAUNCH(2);

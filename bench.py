@@ -109,28 +109,15 @@ def main():
         if errs:
             raise SystemExit("Match failed: %s" % errs[0])
 
-    def sync_all():
-        if dist is not None:
-            dist.barrier()
-        lib.adc_device_synchronize()
-
-    run_steps(a.warmup)
-    sync_all()
+    from adcensus_amd import farm
     prof = []
-    t0 = time.perf_counter()
-    run_steps(a.steps, prof)
-    lib.adc_device_synchronize()
-    if dist is not None:
-        dist.barrier()
-    lib.adc_device_synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, total_steps = farm.timed_region(lambda n: run_steps(n, prof), a.steps, a.warmup, dist=dist,
+                                             device_sync=lib.adc_device_synchronize,
+                                             tensor_device="cuda" if dist is not None else "cpu")
+    prof = prof[-a.steps:] if len(prof) > a.steps else prof  # drop the warm-up samples of object 0
 
     if rank == 0:
-        total_pairs = a.steps * world
+        total_pairs = total_steps  # SUM over ranks of the steps each rank timed
         value = total_pairs / elapsed
         # roofline of the dominant kernel (aggregation pass): algorithmic bytes per launch / avg launch time
         V = 4.0 * P * D

@@ -95,3 +95,31 @@ def test_large_arm_limit_uses_fallback(hip, oracle):
     got = st.match(left, right)
     st.Release()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_cpp_facade_cli_cone(hip, oracle, tmp_path):
+    """Drop-in check: a main.cpp-style C++ program (examples/adcensus_cli.cpp) written against
+    include/ADCensusStereo.h (Initialize / Match) reproduces the reference output on the Cone pair."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "adcensus_amd", "bin", "adcensus_cli")
+    if not os.path.exists(cli):
+        pytest.fail("adcensus_cli not built (python -c 'import __graft_entry__ as g; g.build()')")
+    left, right, opt = cases.make_case("cone")
+    h, w = left.shape[:2]
+    for name, img in (("l.ppm", left), ("r.ppm", right)):
+        with open(tmp_path / name, "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (w, h))
+            f.write(np.ascontiguousarray(img[:, :, ::-1]).tobytes())
+    out = subprocess.run([cli, str(tmp_path / "l.ppm"), str(tmp_path / "r.ppm"), "0", "64", str(tmp_path / "out")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "cost aggregating! timing" in out.stdout  # the reference's stage lines (ADCensusStereo.cpp:88-129)
+    with open(tmp_path / "out.pfm", "rb") as f:
+        assert f.readline().strip() == b"Pf"
+        assert f.readline().split() == [str(w).encode(), str(h).encode()]
+        f.readline()
+        got = np.frombuffer(f.read(), dtype="<f4").reshape(h, w)[::-1]
+    want = oracle.run(left, right, opt, stages=["disp_final"])["disp_final"]
+    assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), want.view(np.uint32))
