@@ -595,12 +595,13 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
 // MEDB_K levels and reads the row with agent-scope loads.  Dependencies only point upstream, all
 // bands are co-resident (<= 80 workgroups), spins are bounded (error word + bail out).
 #define MEDB_ROWS 128
-#define MEDB_K 16
+#define MEDB_K 16 // levels per block: progress publication / polling period and bulk-prefetch depth
 
 __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* out, int W, int H,
                                                              int* progress, int* error_word)
 {
     __shared__ float mring[MEDB_ROWS * 4];
+    __shared__ int bail;
     const int tid = threadIdx.x;
     const int band = blockIdx.x;
     const int y = band * MEDB_ROWS + tid;
@@ -613,28 +614,29 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     const float* rowA = in + (size_t)ya * W;
     const float* rowB = in + (size_t)yb * W;
     const float* rowUp = out + (size_t)(y > 0 ? y - 1 : 0) * W; // upstream band's last row (first_row only)
-    int x0 = -2 * y; // column at level 0
+    const int x0 = -2 * y; // column at level 0
     float A0 = rowA[clampc(x0)], A1 = rowA[clampc(x0 + 1)];
     float Bm = rowB[clampc(x0 - 1)], B0 = rowB[clampc(x0)], B1 = rowB[clampc(x0 + 1)];
     float Fm = 0.f, F0 = 0.f, Pv = 0.f;
-    float fa[MED_K], fb[MED_K];
-    float fu[MED_K]; // first_row only: upstream row values for the next MED_K levels (prefetched, agent-scope loads)
+    // bulk prefetch: the new unfiltered columns (x+2 of rows y, y+1) and, for the band's first row, the
+    // upstream row values of a whole block of MEDB_K levels are loaded one block ahead, so the per-level
+    // critical path holds no global load (one vmcnt drain per block instead of one per level)
+    float na[MEDB_K], nb[MEDB_K], nu[MEDB_K];
 #pragma unroll
-    for (int k = 0; k < MED_K; k++) {
-        fa[k] = rowA[clampc(x0 + 2 + k)];
-        fb[k] = rowB[clampc(x0 + 2 + k)];
-        fu[k] = 0.0f; // levels 0..MED_K-1 of a band > 0 are idle for its first row (x < 0): never used
+    for (int k = 0; k < MEDB_K; k++) {
+        na[k] = rowA[clampc(x0 + 2 + k)];
+        nb[k] = rowB[clampc(x0 + 2 + k)];
+        nu[k] = 0.0f; // levels 0..MEDB_K-1 of a band > 0: its first row is idle (x < 0)
     }
-    __shared__ int bail;
     if (tid == 0) bail = 0;
     __syncthreads();
 
-    for (int t0 = 0; t0 < nsteps; t0 += MED_K) {
-        if ((t0 % MEDB_K) == 0 && band > 0) {
-            // stay >= MEDB_K levels behind the upstream band (checked once per MEDB_K levels)
+    for (int t0 = 0; t0 < nsteps; t0 += MEDB_K) {
+        if (band > 0) {
+            // stay behind the upstream band: this block reads its rows of levels < t0+MEDB_K and prefetches those of
+            // the next block (levels < t0 + 2*MEDB_K)
             if (tid == 0) {
-                // levels t0 .. t0+MEDB_K-1 prefetch upstream values up to MED_K levels ahead
-                const int need = t0 + MEDB_K + MED_K < nsteps ? t0 + MEDB_K + MED_K : nsteps;
+                const int need = t0 + 2 * MEDB_K < nsteps ? t0 + 2 * MEDB_K : nsteps;
                 int spins = 0;
                 while (__hip_atomic_load(&progress[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                     __builtin_amdgcn_s_sleep(8);
@@ -644,23 +646,27 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
             __syncthreads();
             if (bail) return;
         }
+        float ca[MEDB_K], cb[MEDB_K], cu[MEDB_K];
 #pragma unroll
-        for (int k = 0; k < MED_K; k++) {
+        for (int k = 0; k < MEDB_K; k++) { ca[k] = na[k]; cb[k] = nb[k]; cu[k] = nu[k]; }
+        {
+            const int xn = t0 + MEDB_K - 2 * y; // column of this row at the first level of the next block
+#pragma unroll
+            for (int k = 0; k < MEDB_K; k++) {
+                na[k] = rowA[clampc(xn + k + 2)];
+                nb[k] = rowB[clampc(xn + k + 2)];
+                if (first_row) nu[k] = __hip_atomic_load(rowUp + clampc(xn + k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MEDB_K; k++) {
             const int t = t0 + k;
             const int x = t - 2 * y;
-            const float na = fa[k], nb = fb[k];
-            fa[k] = rowA[clampc(x + 2 + MED_K)];
-            fb[k] = rowB[clampc(x + 2 + MED_K)];
             const bool active = (t < nsteps) && row_ok && (x >= 0) && (x < W);
             // newest filtered value of the row above: out[y-1][x+1] was produced at level t-1
             float F1 = 0.0f;
-            if (first_row) {
-                // out[y-1][x+1] of level t was prefetched at level t-MED_K; refill the slot for level t+MED_K
-                F1 = fu[k];
-                fu[k] = __hip_atomic_load(rowUp + clampc(x + 1 + MED_K), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (row_ok && tid > 0 && x + 1 >= 0 && x + 1 < W) {
-                F1 = mring[(tid - 1) * 4 + ((x + 1) & 3)];
-            }
+            if (first_row) F1 = cu[k];
+            else if (row_ok && tid > 0 && x + 1 >= 0 && x + 1 < W) F1 = mring[(tid - 1) * 4 + ((x + 1) & 3)];
             if (active) {
                 const bool up = y > 0, dn = y + 1 < H, lf = x > 0, rt = x + 1 < W;
                 float v[9];
@@ -685,15 +691,15 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
                 Pv = res;
             }
             Fm = F0; F0 = F1;
-            A0 = A1; A1 = na;
-            Bm = B0; B0 = B1; B1 = nb;
+            A0 = A1; A1 = ca[k];
+            Bm = B0; B0 = B1; B1 = cb[k];
             __syncthreads();
-            // publish "levels completed" every MEDB_K levels (and at the end): the thread that stores the
-            // band's last row drains ITS stores first, then stores the counter
-            if (last_row && (((t + 1) % MEDB_K) == 0 || t + 1 >= nsteps) && t < nsteps) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&progress[band], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        }
+        // publish "levels completed": the thread that stores the band's last row drains ITS stores first
+        if (last_row) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int done = t0 + MEDB_K < nsteps ? t0 + MEDB_K : nsteps;
+            __hip_atomic_store(&progress[band], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
