@@ -229,7 +229,8 @@ static hipError_t run_refine(adc_handle* h)
 // The streaming phase (cost .. WTA, ~26 passes over the volume) of different objects on one device is
 // made mutually exclusive with a host lock: bandwidth-bound kernels of two pairs only fight for HBM/L2,
 // while the latency-bound refinement (one-CU median, voting rounds) of one pair overlaps the streaming
-// phase of the next.  ADC_HEAVY_EXCLUSIVE=0 lets everything overlap freely.
+// phase of the next.  Measured on MI355X this is SLOWER than free overlap (56 vs 74 pairs/s with two objects),
+// so it is opt-in: ADC_HEAVY_EXCLUSIVE=1.
 static std::mutex& heavy_lock(int dev)
 {
     static std::mutex locks[64];
@@ -237,7 +238,7 @@ static std::mutex& heavy_lock(int dev)
 }
 static bool heavy_exclusive()
 {
-    static const bool v = [] { const char* e = getenv("ADC_HEAVY_EXCLUSIVE"); return e ? atoi(e) != 0 : true; }();
+    static const bool v = [] { const char* e = getenv("ADC_HEAVY_EXCLUSIVE"); return e ? atoi(e) != 0 : false; }();
     return v;
 }
 

@@ -260,26 +260,98 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         minLp = wave_min_f32<DPP>(omin_);                                                                  \
     } while (0)
 
-    // software prefetch ring: the inputs of the next SO_PF path elements stay in flight in registers.
-    // Prefetch loads are unconditional (index clamped to the path end) and carry no ALU work.
-    SoElem<VPL> pre[SO_PF];
+    if constexpr (VPL <= 2) {
+        // Prefetch ring with asm-issued loads and hand-counted vmcnt (same technique and the same reasons as
+        // k_agg_march, see k_aggregate.hip): SO_PF path elements (data term + class byte) in flight.
+        // VMEM ops per steady-state step in program order: [data load][class load] ... [output store].
+        typedef typename VecT<VPL>::type vec_t;
+        vec_t pfc[SO_PF];
+        int pfk[SO_PF];
+#define SO_ISSUE(U, I)                                                                                         \
+    do {                                                                                                       \
+        const size_t px_ = so_pixel<VERT>(g, (I));                                                             \
+        const float* dp_ = src + px_ * Dp + g.d0;                                                              \
+        const uint8_t* cp_ = cls + px_ * 64 + g.lane;                                                          \
+        if constexpr (VPL == 1) asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[U]) : "v"(dp_) : "memory"); \
+        else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[U]) : "v"(dp_) : "memory");              \
+        asm volatile("global_load_ubyte %0, %1, off" : "=v"(pfk[U]) : "v"(cp_) : "memory");                    \
+    } while (0)
+#define SO_TAKE(U, WAITN, E)                                                                                   \
+    do {                                                                                                       \
+        vec_t tc_;                                                                                             \
+        int tk_;                                                                                               \
+        if constexpr (VPL == 1)                                                                                \
+            asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                         \
+                         : "=&v"(tc_), "=&v"(tk_) : "v"(pfc[U]), "v"(pfk[U]), "n"(WAITN) : "memory");          \
+        else                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b32 %1, %3"                         \
+                         : "=&v"(tc_), "=&v"(tk_) : "v"(pfc[U]), "v"(pfk[U]), "n"(WAITN) : "memory");          \
+        if constexpr (VPL == 1) (E).c[0] = tc_;                                                                \
+        else { (E).c[0] = tc_.x; (E).c[VPL - 1] = tc_.y; }                                                     \
+        (E).cls = tk_;                                                                                         \
+    } while (0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // start the manual bookkeeping from an empty queue
+        int i = 1;
+        if (i + 2 * SO_PF <= g.plen) {
 #pragma unroll
-    for (int u = 0; u < SO_PF; u++) pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(1 + u, g.plen - 1));
-
-    int i = 1;
-    for (; i + SO_PF <= g.plen; i += SO_PF) {
+            for (int u = 0; u < SO_PF; u++) SO_ISSUE(u, i + u);
+            // first iteration: younger ops = 2 per not-yet-consumed prologue slot + 3 per finished step
+#define SO_FIRST(U)                                     \
+    do {                                                \
+        SoElem<VPL> cur_;                               \
+        SO_TAKE(U, 2 * (SO_PF - 1 - (U)) + 3 * (U), cur_); \
+        SO_ISSUE(U, i + (U) + SO_PF);                   \
+        SO_STEP(i + (U), cur_);                         \
+    } while (0)
+            static_assert(SO_PF == 16, "peeled first iteration written for SO_PF == 16");
+            SO_FIRST(0); SO_FIRST(1); SO_FIRST(2); SO_FIRST(3); SO_FIRST(4); SO_FIRST(5); SO_FIRST(6); SO_FIRST(7);
+            SO_FIRST(8); SO_FIRST(9); SO_FIRST(10); SO_FIRST(11); SO_FIRST(12); SO_FIRST(13); SO_FIRST(14); SO_FIRST(15);
+#undef SO_FIRST
+            i += SO_PF;
+            for (; i + 2 * SO_PF <= g.plen; i += SO_PF) {
+#pragma unroll
+                for (int u = 0; u < SO_PF; u++) {
+                    SoElem<VPL> cur;
+                    SO_TAKE(u, 3 * (SO_PF - 1), cur); // steady state: 3 ops per younger step (+ own store): one stricter
+                    SO_ISSUE(u, i + u + SO_PF);
+                    SO_STEP(i + u, cur);
+                }
+            }
+            // drain: the SO_PF elements still in flight are elements i .. i+SO_PF-1
+#pragma unroll
+            for (int u = 0; u < SO_PF; u++) {
+                SoElem<VPL> cur;
+                SO_TAKE(u, 0, cur);
+                SO_STEP(i + u, cur);
+            }
+            i += SO_PF;
+        }
+        for (; i < g.plen; i++) { // tail (< 2*SO_PF elements): compiler-scheduled loads
+            const SoElem<VPL> cur = so_load<VPL, VERT>(g, src, cls, i);
+            SO_STEP(i, cur);
+        }
+#undef SO_ISSUE
+#undef SO_TAKE
+    } else {
+        // VPL == 4 (disparity range > 128): compiler-scheduled prefetch ring
+        SoElem<VPL> pre[SO_PF];
+#pragma unroll
+        for (int u = 0; u < SO_PF; u++) pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(1 + u, g.plen - 1));
+        int i = 1;
+        for (; i + SO_PF <= g.plen; i += SO_PF) {
+#pragma unroll
+            for (int u = 0; u < SO_PF; u++) {
+                const SoElem<VPL> cur = pre[u];
+                pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(i + u + SO_PF, g.plen - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                SO_STEP(i + u, cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < SO_PF; u++) {
-            const SoElem<VPL> cur = pre[u];
-            pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(i + u + SO_PF, g.plen - 1));
-            __builtin_amdgcn_sched_barrier(0); // keep the refill loads ahead of the dependent chain, in program order
-            SO_STEP(i + u, cur);
-            __builtin_amdgcn_sched_barrier(0);
+            if (i + u < g.plen) SO_STEP(i + u, pre[u]);
         }
-    }
-#pragma unroll
-    for (int u = 0; u < SO_PF; u++) {
-        if (i + u < g.plen) SO_STEP(i + u, pre[u]);
     }
 #undef SO_STEP
 }

@@ -39,10 +39,10 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--disp", type=int, default=128)
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ADC_BENCH_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ADC_BENCH_INFLIGHT", "1")),
                     help="ADCensusStereo objects (streams) in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=216, help="rows of the CPU-baseline sample strip")
+    ap.add_argument("--cpu-rows", type=int, default=540, help="rows of the CPU-baseline sample strip")
     return ap.parse_args()
 
 

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Summarises the two rocprofv3 --pmc passes of tools/gpu_pmc.sh for the aggregation kernel.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced stream
+(MI355X_MICROARCH.md, HBM section) -> doubled here; WRITE_SIZE matched the known byte count (V) exactly."""
+import collections
+import csv
+import json
+import sys
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "noise"
+out = {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open("gpurun_out/pmc_%s_%s/pmc_counter_collection.csv" % (wl, C))):
+        if r["Counter_Name"] == C and "k_agg_march" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]) * 1024.0)
+    out[C] = {k: sum(v) / len(v) for k, v in agg.items()}
+per = {}
+for k in out["FETCH_SIZE"]:
+    per[k] = {"fetch_bytes_corrected": 2.0 * out["FETCH_SIZE"][k], "write_bytes": out["WRITE_SIZE"].get(k, 0.0)}
+    per[k]["total"] = per[k]["fetch_bytes_corrected"] + per[k]["write_bytes"]
+avg = sum(v["total"] for v in per.values()) / max(1, len(per))
+print(json.dumps({"workload": wl, "per_kernel": per, "traffic_bytes_per_launch_avg": avg,
+                  "note": "FETCH_SIZE x2 (gfx950 calibration), separate --pmc passes, bench.py --steps 2 --inflight 1"}, indent=1))
