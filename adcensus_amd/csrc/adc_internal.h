@@ -60,6 +60,7 @@ struct adc_handle {
     float *disp_l, *disp_r, *disp_tmp;
     uint8_t* label;
     uint8_t* elig;       // region voting: eligible mask of the current pass
+    uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
     int32_t* vote_list;  // compact list of eligible pixels
     int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
     int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...

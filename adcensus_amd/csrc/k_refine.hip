@@ -17,6 +17,8 @@
 #include "adc_device_fn.h"
 
 #include <vector>
+#include <stdio.h>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------- K7 LR check
 __device__ __forceinline__ bool lr_invalid(const float* __restrict__ dl, const float* __restrict__ dr, int W, int x, int y,
@@ -86,7 +88,25 @@ hipError_t adc_launch_lrcheck(adc_handle* h)
 }
 
 // ------------------------------------------------------------------------------ K8 region voting
-#define IRV_TILE 16
+#define IRV_TILE 8
+
+// Dependency box of a pixel's vote: the cross region of p spans rows y-top..y+bottom, but only pixels that PRECEDE p in
+// raster order can influence it, i.e. rows y-top..y; its horizontal extent is the widest H arm of those rows.
+// bbox[p] = {top, max left arm, max right arm} (computed once per Match; arms do not change).
+__global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arms, uchar4* __restrict__ bbox, int W, int H)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uchar4 a = arms[(size_t)y * W + x];
+    int ml = 0, mr = 0;
+    for (int t = -(int)a.z; t <= 0; t++) {
+        const uchar4 q = arms[(size_t)(y + t) * W + x];
+        ml = adc_imax(ml, (int)q.x);
+        mr = adc_imax(mr, (int)q.y);
+    }
+    bbox[(size_t)y * W + x] = make_uchar4(a.z, (unsigned char)ml, (unsigned char)mr, 0);
+}
 
 // Pass set-up: elig = pixels of this list that are still invalid (the ordering mask of the pass);
 // the work list only keeps those that CAN be filled: the vote needs count > irv_ts and count <= region
@@ -130,10 +150,10 @@ __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ l
 #define IRV_NDIRTY(r) (72 + ((r)&63))
 
 // Round r > 0, step 1: one thread per list entry decides whether the entry must be re-evaluated: some pixel
-// of its dependency box (rows y-L..y, cols x-L..x+L) changed in round r-1.  Dirty entries are compacted.
+// of its dependency box (k_irv_bbox) changed in round r-1 (8x8 change tiles).  Dirty entries are compacted.
 __global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ list, int n, const int32_t* __restrict__ chg,
-                                                   int32_t* __restrict__ dlist, int32_t* __restrict__ counters, int W, int H,
-                                                   int round, int Lmax)
+                                                   const uchar4* __restrict__ bbox, int32_t* __restrict__ dlist,
+                                                   int32_t* __restrict__ counters, int W, int H, int round)
 {
     if (counters[IRV_FLAG(round - 1)] == 0) return; // previous round changed nothing: converged
     __shared__ int wcnt[4];
@@ -146,8 +166,9 @@ __global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ l
     if (i < n) {
         p = list[i];
         const int y = p / W, x = p - y * W;
-        const int tx0 = adc_imax(0, x - Lmax) / IRV_TILE, tx1 = adc_imin(W - 1, x + Lmax) / IRV_TILE;
-        const int ty0 = adc_imax(0, y - Lmax) / IRV_TILE, ty1 = y / IRV_TILE;
+        const uchar4 bb = bbox[p];
+        const int tx0 = adc_imax(0, x - (int)bb.y) / IRV_TILE, tx1 = adc_imin(W - 1, x + (int)bb.z) / IRV_TILE;
+        const int ty0 = adc_imax(0, y - (int)bb.x) / IRV_TILE, ty1 = y / IRV_TILE;
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) dirty |= chg[ty * tiles_x + tx] == round; // changed in round-1
     }
@@ -190,24 +211,45 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
         const int y = p / W, x = p - y * W;
         for (int b = lane; b < D; b += 64) hist[b] = 0;
         const uchar4 arm = arms[p];
-        const int sub = lane >> 4, sl = lane & 15;
-        for (int t0 = -(int)arm.z; t0 <= (int)arm.w; t0 += 4) {
-            const int t = t0 + sub;
-            if (t <= (int)arm.w) {
-                const int yt = y + t;
-                const uchar4 arm2 = arms[yt * W + x];
-                for (int s = -(int)arm2.x + sl; s <= (int)arm2.y; s += 16) {
-                    const int q = yt * W + x + s;
-                    // agent-scope load: fills made earlier in THIS launch by other CUs / XCDs become visible, so a
-                    // sweep in (roughly) raster order propagates like the sequential scan (speed only: staleness
-                    // can never change the fixed point, the confirming round runs after a kernel boundary)
-                    float v = __hip_atomic_load(&disp[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // eligible pixels of this pass: visible only if they precede p in raster order
-                    // (already processed by the sequential scan), otherwise still invalid
-                    if (elig[q] && q >= p) v = ADC_INVALID_FLOAT;
-                    if (v != ADC_INVALID_FLOAT) {
-                        const int b = (int)lroundf(v) - dmin; // multistep_refiner.cpp:193-196
-                        if (b >= 0 && b < D) atomicAdd(&hist[b], 1);
+        const int top = (int)arm.z, nrows = top + (int)arm.w + 1; // region rows y-top .. y+bottom (<= 2*255+1)
+        // the H arms of all region rows are fetched in ONE round trip (lane r holds row r), then handed to the
+        // 16-lane row groups with a shuffle; 4 rows x 16 columns of the region are read per trip
+        for (int rbase = 0; rbase < nrows; rbase += 64) {
+            const int myr = rbase + lane;
+            uint32_t a2 = 0;
+            if (myr < nrows) a2 = reinterpret_cast<const uint32_t*>(arms)[(y - top + myr) * W + x];
+            const int sub = lane >> 4, sl = lane & 15;
+            const int rend = adc_imin(nrows - rbase, 64);
+            for (int r0 = 0; r0 < rend; r0 += 4) {
+                const int r = r0 + sub;
+                const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
+                if (r < rend) {
+                    const int yt = y - top + rbase + r;
+                    const int l2 = (int)(arm2 & 255u), r2 = (int)((arm2 >> 8) & 255u);
+                    // up to 5 x 16 columns (arm <= 39) are fetched with all loads in flight at once; wider rows loop
+                    for (int sb = -l2 + sl; sb <= r2; sb += 80) {
+                        float vv[5];
+                        uint8_t ee[5];
+#pragma unroll
+                        for (int j = 0; j < 5; j++) {
+                            const int s2 = sb + 16 * j;
+                            const int q = s2 <= r2 ? yt * W + x + s2 : p; // clamped: loads stay unconditional
+                            vv[j] = disp[q];
+                            ee[j] = elig[q];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 5; j++) {
+                            const int s2 = sb + 16 * j;
+                            const int q = yt * W + x + s2;
+                            float v = vv[j];
+                            // eligible pixels of this pass: visible only if they precede p in raster order
+                            // (already processed by the sequential scan), otherwise still invalid
+                            if (s2 > r2 || (ee[j] && q >= p)) v = ADC_INVALID_FLOAT;
+                            if (v != ADC_INVALID_FLOAT) {
+                                const int b = (int)lroundf(v) - dmin; // multistep_refiner.cpp:193-196
+                                if (b >= 0 && b < D) atomicAdd(&hist[b], 1);
+                            }
+                        }
                     }
                 }
             }
@@ -230,9 +272,9 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
         const float nv = adc_vote_decide(bb, bh, cnt, dmin, irv_ts, irv_th);
         evals++;
         if (lane == 0) {
-            const float cur = __hip_atomic_load(&disp[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float cur = disp[p];
             if (__float_as_uint(cur) != __float_as_uint(nv)) {
-                __hip_atomic_store(&disp[p], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                disp[p] = nv;
                 chg[(y / IRV_TILE) * tiles_x + x / IRV_TILE] = round + 1;
                 counters[IRV_FLAG(round)] = 1;
             }
@@ -253,6 +295,11 @@ hipError_t adc_run_region_voting(adc_handle* h)
     h->vote_evals = 0;
     hipError_t e = hipSuccess;
     int32_t host_cnt[136];
+    {
+        dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
+        hipLaunchKernelGGL(k_irv_bbox, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms),
+                           reinterpret_cast<uchar4*>(h->irv_bbox), p.W, p.H);
+    }
     int32_t* chg = reinterpret_cast<int32_t*>(h->chg_a);
     for (int it = 0; it < 5; it++) {         // multistep_refiner.cpp:167
         bool filled_any = false; // an iteration that fills nothing leaves the map unchanged: the remaining ones are no-ops
@@ -266,7 +313,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
             if (n == 0) continue;
             if ((e = hipMemsetAsync(chg, 0, (size_t)tiles * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             const unsigned vote_blocks_full = (unsigned)adc_imin((n + 3) / 4, 256 * 8);
-            const unsigned vote_blocks = (unsigned)adc_imin((n + 3) / 4, 256 * 4);
+            const unsigned vote_blocks = (unsigned)adc_imin((n + 3) / 4, 256 * 8);
             const unsigned check_blocks = (unsigned)((n + 255) / 256);
             bool done = false;
             for (int r0 = 0; !done; r0 += BATCH) {
@@ -278,7 +325,8 @@ hipError_t adc_run_region_voting(adc_handle* h)
                 for (int round = r0; round < r0 + BATCH; round++) {
                     if (round > 0)
                         hipLaunchKernelGGL(k_irv_check, dim3(check_blocks), dim3(256), 0, h->stream, h->vote_list, n, chg,
-                                           h->vote_dirty, h->vote_counters, p.W, p.H, round, Lmax);
+                                           reinterpret_cast<const uchar4*>(h->irv_bbox), h->vote_dirty, h->vote_counters, p.W,
+                                           p.H, round);
                     hipLaunchKernelGGL(k_irv_vote, dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), 0, h->stream,
                                        round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,
                                        reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,
@@ -287,6 +335,12 @@ hipError_t adc_run_region_voting(adc_handle* h)
                 if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 136 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
                 if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
                 if (r0 == 0 && host_cnt[IRV_FLAG(0)] != 0) filled_any = true;
+                if (getenv("ADC_IRV_TRACE")) {
+                    fprintf(stderr, "[irv] it=%d list=%d n=%d r0=%d dirty:", it, k, n, r0);
+                    for (int round = r0; round < r0 + BATCH; round++)
+                        fprintf(stderr, " %d%s", round == 0 ? n : host_cnt[IRV_NDIRTY(round)], host_cnt[IRV_FLAG(round)] ? "*" : "");
+                    fprintf(stderr, "\n");
+                }
                 for (int round = r0; round < r0 + BATCH; round++) {
                     h->vote_rounds++;
                     if (host_cnt[IRV_FLAG(round)] == 0) { done = true; break; } // full round without change: fixed point

@@ -58,9 +58,14 @@ def main():
         import torch as _torch
         import torch.distributed as _dist
         torch, dist = _torch, _dist
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ADC_BENCH_BACKEND", "nccl")  # "gloo": test hook (several ranks on one GPU)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = int(os.environ.get("ADC_BENCH_DEVICE", local_rank))
+            dist.init_process_group(backend=backend)
     import adcensus_amd as A
     from adcensus_amd import workloads
     lib = A.lib()
@@ -113,7 +118,7 @@ def main():
     prof = []
     elapsed, total_steps = farm.timed_region(lambda n: run_steps(n, prof), a.steps, a.warmup, dist=dist,
                                              device_sync=lib.adc_device_synchronize,
-                                             tensor_device="cuda" if dist is not None else "cpu")
+                                             tensor_device="cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu")
     prof = prof[-a.steps:] if len(prof) > a.steps else prof  # drop the warm-up samples of object 0
 
     if rank == 0:
@@ -141,7 +146,7 @@ def main():
             "stage_ms": stage,
             "roofline": {"kernel": "k_agg_march (one aggregation pass)", "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(a.workload, (W, H, D)),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(agg_ms, 5)},
         }
         if not a.no_cpu_baseline and world == 1:
@@ -154,6 +159,20 @@ def main():
             lib.adc_device_free(p)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, whd):
+    """HBM bytes per aggregation launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 +
+    WRITE_SIZE, separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md); None when not collected for
+    this workload / size."""
+    if whd != (1920, 1080, 128):
+        return None
+    p = os.path.join(ROOT, "profiles", "r1_k4_pmc_traffic_%s.json" % workload)
+    try:
+        with open(p) as f:
+            return float(json.load(f)["traffic_bytes_per_launch_avg"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(pair, D, rows, H):

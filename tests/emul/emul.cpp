@@ -270,7 +270,22 @@ void emul_lrcheck(const float* dl, const float* dr, float* out, uint8_t* label, 
 long emul_region_voting(float* disp, const uint8_t* label, const uint8_t* arms, int W, int H, int dmin, int D, int irv_ts,
                         float irv_th, int Lmax, unsigned seed, long* evals_out)
 {
-    const int P = W * H, T = 16;
+    const int P = W * H, T = 8;
+    (void)Lmax;
+    // dependency box per pixel (k_irv_bbox): rows y-top..y, widest H arm of those rows
+    std::vector<uint8_t> bb((size_t)P * 3);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const uint8_t* a = arms + ((size_t)y * W + x) * 4;
+            int ml = 0, mr = 0;
+            for (int t = -(int)a[2]; t <= 0; t++) {
+                const uint8_t* q = arms + ((size_t)(y + t) * W + x) * 4;
+                ml = std::max(ml, (int)q[0]);
+                mr = std::max(mr, (int)q[1]);
+            }
+            uint8_t* o = &bb[((size_t)y * W + x) * 3];
+            o[0] = a[2]; o[1] = (uint8_t)ml; o[2] = (uint8_t)mr;
+        }
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
     std::vector<uint8_t> elig(P), chg_a(tiles_x * tiles_y, 0), chg_b(tiles_x * tiles_y, 0);
     std::vector<int> list, hist(D);
@@ -292,8 +307,9 @@ long emul_region_voting(float* disp, const uint8_t* label, const uint8_t* arms, 
                 for (int p : list) {
                     const int y = p / W, x = p - y * W;
                     if (round > 0) {
-                        const int tx0 = std::max(0, x - Lmax) / T, tx1 = std::min(W - 1, x + Lmax) / T;
-                        const int ty0 = std::max(0, y - Lmax) / T, ty1 = y / T;
+                        const uint8_t* o = &bb[(size_t)p * 3];
+                        const int tx0 = std::max(0, x - (int)o[1]) / T, tx1 = std::min(W - 1, x + (int)o[2]) / T;
+                        const int ty0 = std::max(0, y - (int)o[0]) / T, ty1 = y / T;
                         bool dirty = false;
                         for (int ty = ty0; ty <= ty1; ty++)
                             for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_a[ty * tiles_x + tx] != 0;
