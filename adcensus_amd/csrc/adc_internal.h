@@ -46,6 +46,7 @@ struct adc_handle {
     uint64_t *census_l, *census_r;
     uint8_t* arms;
     uint16_t *sup_h, *sup_v;
+    int* armmax;             // [0] max horizontal arm, [1] max vertical arm of the current left image
     uint32_t *rec_h, *rec_v; // packed {arm_lo, arm_hi, divisor} per pixel, line-major (rec_v transposed)
     uint8_t *cdiff_lh, *cdiff_lv, *cdiff_rh, *cdiff_rv;
     uint8_t* so_cls; // [4 passes][H][W][64] packed 2-bit scanline penalty classes per lane
@@ -63,6 +64,7 @@ struct adc_handle {
     uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
     int32_t* vote_list;  // compact list of eligible pixels
     int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
+    int32_t* vote_fin;   // finality stamps of the current voting pass (round+1 when the value became final)
     int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...
     uint8_t *chg_a, *chg_b; // changed-tile maps (previous / next round)
     uint8_t* edge;       // discontinuity adjustment edge mask

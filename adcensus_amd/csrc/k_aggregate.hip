@@ -79,11 +79,20 @@ __device__ __forceinline__ float agg_run(float acc, const float* q, int cnt)
     return acc;
 }
 
-template <bool VERT, bool DIVIDE>
+// SMALL only gives the small-ring launch its own kernel name in profiles (the code is identical).
+template <bool VERT, bool DIVIDE, bool SMALL>
 __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
                                                   const uint32_t* __restrict__ rec, // {lo, hi, count16} per pixel, line-major
-                                                  int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd)
+                                                  int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
+                                                  const int* __restrict__ armmax, int small_variant, int small_L)
 {
+    // Two launches per pass: the window depth follows the data.  When no arm of this direction exceeds small_L
+    // (e.g. noise-like images) the small-ring variant runs at 32 waves/CU and the full-ring variant exits at once,
+    // otherwise the other way round (armmax[0] = max horizontal arm, armmax[1] = max vertical arm, from k_build_arms).
+    {
+        const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
+        if ((small_variant != 0) != fits_small) return;
+    }
     extern __shared__ __attribute__((aligned(16))) float ring_all[];
     const int R = 2 * L + 1;
     const int lane = threadIdx.x;
@@ -270,16 +279,28 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     }
     const int N = VERT ? p.H : p.W;
     const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / 64);
-    const int waves_per_cu = adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((lds + 511) / 512 * 512))));
-    int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
-    if (nseg < 1) nseg = pick_nseg(nlines, N, L, 256 * waves_per_cu);
-    int seg_len = (N + nseg - 1) / nseg;
-    if (seg_len < 1) seg_len = 1;
-    nseg = (N + seg_len - 1) / seg_len;
-    const long long waves = nlines * nseg;
-    const int per_xcd = (int)((waves + 7) / 8);
-    hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), lds, h->heavy, src, dst,
-                       VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, L, seg_len, nseg, per_xcd);
+    static const int small_L_env = env_int("ADC_AGG_SMALL_L", 8); // 0 disables the small-ring variant
+    const int small_L = adc_imin(small_L_env, L);
+    for (int variant = 0; variant < 2; variant++) { // 0: full ring, 1: small ring (exits unless every arm <= small_L)
+        if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
+        const int Lv = variant ? small_L : L;
+        const size_t ldsv = (size_t)(2 * Lv + 1) * 64 * sizeof(float);
+        const int waves_per_cu = adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
+        int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
+        if (nseg < 1) nseg = pick_nseg(nlines, N, Lv, 256 * waves_per_cu);
+        int seg_len = (N + nseg - 1) / nseg;
+        if (seg_len < 1) seg_len = 1;
+        nseg = (N + seg_len - 1) / seg_len;
+        const long long waves = nlines * nseg;
+        const int per_xcd = (int)((waves + 7) / 8);
+        const int sv = (small_L > 0 && small_L < L) ? variant : 0, sl = (small_L > 0 && small_L < L) ? small_L : 0x7fffffff;
+        if (variant)
+            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+                               VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl);
+        else
+            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, false>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+                               VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl);
+    }
     return hipGetLastError();
 }
 
@@ -290,10 +311,10 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     static bool attr_set = false;
     if (!attr_set) {
         // allow > 64 KiB dynamic LDS for the ring (large cross_L1)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipError_t e = hipSuccess;

@@ -38,17 +38,26 @@ __device__ __forceinline__ int arm_length(const uint8_t* __restrict__ img, int W
 }
 
 __global__ __launch_bounds__(256) void k_build_arms(const uint8_t* __restrict__ img_l, uchar4* __restrict__ arms, int W,
-                                                    int H, int L1, int L2, int t1, int t2)
+                                                    int H, int L1, int L2, int t1, int t2, int* __restrict__ armmax)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    uchar4 a;
+    __shared__ int smax[2];
+    if (threadIdx.x < 2) smax[threadIdx.x] = 0;
+    __syncthreads();
+    uchar4 a = make_uchar4(0, 0, 0, 0);
+    if (x < W && y < H) {
     a.x = (uint8_t)arm_length(img_l, W, H, x, y, -1, 0, L1, L2, t1, t2); // left
     a.y = (uint8_t)arm_length(img_l, W, H, x, y, +1, 0, L1, L2, t1, t2); // right
     a.z = (uint8_t)arm_length(img_l, W, H, x, y, 0, -1, L1, L2, t1, t2); // top
     a.w = (uint8_t)arm_length(img_l, W, H, x, y, 0, +1, L1, L2, t1, t2); // bottom
     arms[(size_t)y * W + x] = a;
+    }
+    // image-wide maximum arm per direction (lets the aggregation pick its window depth from the data)
+    atomicMax(&smax[0], adc_imax((int)a.x, (int)a.y));
+    atomicMax(&smax[1], adc_imax((int)a.z, (int)a.w));
+    __syncthreads();
+    if (threadIdx.x < 2 && smax[threadIdx.x] > 0) atomicMax(&armmax[threadIdx.x], smax[threadIdx.x]);
 }
 
 // Support counts (cross_aggregator.cpp:271-325):
@@ -122,8 +131,9 @@ hipError_t adc_launch_arms(adc_handle* h)
 {
     const AdcParams& p = h->p;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
+    hipMemsetAsync(h->armmax, 0, 2 * sizeof(int), h->heavy);
     hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->img_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
-                       p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2);
+                       p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2, h->armmax);
     hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
                        p.W, p.H);
     dim3 grid2(grid.x, grid.y, 2);

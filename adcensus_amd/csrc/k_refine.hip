@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arm
 __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ label, const float* __restrict__ disp,
                                                    const uint16_t* __restrict__ sup_h, uint8_t* __restrict__ elig,
                                                    int32_t* __restrict__ list, int32_t* __restrict__ counters, int which,
-                                                   int P, int min_region)
+                                                   int P, int min_region, int32_t* __restrict__ fin)
 {
     __shared__ int wcnt[4];
     __shared__ int base;
@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ l
         e = (label[p] == which) && (disp[p] == ADC_INVALID_FLOAT);
         elig[p] = e ? 1 : 0;
         listed = e && ((int)sup_h[p] > min_region);
+        // finality stamp: 0 = open, 1 = final before round 0, r+2 = "value became final in round r".  Pixels that
+        // cannot change in this pass (not eligible, or region too small to ever pass the vote) are final from the start
+        if (fin) fin[p] = (e && listed) ? 0 : 1;
     }
     const unsigned long long m = __ballot(listed);
     if (lane == 0) wcnt[wave] = __popcll(m);
@@ -153,7 +156,8 @@ __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ l
 // of its dependency box (k_irv_bbox) changed in round r-1 (8x8 change tiles).  Dirty entries are compacted.
 __global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ list, int n, const int32_t* __restrict__ chg,
                                                    const uchar4* __restrict__ bbox, int32_t* __restrict__ dlist,
-                                                   int32_t* __restrict__ counters, int W, int H, int round)
+                                                   int32_t* __restrict__ counters, int W, int H, int round,
+                                                   const int32_t* __restrict__ fin)
 {
     if (counters[IRV_FLAG(round - 1)] == 0) return; // previous round changed nothing: converged
     __shared__ int wcnt[4];
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ l
     const int tiles_x = (W + IRV_TILE - 1) / IRV_TILE;
     bool dirty = false;
     int p = -1;
-    if (i < n) {
+    if (i < n && fin[list[i]] == 0) { // final values are never re-evaluated
         p = list[i];
         const int y = p / W, x = p - y * W;
         const uchar4 bb = bbox[p];
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ l
 __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ work, int n_full, float* disp,
                                                   const uint8_t* __restrict__ elig, const uchar4* __restrict__ arms,
                                                   int32_t* __restrict__ chg, int32_t* __restrict__ counters, int W, int H, int dmin,
-                                                  int D, int irv_ts, float irv_th, int round)
+                                                  int D, int irv_ts, float irv_th, int round, int32_t* fin)
 {
     int n = n_full; // round 0 evaluates the whole list
     if (round > 0) {
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
         const int p = work[e];
         const int y = p / W, x = p - y * W;
         for (int b = lane; b < D; b += 64) hist[b] = 0;
+        bool deps_open = false;
         const uchar4 arm = arms[p];
         const int top = (int)arm.z, nrows = top + (int)arm.w + 1; // region rows y-top .. y+bottom (<= 2*255+1)
         // the H arms of all region rows are fetched in ONE round trip (lane r holds row r), then handed to the
@@ -230,12 +235,14 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
                     for (int sb = -l2 + sl; sb <= r2; sb += 80) {
                         float vv[5];
                         uint8_t ee[5];
+                        int ff[5];
 #pragma unroll
                         for (int j = 0; j < 5; j++) {
                             const int s2 = sb + 16 * j;
                             const int q = s2 <= r2 ? yt * W + x + s2 : p; // clamped: loads stay unconditional
                             vv[j] = disp[q];
                             ee[j] = elig[q];
+                            ff[j] = fin[q];
                         }
 #pragma unroll
                         for (int j = 0; j < 5; j++) {
@@ -245,6 +252,8 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
                             // eligible pixels of this pass: visible only if they precede p in raster order
                             // (already processed by the sequential scan), otherwise still invalid
                             if (s2 > r2 || (ee[j] && q >= p)) v = ADC_INVALID_FLOAT;
+                            // an eligible predecessor whose value was not yet final before this round: my vote may still change
+                            if (s2 <= r2 && ee[j] && q < p && !(ff[j] != 0 && ff[j] <= round + 1)) deps_open = true;
                             if (v != ADC_INVALID_FLOAT) {
                                 const int b = (int)lroundf(v) - dmin; // multistep_refiner.cpp:193-196
                                 if (b >= 0 && b < D) atomicAdd(&hist[b], 1);
@@ -271,7 +280,9 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
         }
         const float nv = adc_vote_decide(bb, bh, cnt, dmin, irv_ts, irv_th);
         evals++;
+        const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
         if (lane == 0) {
+            if (all_final) fin[p] = round + 2; // visible as "final" to rounds > this one only
             const float cur = disp[p];
             if (__float_as_uint(cur) != __float_as_uint(nv)) {
                 disp[p] = nv;
@@ -306,7 +317,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
         for (int k = 0; k < 2; k++) {        // mismatches, then occlusions (:170-171)
             if ((e = hipMemsetAsync(h->vote_counters, 0, 136 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
-                               h->vote_list, h->vote_counters, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, P, min_region);
+                               h->vote_list, h->vote_counters, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, P, min_region, h->vote_fin);
             if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
             const int n = host_cnt[0];
@@ -326,11 +337,11 @@ hipError_t adc_run_region_voting(adc_handle* h)
                     if (round > 0)
                         hipLaunchKernelGGL(k_irv_check, dim3(check_blocks), dim3(256), 0, h->stream, h->vote_list, n, chg,
                                            reinterpret_cast<const uchar4*>(h->irv_bbox), h->vote_dirty, h->vote_counters, p.W,
-                                           p.H, round);
+                                           p.H, round, h->vote_fin);
                     hipLaunchKernelGGL(k_irv_vote, dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), 0, h->stream,
                                        round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,
                                        reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,
-                                       p.opt.irv_ts, p.opt.irv_th, round);
+                                       p.opt.irv_ts, p.opt.irv_th, round, h->vote_fin);
                 }
                 if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 136 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
                 if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
@@ -475,7 +486,7 @@ hipError_t adc_launch_interpolation(adc_handle* h)
             hipError_t e;
             if ((e = hipMemsetAsync(h->vote_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
-                               h->vote_list, h->vote_counters, which, P, -1);
+                               h->vote_list, h->vote_counters, which, P, -1, (int32_t*)nullptr);
             if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
                                h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);

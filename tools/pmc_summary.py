@@ -19,6 +19,7 @@ per = {}
 for k in out["FETCH_SIZE"]:
     per[k] = {"fetch_bytes_corrected": 2.0 * out["FETCH_SIZE"][k], "write_bytes": out["WRITE_SIZE"].get(k, 0.0)}
     per[k]["total"] = per[k]["fetch_bytes_corrected"] + per[k]["write_bytes"]
+per = {k: v for k, v in per.items() if v["write_bytes"] > 1e6}  # drop the variant that exits immediately
 avg = sum(v["total"] for v in per.values()) / max(1, len(per))
 print(json.dumps({"workload": wl, "per_kernel": per, "traffic_bytes_per_launch_avg": avg,
                   "note": "FETCH_SIZE x2 (gfx950 calibration), separate --pmc passes, bench.py --steps 2 --inflight 1"}, indent=1))
