@@ -96,8 +96,14 @@ ADC_HD float adc_vote_decide(int best_bin, int max_ht, int count, int dmin, int 
 // ---- sorting network for the 3x3 median (adcensus_util.cpp:55-81): full sort of 9, select [n/2] ----
 ADC_HD void adc_cswap(float& a, float& b)
 {
+    // no NaNs ever reach the filter (+inf is the only special value), so min/max are exact selections
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float lo = __builtin_fminf(a, b);
+    const float hi = __builtin_fmaxf(a, b);
+#else
     const float lo = b < a ? b : a;
     const float hi = b < a ? a : b;
+#endif
     a = lo;
     b = hi;
 }

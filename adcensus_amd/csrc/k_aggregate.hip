@@ -126,6 +126,7 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 
     int slot_w = 0;          // ring slot of the next entry to be written
     int slot_m = m0 - lo;    // ring slot of entry m0 (<= L < R)
+    float* dpn = dp + (long long)m0 * fstep; // outputs leave in increasing m, starting at m0
 
 #define AGG_PUSH(V)                                \
     do {                                           \
@@ -140,14 +141,21 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         int idx_ = slot_m - a_lo_;                                                                \
         if (idx_ < 0) idx_ += R;                                                                  \
         const int n_ = a_lo_ + a_hi_ + 1;                                                         \
-        const int n1_ = adc_imin(n_, R - idx_);                                                   \
-        float acc_ = agg_run(0.0f, ring + idx_ * 64, n1_); /* order t = -arm .. +arm */          \
-        if (n_ > n1_) acc_ = agg_run(acc_, ring, n_ - n1_); /* wrapped part of the ring */       \
+        float acc_;                                                                               \
+        if (n_ == 1) {                                                                            \
+            acc_ = 0.0f + ring[idx_ * 64]; /* arms 0/0: the sum is the pixel itself */            \
+        } else {                                                                                  \
+            const int n1_ = adc_imin(n_, R - idx_);                                               \
+            acc_ = agg_run(0.0f, ring + idx_ * 64, n1_); /* order t = -arm .. +arm */            \
+            if (n_ > n1_) acc_ = agg_run(acc_, ring, n_ - n1_); /* wrapped part of the ring */   \
+        }                                                                                         \
         if (DIVIDE) {                                                                             \
             const uint32_t c_ = r_ >> 16;                                                         \
             if (c_ != 1u) acc_ = acc_ / (float)c_; /* cross_aggregator.cpp:389 (x/1 == x) */     \
         }                                                                                         \
-        dp[(long long)(M)*fstep] = acc_;                                                          \
+        *(dpn) = acc_;                                                                            \
+        dpn += fstep;                                                                             \
+        (void)(M);                                                                                \
         slot_m = slot_m + 1 == R ? 0 : slot_m + 1;                                                \
     } while (0)
 
