@@ -64,6 +64,7 @@ struct adc_handle {
     uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
     int32_t* vote_list;  // compact list of eligible pixels
     int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
+    int32_t* irv_state;  // int2 per pixel: {disparity bits, eligibility / finality stamp} of the current voting pass
     int32_t* vote_fin;   // finality stamps of the current voting pass (round+1 when the value became final)
     int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...
     uint8_t *chg_a, *chg_b; // changed-tile maps (previous / next round)

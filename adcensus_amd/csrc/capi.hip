@@ -88,6 +88,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->vote_list, P * 4));
     HIP_OK(hipMalloc(&h->vote_dirty, P * 4));
     HIP_OK(hipMalloc(&h->vote_fin, P * 4));
+    HIP_OK(hipMalloc(&h->irv_state, P * 8));
     HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
     const size_t tiles = (size_t)((p.W + 7) / 8) * ((p.H + 7) / 8);
     HIP_OK(hipMalloc(&h->chg_a, tiles * 4));
@@ -198,7 +199,7 @@ void adc_destroy(adc_handle* h)
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->vote_counters,
+                    h->ray_sincos, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
                     h->chg_a, h->chg_b, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);

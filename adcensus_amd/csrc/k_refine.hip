@@ -112,37 +112,57 @@ __global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arm
 // the work list only keeps those that CAN be filled: the vote needs count > irv_ts and count <= region
 // size == horizontal-first support count, so pixels with sup_h <= irv_ts stay invalid whatever happens.
 // Block-aggregated compaction (one atomic per 256 pixels).
+#define IRV_BEGIN_PPT 8
 __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ label, const float* __restrict__ disp,
                                                    const uint16_t* __restrict__ sup_h, uint8_t* __restrict__ elig,
                                                    int32_t* __restrict__ list, int32_t* __restrict__ counters, int which,
-                                                   int P, int min_region, int32_t* __restrict__ fin)
+                                                   int P, int min_region, int32_t* __restrict__ fin,
+                                                   int2* __restrict__ state)
 {
-    __shared__ int wcnt[4];
+    // IRV_BEGIN_PPT x 256 pixels per block and ONE list-length atomic per block: same-address atomics retire
+    // at roughly 8 ns each, so a per-256-pixel atomic (8100 of them at 1080p) alone cost ~65 us per pass
+    __shared__ int wcnt[IRV_BEGIN_PPT][4];
     __shared__ int base;
-    const int p = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    bool e = false, listed = false;
-    if (p < P) {
-        e = (label[p] == which) && (disp[p] == ADC_INVALID_FLOAT);
-        elig[p] = e ? 1 : 0;
-        listed = e && ((int)sup_h[p] > min_region);
-        // finality stamp: 0 = open, 1 = final before round 0, r+2 = "value became final in round r".  Pixels that
-        // cannot change in this pass (not eligible, or region too small to ever pass the vote) are final from the start
-        if (fin) fin[p] = (e && listed) ? 0 : 1;
+    unsigned long long m[IRV_BEGIN_PPT];
+    bool listed[IRV_BEGIN_PPT];
+#pragma unroll
+    for (int k = 0; k < IRV_BEGIN_PPT; k++) {
+        const int p = (blockIdx.x * IRV_BEGIN_PPT + k) * 256 + threadIdx.x;
+        bool e = false;
+        listed[k] = false;
+        if (p < P) {
+            const float dv = disp[p];
+            e = (label[p] == which) && (dv == ADC_INVALID_FLOAT);
+            elig[p] = e ? 1 : 0;
+            listed[k] = e && ((int)sup_h[p] > min_region);
+            // finality stamp: 0 = open, 1 = final before round 0, r+2 = "value became final in round r".  Pixels that
+            // cannot change in this pass (not eligible, or region too small to ever pass the vote) are final from the start
+            if (fin) fin[p] = listed[k] ? 0 : 1;
+            // packed per-pixel state read by the votes (ONE 8-byte gather per region pixel instead of three):
+            //   .x = disparity bits, .y = -1 not eligible (constant in this pass) | 0 eligible, open |
+            //   s > 0 eligible, final (1 = before round 0, r+2 = became final in round r)
+            if (state) state[p] = make_int2(__float_as_int(dv), !e ? -1 : (listed[k] ? 0 : 1));
+        }
+        m[k] = __ballot(listed[k]);
+        if (lane == 0) wcnt[k][wave] = __popcll(m[k]);
     }
-    const unsigned long long m = __ballot(listed);
-    if (lane == 0) wcnt[wave] = __popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < IRV_BEGIN_PPT; k++) tot += wcnt[k][0] + wcnt[k][1] + wcnt[k][2] + wcnt[k][3];
         base = tot ? atomicAdd(&counters[0], tot) : 0;
     }
     __syncthreads();
-    if (listed) {
-        int off = base;
-        for (int w = 0; w < wave; w++) off += wcnt[w];
-        off += __popcll(m & ((1ull << lane) - 1ull));
-        list[off] = p;
+    int off = base;
+#pragma unroll
+    for (int k = 0; k < IRV_BEGIN_PPT; k++) {
+        const int p = (blockIdx.x * IRV_BEGIN_PPT + k) * 256 + threadIdx.x;
+        int mine = off;
+        for (int w = 0; w < wave; w++) mine += wcnt[k][w];
+        if (listed[k]) list[mine + __popcll(m[k] & ((1ull << lane) - 1ull))] = p;
+        off += wcnt[k][0] + wcnt[k][1] + wcnt[k][2] + wcnt[k][3];
     }
 }
 
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ l
 __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ work, int n_full, float* disp,
                                                   const uint8_t* __restrict__ elig, const uchar4* __restrict__ arms,
                                                   int32_t* __restrict__ chg, int32_t* __restrict__ counters, int W, int H, int dmin,
-                                                  int D, int irv_ts, float irv_th, int round, int32_t* fin)
+                                                  int D, int irv_ts, float irv_th, int round, int32_t* fin, int2* state)
 {
     int n = n_full; // round 0 evaluates the whole list
     if (round > 0) {
@@ -209,7 +229,6 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
     int* hist = hist_all[wave];
     const int tiles_x = (W + IRV_TILE - 1) / IRV_TILE;
     const int nwaves = gridDim.x * 4;
-    int evals = 0;
     for (int e = blockIdx.x * 4 + wave; e < n; e += nwaves) {
         const int p = work[e];
         const int y = p / W, x = p - y * W;
@@ -225,41 +244,54 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
             if (myr < nrows) a2 = reinterpret_cast<const uint32_t*>(arms)[(y - top + myr) * W + x];
             const int sub = lane >> 4, sl = lane & 15;
             const int rend = adc_imin(nrows - rbase, 64);
-            for (int r0 = 0; r0 < rend; r0 += 4) {
-                const int r = r0 + sub;
-                const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
-                if (r < rend) {
-                    const int yt = y - top + rbase + r;
-                    const int l2 = (int)(arm2 & 255u), r2 = (int)((arm2 >> 8) & 255u);
-                    // up to 5 x 16 columns (arm <= 39) are fetched with all loads in flight at once; wider rows loop
-                    for (int sb = -l2 + sl; sb <= r2; sb += 80) {
-                        float vv[5];
-                        uint8_t ee[5];
-                        int ff[5];
+            // 16 region rows per trip: every 16-lane group takes 4 rows (r0+sub, +4, +8, +12) x 5 column chunks,
+            // i.e. 20 gathers per lane in flight at once -- the vote is latency-bound (one wave, few dependent
+            // round trips), so the trip count is what matters: <= 5 trips for the largest region of the default
+            // arm length instead of 18
+            for (int r0 = 0; r0 < rend; r0 += 16) {
+                int yt[4], l2[4], r2[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int r = r0 + 4 * u + sub;
+                    const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
+                    yt[u] = y - top + rbase + r;
+                    l2[u] = (int)(arm2 & 255u);
+                    r2[u] = r < rend ? (int)((arm2 >> 8) & 255u) : -0x10000; // no column of a row past the end is <= r2
+                }
+                for (int cb = 0;; cb += 80) { // one iteration unless an arm exceeds 39
+                    int2 st[4][5];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
 #pragma unroll
                         for (int j = 0; j < 5; j++) {
-                            const int s2 = sb + 16 * j;
-                            const int q = s2 <= r2 ? yt * W + x + s2 : p; // clamped: loads stay unconditional
-                            vv[j] = disp[q];
-                            ee[j] = elig[q];
-                            ff[j] = fin[q];
+                            const int s2 = -l2[u] + sl + cb + 16 * j;
+                            const int q = s2 <= r2[u] ? yt[u] * W + x + s2 : p; // clamped: loads stay unconditional
+                            st[u][j] = state[q];
                         }
+                    bool more = false;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
 #pragma unroll
                         for (int j = 0; j < 5; j++) {
-                            const int s2 = sb + 16 * j;
-                            const int q = yt * W + x + s2;
-                            float v = vv[j];
+                            const int s2 = -l2[u] + sl + cb + 16 * j;
+                            const int q = yt[u] * W + x + s2;
+                            const bool in = s2 <= r2[u];
+                            float v = __int_as_float(st[u][j].x);
+                            const int meta = st[u][j].y;
+                            const bool el = meta >= 0;
                             // eligible pixels of this pass: visible only if they precede p in raster order
                             // (already processed by the sequential scan), otherwise still invalid
-                            if (s2 > r2 || (ee[j] && q >= p)) v = ADC_INVALID_FLOAT;
+                            if (!in || (el && q >= p)) v = ADC_INVALID_FLOAT;
                             // an eligible predecessor whose value was not yet final before this round: my vote may still change
-                            if (s2 <= r2 && ee[j] && q < p && !(ff[j] != 0 && ff[j] <= round + 1)) deps_open = true;
+                            if (in && el && q < p && !(meta != 0 && meta <= round + 1)) deps_open = true;
                             if (v != ADC_INVALID_FLOAT) {
                                 const int b = (int)lroundf(v) - dmin; // multistep_refiner.cpp:193-196
                                 if (b >= 0 && b < D) atomicAdd(&hist[b], 1);
                             }
                         }
+                        more |= (-l2[u] + cb + 80) <= r2[u];
                     }
+                    if (!__any(more)) break;
                 }
             }
         }
@@ -279,19 +311,18 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
             bb = take ? ob : bb;
         }
         const float nv = adc_vote_decide(bb, bh, cnt, dmin, irv_ts, irv_th);
-        evals++;
         const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
         if (lane == 0) {
-            if (all_final) fin[p] = round + 2; // visible as "final" to rounds > this one only
+            if (all_final) { fin[p] = round + 2; state[p].y = round + 2; } // visible as "final" to rounds > this one only
             const float cur = disp[p];
             if (__float_as_uint(cur) != __float_as_uint(nv)) {
                 disp[p] = nv;
+                state[p].x = __float_as_int(nv);
                 chg[(y / IRV_TILE) * tiles_x + x / IRV_TILE] = round + 1;
                 counters[IRV_FLAG(round)] = 1;
             }
         }
     }
-    if (lane == 0 && evals) atomicAdd(&counters[2], evals);
 }
 
 hipError_t adc_run_region_voting(adc_handle* h)
@@ -316,8 +347,9 @@ hipError_t adc_run_region_voting(adc_handle* h)
         bool filled_any = false; // an iteration that fills nothing leaves the map unchanged: the remaining ones are no-ops
         for (int k = 0; k < 2; k++) {        // mismatches, then occlusions (:170-171)
             if ((e = hipMemsetAsync(h->vote_counters, 0, 136 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
-                               h->vote_list, h->vote_counters, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, P, min_region, h->vote_fin);
+            hipLaunchKernelGGL(k_irv_begin, dim3((P + 256 * IRV_BEGIN_PPT - 1) / (256 * IRV_BEGIN_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
+                               h->vote_list, h->vote_counters, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, P, min_region, h->vote_fin,
+                               reinterpret_cast<int2*>(h->irv_state));
             if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
             const int n = host_cnt[0];
@@ -341,7 +373,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
                     hipLaunchKernelGGL(k_irv_vote, dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), 0, h->stream,
                                        round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,
                                        reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,
-                                       p.opt.irv_ts, p.opt.irv_th, round, h->vote_fin);
+                                       p.opt.irv_ts, p.opt.irv_th, round, h->vote_fin, reinterpret_cast<int2*>(h->irv_state));
                 }
                 if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 136 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
                 if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
@@ -354,11 +386,11 @@ hipError_t adc_run_region_voting(adc_handle* h)
                 }
                 for (int round = r0; round < r0 + BATCH; round++) {
                     h->vote_rounds++;
+                    h->vote_evals += round == 0 ? n : host_cnt[IRV_NDIRTY(round)]; // votes evaluated (statistics)
                     if (host_cnt[IRV_FLAG(round)] == 0) { done = true; break; } // full round without change: fixed point
                 }
                 if (r0 > n + 16) return hipErrorUnknown; // cannot happen: the triangular system converges in <= n rounds
             }
-            h->vote_evals += host_cnt[2];
         }
         if (!filled_any) break;
     }
@@ -485,8 +517,8 @@ hipError_t adc_launch_interpolation(adc_handle* h)
         if (rays) {
             hipError_t e;
             if ((e = hipMemsetAsync(h->vote_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_irv_begin, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
-                               h->vote_list, h->vote_counters, which, P, -1, (int32_t*)nullptr);
+            hipLaunchKernelGGL(k_irv_begin, dim3((P + 256 * IRV_BEGIN_PPT - 1) / (256 * IRV_BEGIN_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
+                               h->vote_list, h->vote_counters, which, P, -1, (int32_t*)nullptr, (int2*)nullptr);
             if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
                                h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
