@@ -107,6 +107,51 @@ ADC_HD void adc_cswap(float& a, float& b)
     a = lo;
     b = hi;
 }
+// ---- rank selection without a full sort (used by the banded median kernel) ----
+// 3x3 window positions: 0 1 2 / 3 4 5 / 6 7 8.  The reference sorts the n in-image values and takes
+// wnd[n/2] (adcensus_util.cpp:64-77).  With W,H >= 2 only n = 9, 6 (edge) and 4 (corner) occur, and
+// wnd[n/2] equals the MEDIAN of nine values when the missing positions are padded with 'a' values of -inf
+// and 'b' values of +inf where a = 4 - n/2: edge a=1,b=2, corner a=2,b=3.  Rule that yields exactly these
+// counts: a missing side-centre (1,3,5,7) is padded with -inf, a missing corner (0,2,6,8) with +inf.
+ADC_HD float adc_min3(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fminf(__builtin_fminf(a, b), c);
+#else
+    const float m = b < a ? b : a;
+    return c < m ? c : m;
+#endif
+}
+ADC_HD float adc_max3(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+#else
+    const float m = b < a ? a : b;
+    return c < m ? m : c;
+#endif
+}
+ADC_HD float adc_med3(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    const float lo = b < a ? b : a, hi = b < a ? a : b;
+    const float m = c < hi ? c : hi; // min(hi, c)
+    return m < lo ? lo : m;          // max(lo, min(hi, c))
+#endif
+}
+// Median of nine = med3(max of the triple minima, median of the triple medians, min of the triple maxima)
+// for ANY partition into three triples (13 min/max/med3 operations; all monotone, checked over all 512
+// 0/1 inputs in tests/test_emul.py).  The last triple holds the values that arrive latest in the kernel.
+ADC_HD float adc_median9(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8)
+{
+    const float lo1 = adc_min3(v0, v1, v2), me1 = adc_med3(v0, v1, v2), hi1 = adc_max3(v0, v1, v2);
+    const float lo2 = adc_min3(v3, v4, v5), me2 = adc_med3(v3, v4, v5), hi2 = adc_max3(v3, v4, v5);
+    const float lo3 = adc_min3(v6, v7, v8), me3 = adc_med3(v6, v7, v8), hi3 = adc_max3(v6, v7, v8);
+    return adc_med3(adc_max3(lo1, lo2, lo3), adc_med3(me1, me2, me3), adc_min3(hi1, hi2, hi3));
+}
+
 // Sorts v[0..8] ascending (25 compare-exchanges, optimal-size network for n=9).
 ADC_HD void adc_sort9(float* v)
 {

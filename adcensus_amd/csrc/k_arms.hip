@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void k_build_arms(const uint8_t* __restrict__ 
     atomicMax(&smax[0], adc_imax((int)a.x, (int)a.y));
     atomicMax(&smax[1], adc_imax((int)a.z, (int)a.w));
     __syncthreads();
-    if (threadIdx.x < 2 && smax[threadIdx.x] > 0) atomicMax(&armmax[threadIdx.x], smax[threadIdx.x]);
+    // monotone maximum: skip the (serialising, same-address) atomic when the value already there is large enough;
+    // a stale read can only be too small, which just means one redundant atomic
+    if (threadIdx.x < 2 && smax[threadIdx.x] > __hip_atomic_load(&armmax[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&armmax[threadIdx.x], smax[threadIdx.x]);
 }
 
 // Support counts (cross_aggregator.cpp:271-325):

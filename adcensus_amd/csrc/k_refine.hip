@@ -684,117 +684,109 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
     }
 }
 
-// ---- multi-workgroup variant: bands of MEDB_ROWS rows, one workgroup (one thread per row) per band.
-// Band b's first row needs the filtered last row of band b-1 one level later; to keep that cross-CU
-// hand-off off the per-level critical path, band b runs >= MEDB_K levels behind band b-1: the upstream
-// band publishes its level counter every MEDB_K levels (write-through row stores, drained, then an
-// agent-scope counter store -- cdna guide G16 recipe R1), the downstream band polls it once per
-// MEDB_K levels and reads the row with agent-scope loads.  Dependencies only point upstream, all
-// bands are co-resident (<= 80 workgroups), spins are bounded (error word + bail out).
-#define MEDB_ROWS 128
+// ---- multi-workgroup variant: bands of 64 rows, ONE WAVE (one lane per row) per band.
+// Inside a band everything stays in registers: the newest filtered value of the row above (out[y-1][x+1],
+// produced by lane-1 one level earlier) arrives with a DPP wave_shr:1, the unfiltered row below (in[y+1][x+1])
+// is the value lane+1 prefetched for its own window (DPP wave_shl:1), so there is no LDS and no barrier, and a
+// level costs ~35 VALU instructions (rank selection by adc_median9 with +-inf padding instead of a 25-exchange
+// sort).  Band b's first row needs the filtered last row of band b-1: to keep that cross-CU hand-off off the
+// per-level critical path, band b runs >= 2*MEDB_K levels behind band b-1: the upstream band publishes its level
+// counter every MEDB_K levels (write-through row stores, drained, then an agent-scope counter store -- cdna
+// guide G16 recipe R1), the downstream band polls it once per MEDB_K levels and reads the row with agent-scope
+// loads, a whole block of levels ahead.  Dependencies only point upstream, all bands are co-resident (<= 256
+// single-wave workgroups), spins are bounded (error word + bail out).  Requires W >= 2 and H >= 2.
+#define MEDB_ROWS 64
 #define MEDB_K 16 // levels per block: progress publication / polling period and bulk-prefetch depth
+
+template <int CTRL> __device__ __forceinline__ float medb_dpp(float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
 
 __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* out, int W, int H,
                                                              int* progress, int* error_word)
 {
-    __shared__ float mring[MEDB_ROWS * 4];
-    __shared__ int bail;
     const int tid = threadIdx.x;
     const int band = blockIdx.x;
     const int y = band * MEDB_ROWS + tid;
     const int nsteps = W + 2 * (H - 1);
     const bool row_ok = y < H;
-    const bool first_row = tid == 0 && band > 0;                      // reads the upstream band's last row
-    const bool last_row = row_ok && (tid == MEDB_ROWS - 1 || y == H - 1) && (y + 1 < H); // feeds the downstream band
+    const bool up = y > 0, dn = y + 1 < H;
+    const bool first_row = tid == 0 && band > 0;                  // reads the upstream band's last row
+    const bool own_b = tid == MEDB_ROWS - 1;                      // no lane below: loads row y+1 itself
+    const bool last_row = row_ok && (own_b || y == H - 1) && dn;  // feeds the downstream band
     auto clampc = [&](int c) __attribute__((always_inline)) { return c < 0 ? 0 : (c >= W ? W - 1 : c); };
     const int ya = row_ok ? y : H - 1, yb = y + 1 < H ? y + 1 : H - 1;
     const float* rowA = in + (size_t)ya * W;
-    const float* rowB = in + (size_t)yb * W;
-    const float* rowUp = out + (size_t)(y > 0 ? y - 1 : 0) * W; // upstream band's last row (first_row only)
-    const int x0 = -2 * y; // column at level 0
-    float A0 = rowA[clampc(x0)], A1 = rowA[clampc(x0 + 1)];
-    float Bm = rowB[clampc(x0 - 1)], B0 = rowB[clampc(x0)], B1 = rowB[clampc(x0 + 1)];
+    // lanes that take their row-below / row-above values from a neighbour lane all read ONE dummy address, so
+    // the loads stay unconditional (no vmcnt drain) yet cost a single cache line per instruction
+    const float* rowB = in + (own_b ? (size_t)yb * W : 0);
+    const float* rowU = out + (first_row ? (size_t)(y - 1) * W : 0);
+    const int mB = own_b ? 0x7fffffff : 0, mU = first_row ? 0x7fffffff : 0; // column masks (0 -> dummy column 0)
+    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
+    int x = -2 * y; // column at level 0
+    float A0 = rowA[clampc(x)], A1 = rowA[clampc(x + 1)], A2 = rowA[clampc(x + 2)];
+    const float* rowBfull = in + (size_t)yb * W;
+    float Bm = rowBfull[clampc(x - 1)], B0 = rowBfull[clampc(x)];
     float Fm = 0.f, F0 = 0.f, Pv = 0.f;
-    // bulk prefetch: the new unfiltered columns (x+2 of rows y, y+1) and, for the band's first row, the
-    // upstream row values of a whole block of MEDB_K levels are loaded one block ahead, so the per-level
-    // critical path holds no global load (one vmcnt drain per block instead of one per level)
+    // bulk prefetch, one block of MEDB_K levels ahead: the per-level critical path holds no global load
     float na[MEDB_K], nb[MEDB_K], nu[MEDB_K];
 #pragma unroll
     for (int k = 0; k < MEDB_K; k++) {
-        na[k] = rowA[clampc(x0 + 2 + k)];
-        nb[k] = rowB[clampc(x0 + 2 + k)];
+        na[k] = rowA[clampc(x + 3 + k)];
+        nb[k] = rowB[clampc(x + 1 + k) & mB];
         nu[k] = 0.0f; // levels 0..MEDB_K-1 of a band > 0: its first row is idle (x < 0)
     }
-    if (tid == 0) bail = 0;
-    __syncthreads();
 
     for (int t0 = 0; t0 < nsteps; t0 += MEDB_K) {
         if (band > 0) {
             // stay behind the upstream band: this block reads its rows of levels < t0+MEDB_K and prefetches those of
             // the next block (levels < t0 + 2*MEDB_K)
-            if (tid == 0) {
-                const int need = t0 + 2 * MEDB_K < nsteps ? t0 + 2 * MEDB_K : nsteps;
-                int spins = 0;
-                while (__hip_atomic_load(&progress[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) { bail = 1; atomicExch(error_word, 1); break; }
-                }
+            const int need = t0 + 2 * MEDB_K < nsteps ? t0 + 2 * MEDB_K : nsteps;
+            int spins = 0;
+            while (__hip_atomic_load(&progress[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1 << 22)) { atomicExch(error_word, 1); return; }
             }
-            __syncthreads();
-            if (bail) return;
         }
         float ca[MEDB_K], cb[MEDB_K], cu[MEDB_K];
 #pragma unroll
         for (int k = 0; k < MEDB_K; k++) { ca[k] = na[k]; cb[k] = nb[k]; cu[k] = nu[k]; }
         {
-            const int xn = t0 + MEDB_K - 2 * y; // column of this row at the first level of the next block
+            const int xn = x + MEDB_K; // column of this row at the first level of the next block
 #pragma unroll
             for (int k = 0; k < MEDB_K; k++) {
-                na[k] = rowA[clampc(xn + k + 2)];
-                nb[k] = rowB[clampc(xn + k + 2)];
-                if (first_row) nu[k] = __hip_atomic_load(rowUp + clampc(xn + k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                na[k] = rowA[clampc(xn + k + 3)];
+                nb[k] = rowB[clampc(xn + k + 1) & mB];
+                nu[k] = __hip_atomic_load(rowU + (clampc(xn + k + 1) & mU), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #pragma unroll
         for (int k = 0; k < MEDB_K; k++) {
-            const int t = t0 + k;
-            const int x = t - 2 * y;
-            const bool active = (t < nsteps) && row_ok && (x >= 0) && (x < W);
-            // newest filtered value of the row above: out[y-1][x+1] was produced at level t-1
-            float F1 = 0.0f;
-            if (first_row) F1 = cu[k];
-            else if (row_ok && tid > 0 && x + 1 >= 0 && x + 1 < W) F1 = mring[(tid - 1) * 4 + ((x + 1) & 3)];
+            const bool active = row_ok && (x >= 0) && (x < W);
+            // newest filtered value of the row above: out[y-1][x+1] was produced by lane-1 at the previous level
+            const float F1d = medb_dpp<0x138>(Pv);    // wave_shr:1
+            const float B1d = medb_dpp<0x130>(ca[k]); // wave_shl:1: lane+1's in[y+1][(x-2)+3]
+            const float F1 = first_row ? cu[k] : F1d;
+            const float B1 = own_b ? cb[k] : B1d;
+            const bool lf = x > 0, rt = x + 1 < W;
+            const float v0 = (up && lf) ? Fm : PINF, v1 = up ? F0 : NINF, v2 = (up && rt) ? F1 : PINF;
+            const float v3 = lf ? Pv : NINF, v5 = rt ? A1 : NINF;
+            const float v6 = (dn && lf) ? Bm : PINF, v7 = dn ? B0 : NINF, v8 = (dn && rt) ? B1 : PINF;
+            // the triple that holds the two late values (F1, Pv) goes last
+            const float res = adc_median9(v0, v1, v6, v5, v7, v8, v2, v3, A0);
             if (active) {
-                const bool up = y > 0, dn = y + 1 < H, lf = x > 0, rt = x + 1 < W;
-                float v[9];
-                int n = 1;
-                v[0] = (up && lf) ? Fm : ADC_INVALID_FLOAT; n += (up && lf);
-                v[1] = up ? F0 : ADC_INVALID_FLOAT;          n += up;
-                v[2] = (up && rt) ? F1 : ADC_INVALID_FLOAT;  n += (up && rt);
-                v[3] = lf ? Pv : ADC_INVALID_FLOAT;          n += lf;
-                v[4] = A0;
-                v[5] = rt ? A1 : ADC_INVALID_FLOAT;          n += rt;
-                v[6] = (dn && lf) ? Bm : ADC_INVALID_FLOAT;  n += (dn && lf);
-                v[7] = dn ? B0 : ADC_INVALID_FLOAT;          n += dn;
-                v[8] = (dn && rt) ? B1 : ADC_INVALID_FLOAT;  n += (dn && rt);
-                adc_sort9(v);
-                const int sel = n / 2; // wnd_data[size/2], adcensus_util.cpp:77
-                float res = v[0];
-#pragma unroll
-                for (int i = 1; i < 9; i++) res = (i == sel) ? v[i] : res;
-                if (last_row) __hip_atomic_store(out + (size_t)y * W + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through
-                else out[(size_t)y * W + x] = res;
-                mring[tid * 4 + (x & 3)] = res;
+                __hip_atomic_store(out + (size_t)y * W + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through
                 Pv = res;
             }
             Fm = F0; F0 = F1;
-            A0 = A1; A1 = ca[k];
-            Bm = B0; B0 = B1; B1 = cb[k];
-            __syncthreads();
+            A0 = A1; A1 = A2; A2 = ca[k];
+            Bm = B0; B0 = B1;
+            x++;
         }
-        // publish "levels completed": the thread that stores the band's last row drains ITS stores first
+        // publish "levels completed": the lane that stores the band's last row drains its stores first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (last_row) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int done = t0 + MEDB_K < nsteps ? t0 + MEDB_K : nsteps;
             __hip_atomic_store(&progress[band], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -814,7 +806,7 @@ hipError_t adc_launch_median(adc_handle* h)
     }
     static const bool banded = [] { const char* e = getenv("ADC_MEDIAN_BANDED"); return e ? atoi(e) != 0 : true; }();
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
-    if (banded && nbands > 1 && nbands <= 80) {
+    if (banded && nbands > 1 && nbands <= 256 && p.W >= 2 && p.H >= 2) {
         // progress counters + error word live in vote_counters[160..]; zeroed on the stream before every launch
         int* prog = h->vote_counters + 160;
         hipMemsetAsync(prog, 0, 96 * sizeof(int32_t), h->stream);

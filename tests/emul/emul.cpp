@@ -425,6 +425,30 @@ void emul_median_wavefront(const float* in, float* out, int W, int H)
     }
 }
 
+// ------------------------------------------------------------------ k_median_banded (selection rule)
+// The banded kernel keeps the raster-order (in-place) data flow but replaces "sort the n in-image values,
+// take wnd[n/2]" by the median of nine with -inf / +inf padding (adc_device_fn.h).  Sequential restatement.
+float emul_median9(const float* v) { return adc_median9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]); }
+
+void emul_median_padded(const float* in, float* out, int W, int H)
+{
+    std::vector<float> cur(in, in + (size_t)W * H); // filtered in place, like the reference
+    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float v[9];
+            for (int r = -1; r <= 1; r++)
+                for (int c = -1; c <= 1; c++) {
+                    const int row = y + r, col = x + c, i = (r + 1) * 3 + (c + 1);
+                    const bool corner = (r != 0) && (c != 0);
+                    v[i] = (row >= 0 && row < H && col >= 0 && col < W) ? cur[(size_t)row * W + col] : (corner ? PINF : NINF);
+                }
+            // same triple grouping as the kernel
+            cur[(size_t)y * W + x] = adc_median9(v[0], v[1], v[6], v[5], v[7], v[8], v[2], v[3], v[4]);
+        }
+    std::copy(cur.begin(), cur.end(), out);
+}
+
 // gray of a single pixel (device function check over all 2^24 triples is done from Python in chunks)
 void emul_gray(const uint8_t* bgr, uint8_t* gray, size_t n)
 {

@@ -105,6 +105,10 @@ def test_refiner_parallel_forms(emul, dumps, name):
     m = np.empty((h, w), np.float32)
     emul.emul_median_wavefront(P(o["disp_after_dda"]), P(m), w, h)
     assert same(m, o["disp_final"])
+    m2 = np.empty((h, w), np.float32)
+    if w >= 2 and h >= 2:  # the banded kernel (and its padding rule) is only used for W, H >= 2
+        emul.emul_median_padded(P(o["disp_after_dda"]), P(m2), w, h)  # rank selection of the banded kernel
+        assert same(m2, o["disp_final"])
 
 
 def test_gray_all_triples_sample(emul):
@@ -117,3 +121,30 @@ def test_gray_all_triples_sample(emul):
     b, g, r = (bgr[:, i].astype(np.float64) for i in range(3))
     want = ((r * 0.299 + g * 0.587) + b * 0.114).astype(np.uint8)
     assert np.array_equal(got, want)
+
+
+def test_median9_zero_one_principle(emul):
+    """adc_median9 is built from monotone operators (min3/max3/med3): it is the median for all inputs iff it is
+    for all 512 0/1 inputs; plus random windows with +-inf and ties."""
+    emul.emul_median9.restype = C.c_float
+    for bits in range(512):
+        v = np.array([(bits >> i) & 1 for i in range(9)], np.float32)
+        assert emul.emul_median9(P(v)) == float(np.sort(v)[4]), bits
+    rng = np.random.default_rng(3)
+    pool = np.array([0.0, 1.0, 1.0, 2.5, np.inf, -np.inf, 7.25, 7.25, 64.0, np.inf], np.float32)
+    for _ in range(2000):
+        v = rng.choice(pool, 9).astype(np.float32)
+        assert emul.emul_median9(P(v)) == float(np.sort(v)[4])
+
+
+def test_median_padded_matches_reference_small(emul, oracle):
+    """wnd[n/2] of the n in-image values == median of nine with (-inf side-centre / +inf corner) padding, on tiny
+    images where every pixel is a border pixel, including +inf (invalid) entries."""
+    rng = np.random.default_rng(11)
+    for (h, w) in [(2, 2), (2, 5), (3, 3), (5, 2), (7, 9)]:
+        d = rng.integers(0, 6, (h, w)).astype(np.float32) + rng.integers(0, 2, (h, w)).astype(np.float32) * 0.5
+        d[rng.random((h, w)) < 0.25] = np.inf
+        want = oracle.median3_inplace(d)
+        got = np.empty((h, w), np.float32)
+        emul.emul_median_padded(P(d), P(got), w, h)
+        assert same(got, want), (h, w)
