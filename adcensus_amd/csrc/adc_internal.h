@@ -64,6 +64,12 @@ struct adc_handle {
     uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
     int32_t* vote_list;  // compact list of eligible pixels
     int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
+    int32_t* ray_tab;     // [max_search][16] packed ray offsets (dy<<16 | dx&0xffff), NULL when a step is too close to a .5 tie
+    int ray_tab_rows;
+    float* med_hand;      // banded median: per-band hand-off rows [bands][med_hpitch], indexed by wavefront level
+    int med_hpitch;
+    int32_t* pin_flags;   // pinned host word: error flag of the banded median's hand-off (read back after every Match)
+    uint32_t* bgrx_l;     // left image packed B | G<<8 | R<<16 per pixel (interpolation gathers)
     int32_t* irv_state;  // int2 per pixel: {disparity bits, eligibility / finality stamp} of the current voting pass
     int32_t* vote_fin;   // finality stamps of the current voting pass (round+1 when the value became final)
     int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
 #include <new>
 #include <mutex>
 
@@ -60,6 +61,9 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->img_l, P * 3));
     HIP_OK(hipMalloc(&h->img_r, P * 3));
     HIP_OK(hipMalloc(&h->gray_l, P));
+    HIP_OK(hipMalloc(&h->bgrx_l, P * 4));
+    h->med_hpitch = ((p.W + 2 * p.H + 64 + 15) / 16) * 16;
+    HIP_OK(hipMalloc(&h->med_hand, (size_t)((p.H + 63) / 64 + 1) * h->med_hpitch * sizeof(float)));
     HIP_OK(hipMalloc(&h->gray_r, P));
     HIP_OK(hipMalloc(&h->census_l, P * 8));
     HIP_OK(hipMalloc(&h->census_r, P * 8));
@@ -96,6 +100,8 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->edge, P));
     HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&h->pin_flags, 64, hipHostMallocDefault));
+    memset(h->pin_flags, 0, 64);
     HIP_OK(hipMemset(h->label, 0, P));
     HIP_OK(hipMemset(h->chg_a, 0, tiles));
     HIP_OK(hipMemset(h->chg_b, 0, tiles));
@@ -129,6 +135,30 @@ static hipError_t upload_tables(adc_handle* h)
         ang += pi / 16;
     }
     HIP_OK(hipMemcpy(h->ray_sincos, sc, sizeof(sc), hipMemcpyHostToDevice));
+    {   // integer ray offsets: lround(y + m*sin) == y + lround(m*sin) for every integer 0 <= y < 2^20 as long as m*sin is
+        // not within 1e-9 of a .5 tie (the addition's rounding error is < 2^-32); one unsafe entry disables the table
+        const int da = o.max_disparity < 0 ? -o.max_disparity : o.max_disparity, di = o.min_disparity < 0 ? -o.min_disparity : o.min_disparity;
+        const int ms = da > di ? da : di; // multistep_refiner.cpp:236
+        h->ray_tab = nullptr;
+        h->ray_tab_rows = 0;
+        if (ms >= 1 && ms <= 30000 && h->p.W < (1 << 20) && h->p.H < (1 << 20)) {
+            std::vector<int32_t> tab((size_t)ms * 16, 0);
+            bool safe = true;
+            for (int m = 1; m < ms && safe; m++)
+                for (int s = 0; s < 16; s++) {
+                    const double fy = (double)m * sc[2 * s], fx = (double)m * sc[2 * s + 1];
+                    const double ry = fabs(fabs(fy - floor(fy)) - 0.5), rx = fabs(fabs(fx - floor(fx)) - 0.5);
+                    if (ry < 1e-9 || rx < 1e-9) { safe = false; break; }
+                    const long dy = lround(fy), dx = lround(fx);
+                    tab[(size_t)m * 16 + s] = (int32_t)(((uint32_t)(dy & 0xffff) << 16) | (uint32_t)(dx & 0xffff));
+                }
+            if (safe) {
+                HIP_OK(hipMalloc(&h->ray_tab, tab.size() * sizeof(int32_t)));
+                HIP_OK(hipMemcpy(h->ray_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                h->ray_tab_rows = ms;
+            }
+        }
+    }
     // penalty classes (scanline_optimizer.cpp:129-141): f32 divides on the host
     h->so_P1[0] = o.so_p1;      h->so_P2[0] = o.so_p2;
     h->so_P1[1] = o.so_p1 / 4;  h->so_P2[1] = o.so_p2 / 4;
@@ -199,11 +229,12 @@ void adc_destroy(adc_handle* h)
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
+                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
                     h->chg_a, h->chg_b, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
     if (h->pin_out) hipHostFree(h->pin_out);
+    if (h->pin_flags) hipHostFree(h->pin_flags);
     for (int i = 0; i <= ADC_STAGE_COUNT; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
     for (int i = 0; i < 9; i++) if (h->ev_agg[i]) hipEventDestroy(h->ev_agg[i]);
     if (h->ev_in) hipEventDestroy(h->ev_in);
@@ -343,6 +374,11 @@ int adc_wait(adc_handle* h)
     if (!h) return 1;
     hipSetDevice(h->device);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("adc_wait", hipGetLastError()); return 2; }
+    if (h->pin_flags && h->pin_flags[0] != 0) { // a median band gave up waiting for its upstream band: the map is incomplete
+        h->pin_flags[0] = 0;
+        g_last_error = "adc_wait: median filter hand-off timed out";
+        return 2;
+    }
     if (h->async_dst) {
         memcpy(h->async_dst, h->pin_out, (size_t)h->p.W * h->p.H * 4);
         h->async_dst = nullptr;

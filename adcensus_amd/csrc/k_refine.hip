@@ -504,6 +504,118 @@ __global__ __launch_bounds__(256) void k_interpolate_rays(const int32_t* __restr
     }
 }
 
+// Table variant (default): the reference's step m of ray s lands on (lround(y + m*sin), lround(x + m*cos))
+// (multistep_refiner.cpp:259-260).  For integer y that equals y + lround(m*sin) unless m*sin sits within
+// rounding distance of a .5 tie, which the host excludes when it builds the table (capi.hip: every entry is
+// checked to be > 1e-9 away from a tie; otherwise the f64 kernel above is used).  Table layout [m][16] of
+// packed (dy << 16 | dx & 0xffff): one 64-byte segment per step for the 16 rays of a pixel.  The walk issues
+// 4 steps' loads at once (the loads past the hit are clamped in-image and ignored).
+__global__ __launch_bounds__(256) void k_pack_bgr(const uint8_t* __restrict__ img, uint32_t* __restrict__ out, int P)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < P) out[p] = (uint32_t)img[3 * (size_t)p] | ((uint32_t)img[3 * (size_t)p + 1] << 8) | ((uint32_t)img[3 * (size_t)p + 2] << 16);
+}
+__device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_dist_l1 on packed B | G<<8 | R<<16
+{
+    return adc_iabs((int)(a & 255u) - (int)(b & 255u)) + adc_iabs((int)((a >> 8) & 255u) - (int)((b >> 8) & 255u)) +
+           adc_iabs((int)((a >> 16) & 255u) - (int)((b >> 16) & 255u));
+}
+
+// 16 lanes per target pixel (one ray each), 4 list-consecutive (mostly x-adjacent) pixels per wave.  Lane layout
+// lane = ray*4 + pixel: the texture-address unit merges adjacent lanes that hit the same line, so the 4 pixels'
+// steps of one ray cost one line, not four (the kernel is gather-rate bound: ~78% of a noise pair's pixels are
+// targets, with ~4.5 steps per ray).  Offsets of steps 1..4 live in registers, the next list entries are
+// prefetched, 4 steps' disparities are fetched per round trip (loads past the hit are clamped to the pixel itself
+// and ignored), the colour of the hit is fetched once at the end.
+__global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
+                                                         const float* __restrict__ din, float* __restrict__ dout,
+                                                         const uint32_t* __restrict__ bgr, const int32_t* __restrict__ tab,
+                                                         int W, int H, int which, int max_search)
+{
+    const int n = counters[0];
+    const int lane = threadIdx.x & 63;
+    const int s = lane >> 2;                                   // ray index
+    const int slot = ((blockIdx.x * 256 + threadIdx.x) >> 6) * 4 + (lane & 3); // pixel slot
+    const int nslot = (gridDim.x * 256) >> 4;
+    const bool mismatch = which == ADC_LABEL_MISMATCH;
+    const int nr = (n + 3) & ~3; // whole waves iterate together (4 pixels per wave)
+    int t0[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) t0[j] = tab[(1 + j < max_search ? 1 + j : (max_search > 1 ? max_search - 1 : 0)) * 16 + s];
+    int pn = slot < n ? list[slot] : 0;
+    for (int e = slot; e < nr; e += nslot) {
+        const bool live = e < n;
+        const int p = pn;
+        pn = e + nslot < n ? list[e + nslot] : 0;
+        const int y = p / W, x = p - y * W;
+        float hit = ADC_INVALID_FLOAT; // first valid disparity along this ray
+        int hitq = p;
+        bool walking = live;
+        int q[4];
+        bool in[4];
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int yy = y + (t0[j] >> 16), xx = x + (int)(short)(t0[j] & 0xffff);
+            in[j] = (1 + j < max_search) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            q[j] = in[j] ? yy * W + xx : p;
+            d[j] = din[q[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (walking) {
+                if (!in[j]) walking = false; // left the image (or the search range): the ray ends without a hit
+                else if (d[j] != ADC_INVALID_FLOAT) { hit = d[j]; hitq = q[j]; walking = false; }
+            }
+        }
+        for (int m0 = 5; m0 < max_search && __any(walking); m0 += 4) {
+            const int pw = walking ? p : -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int m = m0 + j < max_search ? m0 + j : max_search - 1; // table has max_search rows (row 0 unused)
+                const int o = tab[m * 16 + s];
+                const int yy = y + (o >> 16), xx = x + (int)(short)(o & 0xffff);
+                in[j] = (m0 + j < max_search) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                q[j] = (in[j] && pw >= 0) ? yy * W + xx : p; // finished rays re-read their own pixel (one line)
+                d[j] = din[q[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (walking) {
+                    if (!in[j]) walking = false;
+                    else if (d[j] != ADC_INVALID_FLOAT) { hit = d[j]; hitq = q[j]; walking = false; }
+                }
+            }
+        }
+        // combine the 16 rays of this pixel (lanes with equal lane&3)
+        float best;
+        bool any;
+        if (mismatch) { // colour-nearest, first minimum in ray order (multistep_refiner.cpp:276-289; min_dist starts at 9999)
+            const int dist = packed_l1(bgr[p], bgr[hitq]); // <= 765 < 9999
+            int key = hit != ADC_INVALID_FLOAT ? dist * 16 + s : 0x7fffffff;
+            float val = hit;
+#pragma unroll
+            for (int msk = 32; msk >= 4; msk >>= 1) {
+                const int ok = __shfl_xor(key, msk, 64);
+                const float ov = __shfl_xor(val, msk, 64);
+                if (ok < key) { key = ok; val = ov; }
+            }
+            any = key != 0x7fffffff;
+            best = any ? val : 0.0f;
+        } else { // smallest disparity (multistep_refiner.cpp:290-296)
+            float val = hit;
+#pragma unroll
+            for (int msk = 32; msk >= 4; msk >>= 1) {
+                const float ov = __shfl_xor(val, msk, 64);
+                val = ov < val ? ov : val;
+            }
+            any = val != ADC_INVALID_FLOAT;
+            best = val;
+        }
+        if (live && s == 0) dout[p] = any ? best : 0.0f; // no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
+    }
+}
+
 hipError_t adc_launch_interpolation(adc_handle* h)
 {
     const AdcParams& p = h->p;
@@ -520,8 +632,14 @@ hipError_t adc_launch_interpolation(adc_handle* h)
             hipLaunchKernelGGL(k_irv_begin, dim3((P + 256 * IRV_BEGIN_PPT - 1) / (256 * IRV_BEGIN_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
                                h->vote_list, h->vote_counters, which, P, -1, (int32_t*)nullptr, (int2*)nullptr);
             if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
-                               h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
+            if (h->ray_tab && max_search == h->ray_tab_rows) {
+                if (k == 0) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
+                hipLaunchKernelGGL(k_interpolate_tab, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
+                                   h->disp_tmp, h->bgrx_l, h->ray_tab, p.W, p.H, which, max_search);
+            }
+            else
+                hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
+                                   h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
         } else {
             hipLaunchKernelGGL(k_interpolate, grid, block, 0, h->stream, h->disp_l, h->disp_tmp, h->label, h->img_l, h->ray_sincos,
                                p.W, p.H, which, max_search);
@@ -688,23 +806,30 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
 // Inside a band everything stays in registers: the newest filtered value of the row above (out[y-1][x+1],
 // produced by lane-1 one level earlier) arrives with a DPP wave_shr:1, the unfiltered row below (in[y+1][x+1])
 // is the value lane+1 prefetched for its own window (DPP wave_shl:1), so there is no LDS and no barrier, and a
-// level costs ~35 VALU instructions (rank selection by adc_median9 with +-inf padding instead of a 25-exchange
-// sort).  Band b's first row needs the filtered last row of band b-1: to keep that cross-CU hand-off off the
-// per-level critical path, band b runs >= 2*MEDB_K levels behind band b-1: the upstream band publishes its level
-// counter every MEDB_K levels (write-through row stores, drained, then an agent-scope counter store -- cdna
-// guide G16 recipe R1), the downstream band polls it once per MEDB_K levels and reads the row with agent-scope
-// loads, a whole block of levels ahead.  Dependencies only point upstream, all bands are co-resident (<= 256
-// single-wave workgroups), spins are bounded (error word + bail out).  Requires W >= 2 and H >= 2.
+// level costs ~45 VALU instructions (rank selection by adc_median9 with +-inf padding instead of a 25-exchange
+// sort).  Requires W >= 2 and H >= 2.
+//
+// Band b's first row needs the filtered last row of band b-1.  Device-scope (sc1) stores are expensive here -- the
+// bands sit on different XCDs, so such a store goes through to memory; 64 of them per level cost 3x the whole
+// filter -- hence the map itself is written with plain stores (made visible by the end of the kernel) and only the
+// band's LAST ROW is additionally written, 16 levels at a time, to a small hand-off buffer indexed by LEVEL
+// (hand[band][t] = result of the last row at level t) with four 16-byte sc1 stores per block.  The downstream band
+// reads hand[band-1][t-1] with sc1 loads one block ahead.  To keep the cross-XCD hand-off off the per-level
+// critical path band b runs >= 2*MEDB_K levels behind band b-1: "levels completed" is published once per block
+// and polled once per block.  Dependencies only point upstream, all bands are co-resident (<= 256 single-wave
+// workgroups), spins are bounded (error word + bail out, reported by adc_wait).
 #define MEDB_ROWS 64
-#define MEDB_K 16 // levels per block: progress publication / polling period and bulk-prefetch depth
+#define MEDB_K 16 // levels per block (the asm take-over statements are written for 16)
+#define MEDB_HPAD 4 // hand[band][MEDB_HPAD + t]
 
+typedef float medb_v4f __attribute__((ext_vector_type(4)));
 template <int CTRL> __device__ __forceinline__ float medb_dpp(float src)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xf, 0xf, false));
 }
 
-__global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* out, int W, int H,
-                                                             int* progress, int* error_word)
+__global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* __restrict__ out, int W, int H,
+                                                             int* progress, int* error_word, float* hand, int hpitch)
 {
     const int tid = threadIdx.x;
     const int band = blockIdx.x;
@@ -718,79 +843,134 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     auto clampc = [&](int c) __attribute__((always_inline)) { return c < 0 ? 0 : (c >= W ? W - 1 : c); };
     const int ya = row_ok ? y : H - 1, yb = y + 1 < H ? y + 1 : H - 1;
     const float* rowA = in + (size_t)ya * W;
-    // lanes that take their row-below / row-above values from a neighbour lane all read ONE dummy address, so
-    // the loads stay unconditional (no vmcnt drain) yet cost a single cache line per instruction
-    const float* rowB = in + (own_b ? (size_t)yb * W : 0);
-    const float* rowU = out + (first_row ? (size_t)(y - 1) * W : 0);
-    const int mB = own_b ? 0x7fffffff : 0, mU = first_row ? 0x7fffffff : 0; // column masks (0 -> dummy column 0)
+    // one auxiliary load stream serves two lanes: lane 0 of a band > 0 reads the upstream hand-off row (by level), the
+    // band's last lane reads the unfiltered row below (column x+1); every other lane reads dummy element 0 of `in`,
+    // so the loads are unconditional yet cost a single cache line per instruction
+    const float* rowX = first_row ? hand + (size_t)(band - 1) * hpitch + MEDB_HPAD - 1 : in + (own_b ? (size_t)yb * W : 0);
     const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
     int x = -2 * y; // column at level 0
     float A0 = rowA[clampc(x)], A1 = rowA[clampc(x + 1)], A2 = rowA[clampc(x + 2)];
     const float* rowBfull = in + (size_t)yb * W;
     float Bm = rowBfull[clampc(x - 1)], B0 = rowBfull[clampc(x)];
     float Fm = 0.f, F0 = 0.f, Pv = 0.f;
-    // bulk prefetch, one block of MEDB_K levels ahead: the per-level critical path holds no global load
-    float na[MEDB_K], nb[MEDB_K], nu[MEDB_K];
-#pragma unroll
-    for (int k = 0; k < MEDB_K; k++) {
-        na[k] = rowA[clampc(x + 3 + k)];
-        nb[k] = rowB[clampc(x + 1 + k) & mB];
-        nu[k] = 0.0f; // levels 0..MEDB_K-1 of a band > 0: its first row is idle (x < 0)
+    // Prefetch, one block of MEDB_K levels ahead, with the loads issued from inline asm (the compiler's own model of
+    // loop-carried outstanding loads forces near-complete drains of the memory counter, i.e. of the stores in
+    // flight).  Every block issues EXACTLY, in this order: 32 loads, 16 map stores (inactive lanes store to a sink
+    // word), 4 hand-off stores, 1 progress store; vector-memory operations complete in issue order, so counted waits
+    // are exact:
+    //   vmcnt(21) before a block    -> the 32 loads issued one block earlier have landed;
+    //   vmcnt(53) before publishing -> the hand-off stores of the PREVIOUS block have completed (only the previous
+    //                                  progress store, this block's loads and stores may be outstanding): "levels
+    //                                  completed" is published one block late, so no store drain sits on the
+    //                                  critical path.
+    float ca[MEDB_K], cx[MEDB_K], ra[MEDB_K], rx[MEDB_K], hr[MEDB_K];
+// take over the prefetched values: wait + moves in ONE statement, nothing can be hoisted above the wait
+#define MEDB_TAKE8(DST, SRC, O, WAIT)                                                                                   \
+    asm volatile(WAIT "v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"               \
+                      "v_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"                 \
+                 : "=&v"(DST[O]), "=&v"(DST[O + 1]), "=&v"(DST[O + 2]), "=&v"(DST[O + 3]), "=&v"(DST[O + 4]),           \
+                   "=&v"(DST[O + 5]), "=&v"(DST[O + 6]), "=&v"(DST[O + 7])                                              \
+                 : "v"(SRC[O]), "v"(SRC[O + 1]), "v"(SRC[O + 2]), "v"(SRC[O + 3]), "v"(SRC[O + 4]), "v"(SRC[O + 5]),    \
+                   "v"(SRC[O + 6]), "v"(SRC[O + 7])                                                                     \
+                 : "memory")
+#define MEDB_TAKE(WAIT)                                                                                                 \
+    do {                                                                                                                \
+        MEDB_TAKE8(ca, ra, 0, WAIT);                                                                                    \
+        MEDB_TAKE8(ca, ra, 8, "");                                                                                      \
+        MEDB_TAKE8(cx, rx, 0, "");                                                                                      \
+        MEDB_TAKE8(cx, rx, 8, "");                                                                                      \
+    } while (0)
+// the 32 loads of the block that starts at level T (this row is then at column XN)
+#define MEDB_ISSUE(T, XN)                                                                                               \
+    _Pragma("unroll") for (int k = 0; k < MEDB_K; k++) {                                                                \
+        const float* pa_ = rowA + clampc((XN) + 3 + k);                                                                 \
+        const int ix_ = first_row ? (T) + k : (own_b ? clampc((XN) + 1 + k) : 0);                                       \
+        const float* px_ = rowX + ix_;                                                                                  \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(ra[k]) : "v"(pa_) : "memory");                              \
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(rx[k]) : "v"(px_) : "memory");                          \
     }
+    // block 0: a band's first row is idle there (x < 0), whatever it reads from the hand-off row is never used
+    MEDB_ISSUE(1, x);
+    MEDB_TAKE("s_waitcnt vmcnt(0)\n\t");
+    // the compiler-issued window loads above are consumed here, so that no wait for them ends up inside the loop
+    asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(Bm), "+v"(B0));
+    float* const sinkf = reinterpret_cast<float*>(error_word + 2);  // store target of inactive lanes
+    float* const sink4 = reinterpret_cast<float*>(error_word + 4);  // 16-byte sink (hand-off stores of the other lanes)
+    int* const pubp = last_row ? progress + band : error_word + 3;  // progress word of the band (sink for the other lanes)
+    float* const hrow = hand + (size_t)band * hpitch + MEDB_HPAD;
+    int seen = 0, pl = 0; // upstream progress: last value observed / value fetched asynchronously during the previous block
+    const int* upstream = progress + (band > 0 ? band - 1 : 0);
+    float* const orow = out + (size_t)(row_ok ? y : 0) * W;
 
-    for (int t0 = 0; t0 < nsteps; t0 += MEDB_K) {
+    for (int t0 = 0;;) {
+        // band > 0 stays behind the upstream band: this block uses hand-off values of levels < t0+MEDB_K-1 and
+        // prefetches those of the next block (levels < t0 + 2*MEDB_K - 1).  The progress word is normally read one
+        // block ahead of its use (scalar load past the scalar cache, tracked by lgkmcnt: nothing on the critical
+        // path); only when that stale value is not enough the band polls, and then it waits for two extra blocks of
+        // slack so that the following stale reads succeed.
         if (band > 0) {
-            // stay behind the upstream band: this block reads its rows of levels < t0+MEDB_K and prefetches those of
-            // the next block (levels < t0 + 2*MEDB_K)
             const int need = t0 + 2 * MEDB_K < nsteps ? t0 + 2 * MEDB_K : nsteps;
-            int spins = 0;
-            while (__hip_atomic_load(&progress[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1 << 22)) { atomicExch(error_word, 1); return; }
+            int plv;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, %1" : "=&s"(plv) : "s"(pl) : "memory");
+            seen = plv > seen ? plv : seen;
+            if (seen < need) {
+                const int want = need + 2 * MEDB_K < nsteps ? need + 2 * MEDB_K : nsteps;
+                int spins = 0;
+                while (true) {
+                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(seen) : "s"(upstream) : "memory");
+                    if (seen >= want) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 22)) { atomicExch(error_word, 1); return; }
+                }
             }
+            asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(pl) : "s"(upstream) : "memory");
         }
-        float ca[MEDB_K], cb[MEDB_K], cu[MEDB_K];
-#pragma unroll
-        for (int k = 0; k < MEDB_K; k++) { ca[k] = na[k]; cb[k] = nb[k]; cu[k] = nu[k]; }
-        {
-            const int xn = x + MEDB_K; // column of this row at the first level of the next block
-#pragma unroll
-            for (int k = 0; k < MEDB_K; k++) {
-                na[k] = rowA[clampc(xn + k + 3)];
-                nb[k] = rowB[clampc(xn + k + 1) & mB];
-                nu[k] = __hip_atomic_load(rowU + (clampc(xn + k + 1) & mU), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        MEDB_ISSUE(t0 + MEDB_K, x + MEDB_K);
 #pragma unroll
         for (int k = 0; k < MEDB_K; k++) {
             const bool active = row_ok && (x >= 0) && (x < W);
             // newest filtered value of the row above: out[y-1][x+1] was produced by lane-1 at the previous level
             const float F1d = medb_dpp<0x138>(Pv);    // wave_shr:1
             const float B1d = medb_dpp<0x130>(ca[k]); // wave_shl:1: lane+1's in[y+1][(x-2)+3]
-            const float F1 = first_row ? cu[k] : F1d;
-            const float B1 = own_b ? cb[k] : B1d;
+            const float F1 = first_row ? cx[k] : F1d;
+            const float B1 = own_b ? cx[k] : B1d;
             const bool lf = x > 0, rt = x + 1 < W;
             const float v0 = (up && lf) ? Fm : PINF, v1 = up ? F0 : NINF, v2 = (up && rt) ? F1 : PINF;
             const float v3 = lf ? Pv : NINF, v5 = rt ? A1 : NINF;
             const float v6 = (dn && lf) ? Bm : PINF, v7 = dn ? B0 : NINF, v8 = (dn && rt) ? B1 : PINF;
             // the triple that holds the two late values (F1, Pv) goes last
             const float res = adc_median9(v0, v1, v6, v5, v7, v8, v2, v3, A0);
-            if (active) {
-                __hip_atomic_store(out + (size_t)y * W + x, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // write-through
-                Pv = res;
-            }
+            float* dst = active ? orow + x : sinkf;
+            asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(res) : "memory");
+            hr[k] = res;
+            Pv = active ? res : Pv;
             Fm = F0; F0 = F1;
             A0 = A1; A1 = A2; A2 = ca[k];
             Bm = B0; B0 = B1;
             x++;
         }
-        // publish "levels completed": the lane that stores the band's last row drains its stores first
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (last_row) {
-            const int done = t0 + MEDB_K < nsteps ? t0 + MEDB_K : nsteps;
-            __hip_atomic_store(&progress[band], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            float* hp = last_row ? hrow + t0 : sink4;
+            const int hs = last_row ? 4 : 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const medb_v4f hv = {hr[4 * j], hr[4 * j + 1], hr[4 * j + 2], hr[4 * j + 3]};
+                float* hq = hp + hs * j;
+                // through to memory.  The s_nop covers the ">64-bit store data, then VALU write of those VGPRs" hazard
+                // the assembler cannot see inside an asm statement (the next tuple is assembled right behind).
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(hq), "v"(hv) : "memory");
+            }
         }
+        asm volatile("s_waitcnt vmcnt(53)\n\tglobal_store_dword %0, %1, off sc1" ::"v"(pubp), "v"(t0) : "memory");
+        t0 += MEDB_K;
+        if (t0 >= nsteps) break;
+        MEDB_TAKE("s_waitcnt vmcnt(21)\n\t");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (last_row) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#undef MEDB_ISSUE
+#undef MEDB_TAKE
+#undef MEDB_TAKE8
 }
 
 hipError_t adc_launch_median(adc_handle* h)
@@ -806,12 +986,14 @@ hipError_t adc_launch_median(adc_handle* h)
     }
     static const bool banded = [] { const char* e = getenv("ADC_MEDIAN_BANDED"); return e ? atoi(e) != 0 : true; }();
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
-    if (banded && nbands > 1 && nbands <= 256 && p.W >= 2 && p.H >= 2) {
+    if (banded && nbands > 1 && nbands <= 256 && p.W >= 2 && p.H >= 2 && h->med_hand) {
         // progress counters + error word live in vote_counters[160..]; zeroed on the stream before every launch
         int* prog = h->vote_counters + 160;
-        hipMemsetAsync(prog, 0, 96 * sizeof(int32_t), h->stream);
+        // layout: prog[0..255] band progress, prog[260] error word, prog[262..267] store sinks of idle lanes
+        hipMemsetAsync(prog, 0, 272 * sizeof(int32_t), h->stream);
         hipLaunchKernelGGL(k_median_banded, dim3(nbands), dim3(MEDB_ROWS), 0, h->stream, h->disp_l, h->disp_tmp, p.W, p.H, prog,
-                           prog + 88);
+                           prog + 260, h->med_hand, h->med_hpitch);
+        if (h->pin_flags) hipMemcpyAsync(h->pin_flags, prog + 260, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream); // checked by adc_wait
         float* t = h->disp_l;
         h->disp_l = h->disp_tmp;
         h->disp_tmp = t;
