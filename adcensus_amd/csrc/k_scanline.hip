@@ -29,17 +29,19 @@ template <bool DPP>
 __device__ __forceinline__ float wave_min_f32(float v)
 {
     if constexpr (DPP) {
-        float o;
-        o = dpp_mov<0x121>(v, v); v = o < v ? o : v; // row_ror:1
-        o = dpp_mov<0x122>(v, v); v = o < v ? o : v; // row_ror:2
-        o = dpp_mov<0x124>(v, v); v = o < v ? o : v; // row_ror:4
-        o = dpp_mov<0x128>(v, v); v = o < v ? o : v; // row_ror:8  -> every lane holds its 16-lane row minimum
-        const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-        const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-        const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-        const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-        const float a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
-        return b < a ? b : a;
+        // six in-place v_min_f32 with a DPP source (costs are finite, never NaN: an exact selection); lanes without
+        // a DPP source / outside the row mask keep their value.  Written as asm because the builtin route costs 4
+        // instructions per stage (copy, v_mov_dpp, canonicalise, min); "s_nop 1" = the 2 wait states a DPP read
+        // needs after a VALU write of the same register, which the assembler cannot insert inside an asm block.
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"  /* 16-lane row minima */
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" /* rows 1,3 += rows 0,2 */
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" /* row 3 = all */
+            "s_nop 1"
+            : "+v"(v));
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); // uniform (SGPR) result
     } else {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(256) void k_so_classes(const uint8_t* __restrict__ 
             for (int j = 0; j < 4 * VPL; j++) {
                 const int dd2 = col[j] >= 0 ? d2[j] : d1;
                 const int l = j / VPL, k = j % VPL; // lane within the quad, disparity within the lane
-                word |= (uint32_t)adc_so_penalty_class(d1, dd2, tso) << (8 * l + 2 * k);
+                // VPL <= 2: classes stored pre-scaled as LDS table offsets (k = 0: class*8 in bits 3-4, k = 1: class*32
+                // in bits 5-6, see SO_STEP); VPL = 4: four packed 2-bit fields
+                word |= (uint32_t)adc_so_penalty_class(d1, dd2, tso) << (8 * l + 2 * k + (VPL <= 2 ? 3 : 0));
             }
         }
         *reinterpret_cast<uint32_t*>(cls + ((size_t)pass * P + pix) * 64 + quad * 4) = word;
@@ -198,6 +202,17 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
                                                   float P1b, float P1c, float P2a, float P2b, float P2c)
 {
     constexpr int Dp = 64 * VPL;
+    // (P1,P2) by penalty class, addressed with the pre-scaled class bits of the class byte: table A has 8-byte
+    // entries (class*8), table B 32-byte entries (class*32); class 3 == class 2 (both differences above the threshold)
+    __shared__ float2 so_tabA[4];
+    __shared__ float2 so_tabB[16];
+    if (threadIdx.x < 4) {
+        const int c = threadIdx.x;
+        const float2 pp = make_float2(c == 0 ? P1a : (c == 1 ? P1b : P1c), c == 0 ? P2a : (c == 1 ? P2b : P2c));
+        so_tabA[c] = pp;
+        so_tabB[4 * c] = pp;
+    }
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int npaths = VERT ? W : H;
@@ -228,36 +243,47 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
 // one DP step for path element I with inputs E (a macro keeps every array in registers)
 #define SO_STEP(I, E)                                                                                      \
     do {                                                                                                   \
-        const size_t pix_ = so_pixel<VERT>(g, (I));                                                        \
         const float up_ = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane); /* L(q, d0-1), sentinel at d=-1 */ \
         const float dn_ = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane); /* L(q, d0+VPL), sentinel at d=D */ \
         float out_[VPL];                                                                                   \
-        float omin_ = ADC_LARGE_FLOAT;                                                                     \
         _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
         {                                                                                                  \
-            const int cls_ = ((E).cls >> (2 * k)) & 3;                                                     \
-            const float P1_ = cls_ == 0 ? P1a : (cls_ == 1 ? P1b : P1c);                                   \
-            const float P2_ = cls_ == 0 ? P2a : (cls_ == 1 ? P2b : P2c);                                   \
+            float P1_, P2_;                                                                                \
+            if constexpr (VPL <= 2) { /* one LDS read of the (P1,P2) pair at the pre-scaled class offset */ \
+                const float2 pp_ = *reinterpret_cast<const float2*>(                                       \
+                    reinterpret_cast<const char*>(k == 0 ? so_tabA : so_tabB) + ((E).cls & (k == 0 ? 0x18 : 0x60))); \
+                P1_ = pp_.x; P2_ = pp_.y;                                                                  \
+            } else {                                                                                       \
+                const int cls_ = ((E).cls >> (2 * k)) & 3;                                                 \
+                P1_ = cls_ == 0 ? P1a : (cls_ == 1 ? P1b : P1c);                                           \
+                P2_ = cls_ == 0 ? P2a : (cls_ == 1 ? P2b : P2c);                                           \
+            }                                                                                              \
             const float lm1_ = k == 0 ? up_ : Lp[k == 0 ? 0 : k - 1];                                      \
             const float lp1_ = k == VPL - 1 ? dn_ : Lp[k == VPL - 1 ? k : k + 1];                          \
             const float l1_ = Lp[k];                                                                       \
             const float l2_ = lm1_ + P1_;                                                                  \
             const float l3_ = lp1_ + P1_;                                                                  \
             const float l4_ = minLp + P2_;                                                                 \
-            const float m12_ = l2_ < l1_ ? l2_ : l1_;                                                      \
-            const float m123_ = l3_ < m12_ ? l3_ : m12_; /* independent of the wave minimum */             \
-            const float mm_ = l4_ < m123_ ? l4_ : m123_; /* == min(min(l1,l2),min(l3,l4)) */               \
+            /* min(min(l1,l2),min(l3,l4)): all finite, never NaN -> v_min3/v_min are exact selections */   \
+            const float mm_ = __builtin_fminf(__builtin_fminf(__builtin_fminf(l1_, l2_), l3_), l4_);       \
             float cs_ = (E).c[k] + mm_;                                                                    \
-            cs_ = cs_ / 2; /* scanline_optimizer.cpp:151 */                                                \
+            cs_ = cs_ * 0.5f; /* == cs / 2 exactly (scanline_optimizer.cpp:151) */                         \
             out_[k] = cs_;                                                                                 \
         }                                                                                                  \
-        vstore<VPL>(dst + pix_ * Dp + g.d0, out_);                                                         \
+        SO_STORE(I, out_);                                                                                 \
+        float omin_ = ADC_LARGE_FLOAT;                                                                     \
         _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
         {                                                                                                  \
             Lp[k] = (g.d0 + k) < D ? out_[k] : ADC_LARGE_FLOAT;                                            \
-            omin_ = Lp[k] < omin_ ? Lp[k] : omin_;                                                         \
+            omin_ = __builtin_fminf(Lp[k], omin_);                                                         \
         }                                                                                                  \
         minLp = wave_min_f32<DPP>(omin_);                                                                  \
+    } while (0)
+// output store of the prefetch path: running pointer (path elements are visited in order)
+#define SO_STORE(I, OUT)              \
+    do {                              \
+        vstore<VPL>(dpn, OUT);        \
+        dpn += fstep;                 \
     } while (0)
 
     if constexpr (VPL <= 2) {
@@ -267,14 +293,20 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         typedef typename VecT<VPL>::type vec_t;
         vec_t pfc[SO_PF];
         int pfk[SO_PF];
+        // running pointers: next element to prefetch (data, classes) and next element to store
+        const long long pstep = (long long)(VERT ? W : 1) * dir; // pixels per path step
+        const long long fstep = pstep * Dp, cstep = pstep * 64;
+        const size_t px1 = so_pixel<VERT>(g, 1);
+        const float* spn = src + px1 * Dp + g.d0;
+        const uint8_t* cpn = cls + px1 * 64 + g.lane;
+        float* dpn = dst + px1 * Dp + g.d0;
 #define SO_ISSUE(U, I)                                                                                         \
     do {                                                                                                       \
-        const size_t px_ = so_pixel<VERT>(g, (I));                                                             \
-        const float* dp_ = src + px_ * Dp + g.d0;                                                              \
-        const uint8_t* cp_ = cls + px_ * 64 + g.lane;                                                          \
-        if constexpr (VPL == 1) asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[U]) : "v"(dp_) : "memory"); \
-        else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[U]) : "v"(dp_) : "memory");              \
-        asm volatile("global_load_ubyte %0, %1, off" : "=v"(pfk[U]) : "v"(cp_) : "memory");                    \
+        if constexpr (VPL == 1) asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory"); \
+        else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory");              \
+        asm volatile("global_load_ubyte %0, %1, off" : "=v"(pfk[U]) : "v"(cpn) : "memory");                    \
+        spn += fstep;                                                                                          \
+        cpn += cstep;                                                                                          \
     } while (0)
 #define SO_TAKE(U, WAITN, E)                                                                                   \
     do {                                                                                                       \
@@ -332,6 +364,8 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         }
 #undef SO_ISSUE
 #undef SO_TAKE
+#undef SO_STORE
+#define SO_STORE(I, OUT) vstore<VPL>(dst + so_pixel<VERT>(g, (I)) * Dp + g.d0, OUT)
     } else {
         // VPL == 4 (disparity range > 128): compiler-scheduled prefetch ring
         SoElem<VPL> pre[SO_PF];
@@ -354,6 +388,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         }
     }
 #undef SO_STEP
+#undef SO_STORE
 }
 
 static bool so_use_dpp()
