@@ -49,7 +49,7 @@ struct adc_handle {
     int* armmax;             // [0] max horizontal arm, [1] max vertical arm of the current left image
     uint32_t *rec_h, *rec_v; // packed {arm_lo, arm_hi, divisor} per pixel, line-major (rec_v transposed)
     uint8_t *cdiff_lh, *cdiff_lv, *cdiff_rh, *cdiff_rv;
-    uint8_t* so_cls; // [4 passes][H][W][64] packed 2-bit scanline penalty classes per lane
+    uint8_t* so_cls; // path-ordered left-image colour-step words (d1) of the 4 scanline pass types (k_scanline.hip)
     // volumes
     float *vol_a, *vol_b;
     // host-built tables: same libm as the CPU reference
@@ -99,7 +99,8 @@ hipError_t adc_launch_cost(adc_handle* h, float* vol_out);
 hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps
 hipError_t adc_launch_records(adc_handle* h); // arms + counts -> packed aggregation records
 hipError_t adc_launch_aggregate(adc_handle* h, int iterations); // vol_a -> vol_a via vol_b
-hipError_t adc_launch_so_classes(adc_handle* h);
+hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream);
+size_t adc_so_cls_bytes(int W, int H);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_lrcheck(adc_handle* h);

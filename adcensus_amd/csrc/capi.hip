@@ -73,11 +73,11 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->armmax, 4 * sizeof(int)));
     HIP_OK(hipMalloc(&h->rec_h, P * 4));
     HIP_OK(hipMalloc(&h->rec_v, P * 4));
-    HIP_OK(hipMalloc(&h->cdiff_lh, P));
-    HIP_OK(hipMalloc(&h->cdiff_lv, P));
-    HIP_OK(hipMalloc(&h->cdiff_rh, P));
-    HIP_OK(hipMalloc(&h->cdiff_rv, P));
-    HIP_OK(hipMalloc(&h->so_cls, P * 64 * 4));
+    HIP_OK(hipMalloc(&h->cdiff_lh, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
+    HIP_OK(hipMalloc(&h->cdiff_lv, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
+    HIP_OK(hipMalloc(&h->cdiff_rh, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
+    HIP_OK(hipMalloc(&h->cdiff_rv, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
+    HIP_OK(hipMalloc(&h->so_cls, adc_so_cls_bytes(p.W, p.H)));
     HIP_OK(hipMalloc(&h->vol_a, VB));
     HIP_OK(hipMalloc(&h->vol_b, VB));
     HIP_OK(hipMalloc(&h->lut_ad, 768 * sizeof(float)));

@@ -93,74 +93,96 @@ __device__ __forceinline__ void vstore(float* p, const float* r)
     else *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
-// ------------------------------------------------------------------------------ penalty-class maps
-// The (P1,P2) class of (pixel, disparity) depends only on the two images: it is precomputed once per
-// Match for the four pass types into cls[pass][pixel][lane] (one byte per lane holding the 2-bit classes
-// of its VPL disparities), so the DP kernel's per-step inputs are two fully coalesced loads (512 B data
-// + 64 B classes per pixel at D=128) and the sticky-d2 logic (adc_so_d2_column) runs in a massively
-// parallel kernel instead of on the sequential critical path.
+// ------------------------------------------------------------------------------ penalty classes
+// The (P1,P2) class of (pixel, disparity) is (d1 >= tso) + (d2' >= tso) (scanline_optimizer.cpp:129-141):
+//   d1  = colour step of the LEFT image along the path at this pixel (one value per pixel),
+//   d2' = colour step of the RIGHT image at column col = adc_so_d2_column(x, dmin, d, W), or d1 again when that
+//         returns -1 (the "sticky d2" quirk, closed form in adc_device_fn.h):
+//         use the right image  <=>  W >= 3  and  x - dmin >= 1  and  xr < W-1,   col = max(xr, 1),  xr = x - d - dmin.
 //   pass 0: L->R   d1 = dh_left[y][x]      d2 = dh_right[y][col]
 //   pass 1: R->L   d1 = dh_left[y][x+1]    d2 = dh_right[y][col+1]
 //   pass 2: T->B   d1 = dv_left[y][x]      d2 = dv_right[y][col]
 //   pass 3: B->T   d1 = dv_left[y+1][x]    d2 = dv_right[y+1][col]
-// with col = adc_so_d2_column(x, dmin, d, W) (or "use d1" when it returns -1).
-// One thread produces the class bytes of 4 consecutive lanes of one pixel for all four passes
-// (dword stores: a wave writes 4 pixels x 64 B contiguous per pass).
-template <int VPL>
-__global__ __launch_bounds__(256) void k_so_classes(const uint8_t* __restrict__ lh, const uint8_t* __restrict__ lv,
-                                                    const uint8_t* __restrict__ rh, const uint8_t* __restrict__ rv,
-                                                    uint8_t* __restrict__ cls, int W, int H, int dmin, int D, int tso)
+// The DP passes are memory-bound with ~1 wave per SIMD, i.e. their ALUs idle, so the classes are derived INSIDE
+// the DP kernel (no class-map pass over P*D elements, no class stream): a lane's VPL disparities need VPL
+// consecutive bytes of the right-image step map (columns max(xr_last,1) .., one ubyte/ushort/dword gather per
+// step from a 2 MB, L2-resident map; the clamp max(.,1) maps onto "read the same byte twice"), and d1 comes from
+// a tiny PATH-ORDERED copy of the left-image step map: c1w[pass][path][g] = the four d1 bytes of path elements
+// 1+4g .. 4+4g (element i sits at coordinate i on a forward path, plen-1-i on a backward one), one uniform
+// dword per four steps.
+struct SoC1Layout {
+    long long off[4]; // dword offset of each pass
+    int ngr[4];       // groups (of 4 path elements) per path
+    long long total;  // dwords
+};
+static SoC1Layout so_c1_layout(int W, int H)
 {
-    const long long P = (long long)W * H;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long pix = gid >> 4;
-    if (pix >= P) return;
-    const int quad = (int)(gid & 15); // lanes 4*quad .. 4*quad+3
-    const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
-    int col[4 * VPL];
+    SoC1Layout L;
+    const int gh = (W - 1 + 3) / 4 > 0 ? (W - 1 + 3) / 4 : 1, gv = (H - 1 + 3) / 4 > 0 ? (H - 1 + 3) / 4 : 1;
+    const long long sh = (long long)H * gh, sv = (long long)W * gv;
+    L.ngr[0] = L.ngr[1] = gh;
+    L.ngr[2] = L.ngr[3] = gv;
+    L.off[0] = 0; L.off[1] = sh; L.off[2] = 2 * sh; L.off[3] = 2 * sh + sv;
+    L.total = 2 * sh + 2 * sv;
+    return L;
+}
+size_t adc_so_cls_bytes(int W, int H) { return (size_t)so_c1_layout(W, H).total * 4 + 64; }
+
+__global__ __launch_bounds__(256) void k_so_c1(const uint8_t* __restrict__ lh, const uint8_t* __restrict__ lv,
+                                               uint32_t* __restrict__ c1w, int W, int H, long long off1, long long off2,
+                                               long long off3, int ngr_h, int ngr_v)
+{
+    const int pass = blockIdx.z;
+    const bool vert = pass >= 2, bwd = (pass & 1) != 0;
+    const int plen = vert ? H : W, npaths = vert ? W : H, ngr = vert ? ngr_v : ngr_h;
+    const int path = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (path >= npaths || g >= ngr) return;
+    const uint8_t* dl = vert ? lv : lh;
+    uint32_t word = 0;
 #pragma unroll
-    for (int j = 0; j < 4 * VPL; j++) col[j] = adc_so_d2_column(x, dmin, quad * 4 * VPL + j, W);
-#pragma unroll
-    for (int pass = 0; pass < 4; pass++) {
-        const bool vert = pass >= 2, bwd = (pass & 1) != 0;
-        const bool has_pred = vert ? (bwd ? y + 1 < H : y > 0) : (bwd ? x + 1 < W : x > 0);
-        uint32_t word = 0;
-        if (has_pred) {
-            const int sx = vert ? x : (bwd ? x + 1 : x);
-            const int sy = vert ? (bwd ? y + 1 : y) : y;
-            const uint8_t* dl = vert ? lv : lh;
-            const uint8_t* dr = (vert ? rv : rh) + (size_t)sy * W;
-            const int shift = (!vert && bwd) ? 1 : 0;
-            const int d1 = dl[(size_t)sy * W + sx];
-            int d2[4 * VPL];
-#pragma unroll
-            for (int j = 0; j < 4 * VPL; j++) d2[j] = (int)dr[(col[j] >= 0 ? col[j] : 0) + shift];
-#pragma unroll
-            for (int j = 0; j < 4 * VPL; j++) {
-                const int dd2 = col[j] >= 0 ? d2[j] : d1;
-                const int l = j / VPL, k = j % VPL; // lane within the quad, disparity within the lane
-                // VPL <= 2: classes stored pre-scaled as LDS table offsets (k = 0: class*8 in bits 3-4, k = 1: class*32
-                // in bits 5-6, see SO_STEP); VPL = 4: four packed 2-bit fields
-                word |= (uint32_t)adc_so_penalty_class(d1, dd2, tso) << (8 * l + 2 * k + (VPL <= 2 ? 3 : 0));
-            }
-        }
-        *reinterpret_cast<uint32_t*>(cls + ((size_t)pass * P + pix) * 64 + quad * 4) = word;
+    for (int b = 0; b < 4; b++) {
+        const int i0 = 1 + 4 * g + b;
+        const int i = i0 < plen ? i0 : plen - 1; // clamped: loads stay unconditional
+        const int m = bwd ? plen - 1 - i : i;
+        const int x = vert ? path : m, y = vert ? m : path;
+        const int sx = vert ? x : (bwd ? x + 1 : x);
+        const int sy = vert ? (bwd ? y + 1 : y) : y;
+        word |= (uint32_t)dl[(size_t)sy * W + sx] << (8 * b);
     }
+    const long long off = pass == 0 ? 0 : (pass == 1 ? off1 : (pass == 2 ? off2 : off3));
+    c1w[off + (long long)path * ngr + g] = word;
 }
 
-hipError_t adc_launch_so_classes(adc_handle* h)
+hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream)
 {
     const AdcParams& p = h->p;
-    const long long P = (long long)p.W * p.H;
-    const unsigned blocks = (unsigned)((P * 16 + 255) / 256);
-#define CLS_LAUNCH(V)                                                                                                    \
-    hipLaunchKernelGGL(k_so_classes<V>, dim3(blocks), dim3(256), 0, h->heavy, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, \
-                       h->cdiff_rv, h->so_cls, p.W, p.H, p.dmin, p.D, p.opt.so_tso)
-    if (p.VPL == 1) CLS_LAUNCH(1);
-    else if (p.VPL == 2) CLS_LAUNCH(2);
-    else CLS_LAUNCH(4);
-#undef CLS_LAUNCH
+    const SoC1Layout L = so_c1_layout(p.W, p.H);
+    const int gmax = L.ngr[0] > L.ngr[2] ? L.ngr[0] : L.ngr[2], pmax = p.W > p.H ? p.W : p.H;
+    if (pmax > 65535) return hipErrorInvalidValue; // grid.y = path
+    hipLaunchKernelGGL(k_so_c1, dim3((gmax + 255) / 256, pmax, 4), dim3(256), 0, stream, h->cdiff_lh, h->cdiff_lv,
+                       reinterpret_cast<uint32_t*>(h->so_cls), p.W, p.H, L.off[1], L.off[2], L.off[3], L.ngr[0], L.ngr[2]);
     return hipGetLastError();
+}
+
+// LDS byte offsets (class * 8) of the (P1,P2) pairs of this lane's VPL disparities.
+//   rb       VPL consecutive bytes of the right-image step map starting at column max(xr_last, 1) (+1 on R->L)
+//   c1byte   left-image step d1 of this pixel
+//   xr_last  x - dmin - (d0 + VPL-1): right-image column of the lane's LAST disparity (the smallest column)
+template <int VPL>
+__device__ __forceinline__ void so_class_offsets(uint32_t rb, int c1byte, int xr_last, int W, int tso, bool row_ok, int* off)
+{
+    const int c1 = c1byte >= tso ? 8 : 0;
+    const int a0 = xr_last > 1 ? xr_last : 1;
+#pragma unroll
+    for (int k = 0; k < VPL; k++) {
+        const int xr = xr_last + (VPL - 1 - k);
+        const int j = (xr > 1 ? xr : 1) - a0; // 0 .. VPL-1: which of the fetched bytes is column max(xr, 1)
+        const int byte = (int)((rb >> (8 * j)) & 0xffu);
+        const int c2 = byte >= tso ? 8 : 0;
+        const bool use_r = row_ok && xr < W - 1;
+        off[k] = c1 + (use_r ? c2 : c1);
+    }
 }
 
 // ------------------------------------------------------------------------------------- DP kernel
@@ -168,8 +190,9 @@ hipError_t adc_launch_so_classes(adc_handle* h)
 
 template <int VPL>
 struct SoElem {
-    float c[VPL]; // data term
-    int cls;      // packed 2-bit penalty classes of this lane's VPL disparities
+    float c[VPL];  // data term
+    uint32_t rb;   // right-image step bytes (see so_class_offsets)
+    int c1;        // left-image step byte d1
 };
 
 struct SoGeom {
@@ -183,34 +206,39 @@ __device__ __forceinline__ size_t so_pixel(const SoGeom& g, int i)
     return VERT ? (size_t)m * g.W + g.path : (size_t)g.path * g.W + m;
 }
 
+// byte offset into the right-image step map of the VPL bytes path element i needs (this lane)
 template <int VPL, bool VERT>
-__device__ __forceinline__ SoElem<VPL> so_load(const SoGeom& g, const float* __restrict__ src, const uint8_t* __restrict__ cls, int i)
+__device__ __forceinline__ int so_rmap_offset(const SoGeom& g, int i, int cl_last, int dmin_unused)
 {
-    constexpr int Dp = 64 * VPL;
-    const size_t pix = so_pixel<VERT>(g, i);
-    SoElem<VPL> e;
-    vload<VPL>(src + pix * Dp + g.d0, e.c);
-    e.cls = cls[pix * 64 + g.lane];
-    return e;
+    const int m = g.dir > 0 ? i : g.plen - 1 - i;
+    const int x = VERT ? g.path : m, y = VERT ? m : g.path;
+    const int sy = VERT ? (g.dir > 0 ? y : y + 1) : y;
+    const int xr = x - cl_last;
+    return sy * g.W + (xr > 1 ? xr : 1) + ((!VERT && g.dir < 0) ? 1 : 0);
+}
+template <int VPL>
+__device__ __forceinline__ uint32_t so_rmap_load(const uint8_t* __restrict__ rmap, int off)
+{
+    if constexpr (VPL == 1) return rmap[off];
+    else if constexpr (VPL == 2) { uint16_t v; __builtin_memcpy(&v, rmap + off, 2); return v; }
+    else { uint32_t v; __builtin_memcpy(&v, rmap + off, 4); return v; }
 }
 
 // VERT=false: path = image row `path`, marching in x.  VERT=true: path = column, marching in y.
-// dir=+1 forward, -1 backward.  cls = class map of this pass type.
+// dir=+1 forward, -1 backward.  c1w = path-ordered d1 words of this pass type, rmap = right-image step map of the
+// pass direction (horizontal / vertical), at least VPL bytes of slack behind its last element.
 template <int VPL, bool VERT, bool DPP>
 __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src, float* __restrict__ dst,
-                                                  const uint8_t* __restrict__ cls, int W, int H, int D, int dir, float P1a,
-                                                  float P1b, float P1c, float P2a, float P2b, float P2c)
+                                                  const uint32_t* __restrict__ c1w, int ngr,
+                                                  const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso,
+                                                  int dir, float P1a, float P1b, float P1c, float P2a, float P2b, float P2c)
 {
     constexpr int Dp = 64 * VPL;
-    // (P1,P2) by penalty class, addressed with the pre-scaled class bits of the class byte: table A has 8-byte
-    // entries (class*8), table B 32-byte entries (class*32); class 3 == class 2 (both differences above the threshold)
-    __shared__ float2 so_tabA[4];
-    __shared__ float2 so_tabB[16];
+    // (P1,P2) by penalty class, 8-byte entries addressed with class*8
+    __shared__ float2 so_tab[4];
     if (threadIdx.x < 4) {
         const int c = threadIdx.x;
-        const float2 pp = make_float2(c == 0 ? P1a : (c == 1 ? P1b : P1c), c == 0 ? P2a : (c == 1 ? P2b : P2c));
-        so_tabA[c] = pp;
-        so_tabB[4 * c] = pp;
+        so_tab[c] = make_float2(c == 0 ? P1a : (c == 1 ? P1b : P1c), c == 0 ? P2a : (c == 1 ? P2b : P2c));
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -222,6 +250,8 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     if (g.path >= npaths) return;
     g.plen = VERT ? H : W;
     g.d0 = lane * VPL; // first disparity index of this lane
+    const uint32_t* c1p = c1w + (size_t)g.path * ngr; // this path's d1 words (uniform)
+    const int cl_last = g.d0 + VPL - 1 + dmin;         // xr of the lane's last disparity = x - cl_last
 
     float Lp[VPL]; // previous path element's costs; padding lanes (d >= D) hold the sentinel
     float minLp;
@@ -243,21 +273,17 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
 // one DP step for path element I with inputs E (a macro keeps every array in registers)
 #define SO_STEP(I, E)                                                                                      \
     do {                                                                                                   \
+        const int m_ = dir > 0 ? (I) : g.plen - 1 - (I);                                                   \
+        const int x_ = VERT ? g.path : m_;                                                                 \
+        int off_[VPL];                                                                                     \
+        so_class_offsets<VPL>((E).rb, (E).c1, x_ - cl_last, W, tso, W >= 3 && x_ - dmin >= 1, off_);       \
         const float up_ = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane); /* L(q, d0-1), sentinel at d=-1 */ \
         const float dn_ = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane); /* L(q, d0+VPL), sentinel at d=D */ \
         float out_[VPL];                                                                                   \
         _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
         {                                                                                                  \
-            float P1_, P2_;                                                                                \
-            if constexpr (VPL <= 2) { /* one LDS read of the (P1,P2) pair at the pre-scaled class offset */ \
-                const float2 pp_ = *reinterpret_cast<const float2*>(                                       \
-                    reinterpret_cast<const char*>(k == 0 ? so_tabA : so_tabB) + ((E).cls & (k == 0 ? 0x18 : 0x60))); \
-                P1_ = pp_.x; P2_ = pp_.y;                                                                  \
-            } else {                                                                                       \
-                const int cls_ = ((E).cls >> (2 * k)) & 3;                                                 \
-                P1_ = cls_ == 0 ? P1a : (cls_ == 1 ? P1b : P1c);                                           \
-                P2_ = cls_ == 0 ? P2a : (cls_ == 1 ? P2b : P2c);                                           \
-            }                                                                                              \
+            const float2 pp_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(so_tab) + off_[k]); \
+            const float P1_ = pp_.x, P2_ = pp_.y;                                                          \
             const float lm1_ = k == 0 ? up_ : Lp[k == 0 ? 0 : k - 1];                                      \
             const float lp1_ = k == VPL - 1 ? dn_ : Lp[k == VPL - 1 ? k : k + 1];                          \
             const float l1_ = Lp[k];                                                                       \
@@ -288,95 +314,144 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
 
     if constexpr (VPL <= 2) {
         // Prefetch ring with asm-issued loads and hand-counted vmcnt (same technique and the same reasons as
-        // k_agg_march, see k_aggregate.hip): SO_PF path elements (data term + class byte) in flight.
-        // VMEM ops per steady-state step in program order: [data load][class load] ... [output store].
+        // k_agg_march, see k_aggregate.hip): SO_PF = 16 path elements = 4 groups in flight.  Per group of 4 steps the
+        // vector-memory operations are, in program order:
+        //   [data 0][rmap 0][d1 word][store 0] [data 1][rmap 1][store 1] [data 2][rmap 2][store 2] [data 3][rmap 3][store 3]
+        // (13 per group, 52 of the 63 operations the memory counter can track), which gives exact wait counts --
+        // operations younger than everything the step takes (its data, its rmap bytes and, on the first step of a
+        // group, the group's d1 word):
+        //   steady state    : 49 on the first step of a group, 50 on the others
+        //   first iteration : 33 + 4*group on the first step, 34 + 4*group + step otherwise (the prologue issued no stores)
+        //   final chunk     : 33 - 9*group - 2*step, a lower bound that ignores the stores (always safe)
+        // Loads past the end of the path are clamped to its last element / group (harmless duplicates).
         typedef typename VecT<VPL>::type vec_t;
-        vec_t pfc[SO_PF];
-        int pfk[SO_PF];
-        // running pointers: next element to prefetch (data, classes) and next element to store
+        constexpr int PF = 16, NG = PF / 4;
+        vec_t pfc[PF];
+        uint32_t pfr[PF];
+        uint32_t pfw[NG];
         const long long pstep = (long long)(VERT ? W : 1) * dir; // pixels per path step
-        const long long fstep = pstep * Dp, cstep = pstep * 64;
+        const long long fstep = pstep * Dp;
         const size_t px1 = so_pixel<VERT>(g, 1);
-        const float* spn = src + px1 * Dp + g.d0;
-        const uint8_t* cpn = cls + px1 * 64 + g.lane;
-        float* dpn = dst + px1 * Dp + g.d0;
-#define SO_ISSUE(U, I)                                                                                         \
+        const float* spn = src + px1 * Dp + g.d0; // next element to prefetch
+        const uint32_t* cwn = c1p;                 // next d1 word to prefetch
+        float* dpn = dst + px1 * Dp + g.d0;        // next element to store
+        const int last = g.plen - 1;
+        int ii = 1, gi = 0; // element / group the prefetch stands on
+#define SO_ISSUE_D(U)                                                                                          \
     do {                                                                                                       \
-        if constexpr (VPL == 1) asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory"); \
-        else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory");              \
-        asm volatile("global_load_ubyte %0, %1, off" : "=v"(pfk[U]) : "v"(cpn) : "memory");                    \
-        spn += fstep;                                                                                          \
-        cpn += cstep;                                                                                          \
+        const int ro_ = so_rmap_offset<VPL, VERT>(g, ii, cl_last, 0);                                          \
+        if constexpr (VPL == 1) {                                                                              \
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory");                \
+            asm volatile("global_load_ubyte %0, %1, %2" : "=v"(pfr[U]) : "v"(ro_), "s"(rmap) : "memory");      \
+        } else {                                                                                               \
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory");              \
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(pfr[U]) : "v"(ro_), "s"(rmap) : "memory");     \
+        }                                                                                                      \
+        spn += ii < last ? fstep : 0;                                                                          \
+        ii += ii < last ? 1 : 0;                                                                               \
     } while (0)
+#define SO_ISSUE_C(G)                                                                                          \
+    do {                                                                                                       \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pfw[G]) : "v"(cwn) : "memory");                    \
+        cwn += gi + 1 < ngr ? 1 : 0;                                                                           \
+        gi++;                                                                                                  \
+    } while (0)
+// take element U (and, on the first step of a group, the group's d1 word) after waiting for <= WAITN younger ops
 #define SO_TAKE(U, WAITN, E)                                                                                   \
     do {                                                                                                       \
         vec_t tc_;                                                                                             \
-        int tk_;                                                                                               \
-        if constexpr (VPL == 1)                                                                                \
-            asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                         \
-                         : "=&v"(tc_), "=&v"(tk_) : "v"(pfc[U]), "v"(pfk[U]), "n"(WAITN) : "memory");          \
-        else                                                                                                   \
-            asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b32 %1, %3"                         \
-                         : "=&v"(tc_), "=&v"(tk_) : "v"(pfc[U]), "v"(pfk[U]), "n"(WAITN) : "memory");          \
+        uint32_t tr_;                                                                                          \
+        if constexpr (((U)&3) == 0) {                                                                          \
+            if constexpr (VPL == 1)                                                                            \
+                asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" \
+                             : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
+                             : "v"(pfc[U]), "v"(pfr[U]), "v"(pfw[(U) >> 2]), "n"(WAITN) : "memory");           \
+            else                                                                                               \
+                asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b64 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" \
+                             : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
+                             : "v"(pfc[U]), "v"(pfr[U]), "v"(pfw[(U) >> 2]), "n"(WAITN) : "memory");           \
+        } else {                                                                                               \
+            if constexpr (VPL == 1)                                                                            \
+                asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                     \
+                             : "=&v"(tc_), "=&v"(tr_) : "v"(pfc[U]), "v"(pfr[U]), "n"(WAITN) : "memory");      \
+            else                                                                                               \
+                asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b32 %1, %3"                     \
+                             : "=&v"(tc_), "=&v"(tr_) : "v"(pfc[U]), "v"(pfr[U]), "n"(WAITN) : "memory");      \
+        }                                                                                                      \
         if constexpr (VPL == 1) (E).c[0] = tc_;                                                                \
         else { (E).c[0] = tc_.x; (E).c[VPL - 1] = tc_.y; }                                                     \
-        (E).cls = tk_;                                                                                         \
+        (E).rb = tr_;                                                                                          \
+        (E).c1 = (int)((cw >> (8 * ((U)&3))) & 0xffu);                                                         \
     } while (0)
+// one full step of the pipelined loop: take, re-issue the slot for the element PF ahead, DP step
+#define SO_PIPE(U, WAITN)                                                                                      \
+    do {                                                                                                       \
+        SoElem<VPL> cur_;                                                                                      \
+        SO_TAKE(U, WAITN, cur_);                                                                               \
+        SO_ISSUE_D(U);                                                                                         \
+        if constexpr (((U)&3) == 0) SO_ISSUE_C((U) >> 2);                                                      \
+        SO_STEP(i + (U), cur_);                                                                                \
+    } while (0)
+#define SO_FIRST4(G)                                                                                           \
+    SO_PIPE(4 * (G), 33 + 4 * (G)); SO_PIPE(4 * (G) + 1, 35 + 4 * (G)); SO_PIPE(4 * (G) + 2, 36 + 4 * (G));     \
+    SO_PIPE(4 * (G) + 3, 37 + 4 * (G))
+#define SO_STEADY4(G) SO_PIPE(4 * (G), 49); SO_PIPE(4 * (G) + 1, 50); SO_PIPE(4 * (G) + 2, 50); SO_PIPE(4 * (G) + 3, 50)
+#define SO_LAST(U)                                                                                             \
+    if (i + (U) < g.plen) {                                                                                    \
+        SoElem<VPL> cur_;                                                                                      \
+        SO_TAKE(U, 33 - 9 * ((U) >> 2) - 2 * ((U)&3), cur_);                                                   \
+        SO_STEP(i + (U), cur_);                                                                                \
+    }
+#define SO_LAST4(G) SO_LAST(4 * (G)) SO_LAST(4 * (G) + 1) SO_LAST(4 * (G) + 2) SO_LAST(4 * (G) + 3)
+        static_assert(PF == 16, "wait counts and the unrolled groups are written for 16 elements / 4 groups in flight");
+        uint32_t cw = 0; // d1 word of the current group
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // start the manual bookkeeping from an empty queue
+#pragma unroll
+        for (int G = 0; G < NG; G++) { // prologue, same order as the steady state without the stores
+            SO_ISSUE_D(4 * G);
+            SO_ISSUE_C(G);
+            SO_ISSUE_D(4 * G + 1);
+            SO_ISSUE_D(4 * G + 2);
+            SO_ISSUE_D(4 * G + 3);
+        }
         int i = 1;
-        if (i + 2 * SO_PF <= g.plen) {
-#pragma unroll
-            for (int u = 0; u < SO_PF; u++) SO_ISSUE(u, i + u);
-            // first iteration: younger ops = 2 per not-yet-consumed prologue slot + 3 per finished step
-#define SO_FIRST(U)                                     \
-    do {                                                \
-        SoElem<VPL> cur_;                               \
-        SO_TAKE(U, 2 * (SO_PF - 1 - (U)) + 3 * (U), cur_); \
-        SO_ISSUE(U, i + (U) + SO_PF);                   \
-        SO_STEP(i + (U), cur_);                         \
-    } while (0)
-            static_assert(SO_PF == 16, "peeled first iteration written for SO_PF == 16");
-            SO_FIRST(0); SO_FIRST(1); SO_FIRST(2); SO_FIRST(3); SO_FIRST(4); SO_FIRST(5); SO_FIRST(6); SO_FIRST(7);
-            SO_FIRST(8); SO_FIRST(9); SO_FIRST(10); SO_FIRST(11); SO_FIRST(12); SO_FIRST(13); SO_FIRST(14); SO_FIRST(15);
-#undef SO_FIRST
-            i += SO_PF;
-            for (; i + 2 * SO_PF <= g.plen; i += SO_PF) {
-#pragma unroll
-                for (int u = 0; u < SO_PF; u++) {
-                    SoElem<VPL> cur;
-                    SO_TAKE(u, 3 * (SO_PF - 1), cur); // steady state: 3 ops per younger step (+ own store): one stricter
-                    SO_ISSUE(u, i + u + SO_PF);
-                    SO_STEP(i + u, cur);
-                }
+        if (i + PF <= g.plen) {
+            SO_FIRST4(0); SO_FIRST4(1); SO_FIRST4(2); SO_FIRST4(3);
+            i += PF;
+            for (; i + PF <= g.plen; i += PF) {
+                SO_STEADY4(0); SO_STEADY4(1); SO_STEADY4(2); SO_STEADY4(3);
             }
-            // drain: the SO_PF elements still in flight are elements i .. i+SO_PF-1
-#pragma unroll
-            for (int u = 0; u < SO_PF; u++) {
-                SoElem<VPL> cur;
-                SO_TAKE(u, 0, cur);
-                SO_STEP(i + u, cur);
-            }
-            i += SO_PF;
         }
-        for (; i < g.plen; i++) { // tail (< 2*SO_PF elements): compiler-scheduled loads
-            const SoElem<VPL> cur = so_load<VPL, VERT>(g, src, cls, i);
-            SO_STEP(i, cur);
-        }
-#undef SO_ISSUE
+        // final chunk: fewer than PF elements left, all of them in flight
+        SO_LAST4(0) SO_LAST4(1) SO_LAST4(2) SO_LAST4(3)
+#undef SO_ISSUE_D
+#undef SO_ISSUE_C
 #undef SO_TAKE
+#undef SO_PIPE
+#undef SO_FIRST4
+#undef SO_STEADY4
+#undef SO_LAST
+#undef SO_LAST4
 #undef SO_STORE
 #define SO_STORE(I, OUT) vstore<VPL>(dst + so_pixel<VERT>(g, (I)) * Dp + g.d0, OUT)
     } else {
         // VPL == 4 (disparity range > 128): compiler-scheduled prefetch ring
+        auto so_load = [&](int i) __attribute__((always_inline)) {
+            SoElem<VPL> e;
+            vload<VPL>(src + so_pixel<VERT>(g, i) * Dp + g.d0, e.c);
+            e.rb = so_rmap_load<VPL>(rmap, so_rmap_offset<VPL, VERT>(g, i, cl_last, 0));
+            e.c1 = (int)((c1p[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xffu);
+            return e;
+        };
         SoElem<VPL> pre[SO_PF];
 #pragma unroll
-        for (int u = 0; u < SO_PF; u++) pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(1 + u, g.plen - 1));
+        for (int u = 0; u < SO_PF; u++) pre[u] = so_load(adc_imin(1 + u, g.plen - 1));
         int i = 1;
         for (; i + SO_PF <= g.plen; i += SO_PF) {
 #pragma unroll
             for (int u = 0; u < SO_PF; u++) {
                 const SoElem<VPL> cur = pre[u];
-                pre[u] = so_load<VPL, VERT>(g, src, cls, adc_imin(i + u + SO_PF, g.plen - 1));
+                pre[u] = so_load(adc_imin(i + u + SO_PF, g.plen - 1));
                 __builtin_amdgcn_sched_barrier(0);
                 SO_STEP(i + u, cur);
                 __builtin_amdgcn_sched_barrier(0);
@@ -404,10 +479,13 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
     const int npaths = vert ? p.W : p.H;
     const unsigned blocks = (unsigned)((npaths + 3) / 4);
     const int pass = (vert ? 2 : 0) + (dir > 0 ? 0 : 1);
-    const uint8_t* cls = h->so_cls + (size_t)pass * p.W * p.H * 64;
+    const SoC1Layout L = so_c1_layout(p.W, p.H);
+    const uint32_t* c1w = reinterpret_cast<const uint32_t*>(h->so_cls) + L.off[pass];
+    const uint8_t* rmap = vert ? h->cdiff_rv : h->cdiff_rh;
 #define SO_LAUNCH(VERT_, DPP_)                                                                                         \
-    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_>), dim3(blocks), dim3(256), 0, h->heavy, src, dst, cls, p.W, p.H, \
-                       p.D, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2])
+    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_>), dim3(blocks), dim3(256), 0, h->heavy, src, dst, c1w, L.ngr[pass], \
+                       rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2],         \
+                       h->so_P2[0], h->so_P2[1], h->so_P2[2])
     const bool dpp = so_use_dpp();
     if (vert) { if (dpp) SO_LAUNCH(true, true); else SO_LAUNCH(true, false); }
     else { if (dpp) SO_LAUNCH(false, true); else SO_LAUNCH(false, false); }
@@ -419,7 +497,7 @@ template <int VPL>
 static hipError_t run_so(adc_handle* h, int passes)
 {
     // scanline_optimizer.cpp:54-60 (cost_aggr_ == vol_a, cost_init_ == vol_b)
-    hipError_t e = adc_launch_so_classes(h);
+    hipError_t e = adc_launch_so_classes(h, h->heavy); // the path-ordered d1 words (tiny)
     if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1);
     if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1);
     if (e == hipSuccess && passes >= 3) e = launch_so<VPL>(h, h->vol_a, h->vol_b, true, +1);
