@@ -66,6 +66,8 @@ struct adc_handle {
     int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
     int32_t* ray_tab;     // [max_search][16] packed ray offsets (dy<<16 | dx&0xffff), NULL when a step is too close to a .5 tie
     int ray_tab_rows;
+    int fuse_wta;         // set by the pipeline: the last scanline pass also writes the left-view disparity map
+    int wta_left_done;    // the scanline stage did so: adc_launch_wta only runs the right view
     float* med_hand;      // banded median: per-band hand-off rows [bands][med_hpitch], indexed by wavefront level
     int med_hpitch;
     int32_t* pin_flags;   // pinned host word: error flag of the banded median's hand-off (read back after every Match)

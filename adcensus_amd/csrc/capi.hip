@@ -294,7 +294,13 @@ static hipError_t run_heavy(adc_handle* h)
     HIP_OK(adc_launch_records(h));
     HIP_OK(adc_launch_aggregate(h, 4));          // aggregator_.Aggregate(4), :164
     MARK(3, h->heavy);
-    HIP_OK(adc_launch_scanline(h, 4));           // ScanlineOptimize, :100
+    static const bool fuse_wta = [] { const char* e = getenv("ADC_FUSE_WTA"); return e ? atoi(e) != 0 : true; }();
+    h->fuse_wta = fuse_wta ? 1 : 0;
+    {
+        const hipError_t e_ = adc_launch_scanline(h, 4); // ScanlineOptimize, :100 (+ left-view ComputeDisparity, :108)
+        h->fuse_wta = 0;
+        HIP_OK(e_);
+    }
     MARK(4, h->heavy);
     HIP_OK(adc_launch_wta(h));                   // ComputeDisparity + ComputeDisparityRight, :108-109
     MARK(5, h->heavy);

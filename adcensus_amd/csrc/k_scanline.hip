@@ -227,12 +227,19 @@ __device__ __forceinline__ uint32_t so_rmap_load(const uint8_t* __restrict__ rma
 // VERT=false: path = image row `path`, marching in x.  VERT=true: path = column, marching in y.
 // dir=+1 forward, -1 backward.  c1w = path-ordered d1 words of this pass type, rmap = right-image step map of the
 // pass direction (horizontal / vertical), at least VPL bytes of slack behind its last element.
-template <int VPL, bool VERT, bool DPP>
+// WTA=true (last pass of the production pipeline only): the left-view winner-takes-all + sub-pixel step
+// (ADCensusStereo::ComputeDisparity, ADCensusStereo.cpp:188-245; same rules as k_wta<VPL,false>) is evaluated on the
+// final costs while they are still in registers and written to `disp`: the path minimum the recurrence needs anyway IS
+// the winning cost, the winner is the lowest set bit of a ballot, its two neighbours come with two readlanes -- the
+// separate pass that re-reads the whole volume disappears.
+template <int VPL, bool VERT, bool DPP, bool WTA>
 __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src, float* __restrict__ dst,
                                                   const uint32_t* __restrict__ c1w, int ngr,
                                                   const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso,
-                                                  int dir, float P1a, float P1b, float P1c, float P2a, float P2b, float P2c)
+                                                  int dir, float P1a, float P1b, float P1c, float P2a, float P2b, float P2c,
+                                                  float* __restrict__ disp)
 {
+    static_assert(!WTA || DPP, "the fused winner-takes-all relies on the uniform (SGPR) path minimum of the DPP reduction");
     constexpr int Dp = 64 * VPL;
     // (P1,P2) by penalty class, 8-byte entries addressed with class*8
     __shared__ float2 so_tab[4];
@@ -268,6 +275,57 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         }
         minLp = wave_min_f32<DPP>(lmin);
     }
+    // d-1 / d+1 neighbours of the lane's first / last disparity in the CURRENT costs (sentinels beyond the range):
+    // needed by the next DP step and by the fused winner-takes-all, so they are computed once, right after Lp
+    float upN = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane);
+    float dnN = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane);
+// Left-view winner of path element I, whose final costs are in Lp / minLp (pads hold Large_Float).  Only the cheap,
+// mostly scalar part runs per step: winner index (lowest set bit of a ballot against the path minimum -- lowest d
+// wins ties, like the reference's strict '>' scan), its two neighbour costs (readlane), and the minimum; they are
+// parked in lane (I & 63) of four accumulator registers.  Every 64 elements (and at the end of the path) SO_WTA_FLUSH
+// evaluates the edge rules and the sub-pixel parabola for 64 pixels at once, one pixel per lane.
+    int wtaB = 0;
+    float wtaC1 = 0.f, wtaC2 = 0.f, wtaM = 0.f;
+#define SO_WTA(I)                                                                                          \
+    if constexpr (WTA) {                                                                                   \
+        int bi_ = 0x7fffffff;                                                                              \
+        _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
+        {                                                                                                  \
+            const unsigned long long m_ = __ballot(Lp[k] == minLp);                                        \
+            const int c_ = m_ ? (int)__builtin_ctzll(m_) * VPL + k : 0x7fffffff;                           \
+            bi_ = c_ < bi_ ? c_ : bi_;                                                                     \
+        }                                                                                                  \
+        /* the reference scan only updates on cost < min, starting at Large_Float: nothing below -> best stays 0 */ \
+        const int best_ = minLp < ADC_LARGE_FLOAT ? bi_ + dmin : 0;                                        \
+        /* its two neighbour costs: every lane already holds the d-1 / d+1 neighbours of its own disparities */ \
+        const int idx_ = (best_ - dmin) & (64 * VPL - 1);                                                  \
+        const int kw_ = idx_ % VPL, lw_ = idx_ / VPL;                                                      \
+        float s1_ = upN, s2_ = VPL == 1 ? dnN : Lp[VPL == 1 ? 0 : 1];                                      \
+        _Pragma("unroll") for (int k = 1; k < VPL; k++)                                                    \
+        {                                                                                                  \
+            s1_ = kw_ == k ? Lp[k - 1] : s1_;                                                              \
+            s2_ = kw_ == k ? (k == VPL - 1 ? dnN : Lp[k == VPL - 1 ? k : k + 1]) : s2_;                    \
+        }                                                                                                  \
+        const int c1_ = __builtin_amdgcn_readlane(__float_as_int(s1_), lw_);                               \
+        const int c2_ = __builtin_amdgcn_readlane(__float_as_int(s2_), lw_);                               \
+        const int slot_ = (I)&63;                                                                          \
+        const int mn_ = __builtin_amdgcn_readfirstlane(__float_as_int(minLp));                             \
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaB) : "s"(best_), "s"(slot_) : "m0");  \
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaC1) : "s"(c1_), "s"(slot_) : "m0");   \
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaC2) : "s"(c2_), "s"(slot_) : "m0");   \
+        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaM) : "s"(mn_), "s"(slot_) : "m0");    \
+        if (slot_ == 63 || (I) == g.plen - 1) {                                                            \
+            const int e_ = ((I) & ~63) + lane; /* path element parked in this lane */                      \
+            if (e_ <= (I)) {                                                                               \
+                float o_;                                                                                  \
+                if (wtaB == dmin || wtaB == dmin + D - 1) o_ = ADC_INVALID_FLOAT;                          \
+                else if (wtaB - 1 - dmin < 0 || wtaB + 1 - dmin >= D) o_ = (float)wtaB;                    \
+                else o_ = adc_subpixel(wtaB, wtaC1, wtaC2, wtaM);                                          \
+                disp[so_pixel<VERT>(g, e_)] = o_;                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    SO_WTA(0);
     if (g.plen <= 1) return;
 
 // one DP step for path element I with inputs E (a macro keeps every array in registers)
@@ -277,8 +335,8 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         const int x_ = VERT ? g.path : m_;                                                                 \
         int off_[VPL];                                                                                     \
         so_class_offsets<VPL>((E).rb, (E).c1, x_ - cl_last, W, tso, W >= 3 && x_ - dmin >= 1, off_);       \
-        const float up_ = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane); /* L(q, d0-1), sentinel at d=-1 */ \
-        const float dn_ = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane); /* L(q, d0+VPL), sentinel at d=D */ \
+        const float up_ = upN; /* L(q, d0-1), sentinel at d=-1 */                                          \
+        const float dn_ = dnN; /* L(q, d0+VPL), sentinel at d=D */                                         \
         float out_[VPL];                                                                                   \
         _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
         {                                                                                                  \
@@ -304,6 +362,9 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
             omin_ = __builtin_fminf(Lp[k], omin_);                                                         \
         }                                                                                                  \
         minLp = wave_min_f32<DPP>(omin_);                                                                  \
+        upN = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane);                                            \
+        dnN = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane);                                                \
+        SO_WTA(I);                                                                                         \
     } while (0)
 // output store of the prefetch path: running pointer (path elements are visited in order)
 #define SO_STORE(I, OUT)              \
@@ -464,6 +525,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     }
 #undef SO_STEP
 #undef SO_STORE
+#undef SO_WTA
 }
 
 static bool so_use_dpp()
@@ -473,7 +535,7 @@ static bool so_use_dpp()
 }
 
 template <int VPL>
-static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool vert, int dir)
+static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool vert, int dir, float* disp = nullptr)
 {
     const AdcParams& p = h->p;
     const int npaths = vert ? p.W : p.H;
@@ -482,13 +544,19 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
     const SoC1Layout L = so_c1_layout(p.W, p.H);
     const uint32_t* c1w = reinterpret_cast<const uint32_t*>(h->so_cls) + L.off[pass];
     const uint8_t* rmap = vert ? h->cdiff_rv : h->cdiff_rh;
-#define SO_LAUNCH(VERT_, DPP_)                                                                                         \
-    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_>), dim3(blocks), dim3(256), 0, h->heavy, src, dst, c1w, L.ngr[pass], \
-                       rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2],         \
-                       h->so_P2[0], h->so_P2[1], h->so_P2[2])
+#define SO_LAUNCH(VERT_, DPP_, WTA_)                                                                                   \
+    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(256), 0, h->heavy, src, dst, c1w,      \
+                       L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1],         \
+                       h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2], disp)
     const bool dpp = so_use_dpp();
-    if (vert) { if (dpp) SO_LAUNCH(true, true); else SO_LAUNCH(true, false); }
-    else { if (dpp) SO_LAUNCH(false, true); else SO_LAUNCH(false, false); }
+    if (vert) {
+        if (dpp && disp) SO_LAUNCH(true, true, true);
+        else if (dpp) SO_LAUNCH(true, true, false);
+        else SO_LAUNCH(true, false, false);
+    } else {
+        if (dpp) SO_LAUNCH(false, true, false);
+        else SO_LAUNCH(false, false, false);
+    }
 #undef SO_LAUNCH
     return hipGetLastError();
 }
@@ -501,7 +569,12 @@ static hipError_t run_so(adc_handle* h, int passes)
     if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1);
     if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1);
     if (e == hipSuccess && passes >= 3) e = launch_so<VPL>(h, h->vol_a, h->vol_b, true, +1);
-    if (e == hipSuccess && passes >= 4) e = launch_so<VPL>(h, h->vol_b, h->vol_a, true, -1);
+    if (e == hipSuccess && passes >= 4) {
+        // production pipeline: the left-view winner-takes-all rides on the last pass (capi.hip sets fuse_wta)
+        float* disp = (h->fuse_wta && so_use_dpp()) ? h->disp_l : nullptr;
+        e = launch_so<VPL>(h, h->vol_b, h->vol_a, true, -1, disp);
+        h->wta_left_done = disp ? 1 : 0;
+    }
     if (e == hipSuccess && (passes == 1 || passes == 3)) // debug: leave the partial result in vol_a
         e = hipMemcpyAsync(h->vol_a, h->vol_b, (size_t)h->p.W * h->p.H * h->p.Dp * sizeof(float), hipMemcpyDeviceToDevice,
                            h->heavy);

@@ -93,9 +93,11 @@ hipError_t adc_launch_wta(adc_handle* h)
     const AdcParams& p = h->p;
     const long long P = (long long)p.W * p.H;
     const unsigned blocks = (unsigned)((P + 4 * WTA_PPW - 1) / (4 * WTA_PPW));
+    const bool left = !h->wta_left_done; // the last scanline pass of the pipeline already produced the left view
+    h->wta_left_done = 0;
 #define LAUNCH(V)                                                                                                       \
     do {                                                                                                                \
-        hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \
+        if (left) hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \
         hipLaunchKernelGGL((k_wta<V, true>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D);  \
     } while (0)
     if (p.VPL == 1) LAUNCH(1);
