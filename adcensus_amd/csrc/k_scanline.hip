@@ -216,6 +216,15 @@ __device__ __forceinline__ int so_rmap_offset(const SoGeom& g, int i, int cl_las
     const int xr = x - cl_last;
     return sy * g.W + (xr > 1 ? xr : 1) + ((!VERT && g.dir < 0) ? 1 : 0);
 }
+// same, from the coordinate m of the path element (x on a row path, y on a column path)
+template <int VPL, bool VERT>
+__device__ __forceinline__ int so_rmap_offset_m(const SoGeom& g, int m, int cl_last)
+{
+    const int x = VERT ? g.path : m, y = VERT ? m : g.path;
+    const int sy = VERT ? (g.dir > 0 ? y : y + 1) : y;
+    const int xr = x - cl_last;
+    return sy * g.W + (xr > 1 ? xr : 1) + ((!VERT && g.dir < 0) ? 1 : 0);
+}
 template <int VPL>
 __device__ __forceinline__ uint32_t so_rmap_load(const uint8_t* __restrict__ rmap, int off)
 {
@@ -241,7 +250,8 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
 {
     static_assert(!WTA || DPP, "the fused winner-takes-all relies on the uniform (SGPR) path minimum of the DPP reduction");
     constexpr int Dp = 64 * VPL;
-    // (P1,P2) by penalty class, 8-byte entries addressed with class*8
+    // (P1,P2) by penalty class, 8-byte entries addressed with class*8 (selecting them with v_cndmask instead was
+    // measured: no faster)
     __shared__ float2 so_tab[4];
     if (threadIdx.x < 4) {
         const int c = threadIdx.x;
@@ -309,11 +319,11 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         const int c1_ = __builtin_amdgcn_readlane(__float_as_int(s1_), lw_);                               \
         const int c2_ = __builtin_amdgcn_readlane(__float_as_int(s2_), lw_);                               \
         const int slot_ = (I)&63;                                                                          \
-        const int mn_ = __builtin_amdgcn_readfirstlane(__float_as_int(minLp));                             \
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaB) : "s"(best_), "s"(slot_) : "m0");  \
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaC1) : "s"(c1_), "s"(slot_) : "m0");   \
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaC2) : "s"(c2_), "s"(slot_) : "m0");   \
-        asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(wtaM) : "s"(mn_), "s"(slot_) : "m0");    \
+        const bool mine_ = lane == slot_; /* park the four scalars in lane (I & 63) */                       \
+        wtaB = mine_ ? best_ : wtaB;                                                                       \
+        wtaC1 = mine_ ? __int_as_float(c1_) : wtaC1;                                                       \
+        wtaC2 = mine_ ? __int_as_float(c2_) : wtaC2;                                                       \
+        wtaM = mine_ ? minLp : wtaM;                                                                       \
         if (slot_ == 63 || (I) == g.plen - 1) {                                                            \
             const int e_ = ((I) & ~63) + lane; /* path element parked in this lane */                      \
             if (e_ <= (I)) {                                                                               \
@@ -328,11 +338,11 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     SO_WTA(0);
     if (g.plen <= 1) return;
 
+    int mcur = dir > 0 ? 1 : g.plen - 2; // coordinate of path element 1, advanced by every SO_STEP
 // one DP step for path element I with inputs E (a macro keeps every array in registers)
 #define SO_STEP(I, E)                                                                                      \
     do {                                                                                                   \
-        const int m_ = dir > 0 ? (I) : g.plen - 1 - (I);                                                   \
-        const int x_ = VERT ? g.path : m_;                                                                 \
+        const int x_ = VERT ? g.path : mcur; /* mcur = coordinate of path element I (running counter) */   \
         int off_[VPL];                                                                                     \
         so_class_offsets<VPL>((E).rb, (E).c1, x_ - cl_last, W, tso, W >= 3 && x_ - dmin >= 1, off_);       \
         const float up_ = upN; /* L(q, d0-1), sentinel at d=-1 */                                          \
@@ -365,6 +375,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         upN = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane);                                            \
         dnN = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane);                                                \
         SO_WTA(I);                                                                                         \
+        mcur += dir;                                                                                       \
     } while (0)
 // output store of the prefetch path: running pointer (path elements are visited in order)
 #define SO_STORE(I, OUT)              \
@@ -398,9 +409,10 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         float* dpn = dst + px1 * Dp + g.d0;        // next element to store
         const int last = g.plen - 1;
         int ii = 1, gi = 0; // element / group the prefetch stands on
+        int mpf = dir > 0 ? 1 : g.plen - 2; // coordinate of element ii
 #define SO_ISSUE_D(U)                                                                                          \
     do {                                                                                                       \
-        const int ro_ = so_rmap_offset<VPL, VERT>(g, ii, cl_last, 0);                                          \
+        const int ro_ = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last);                                          \
         if constexpr (VPL == 1) {                                                                              \
             asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory");                \
             asm volatile("global_load_ubyte %0, %1, %2" : "=v"(pfr[U]) : "v"(ro_), "s"(rmap) : "memory");      \
@@ -409,6 +421,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
             asm volatile("global_load_ushort %0, %1, %2" : "=v"(pfr[U]) : "v"(ro_), "s"(rmap) : "memory");     \
         }                                                                                                      \
         spn += ii < last ? fstep : 0;                                                                          \
+        mpf += ii < last ? dir : 0;                                                                            \
         ii += ii < last ? 1 : 0;                                                                               \
     } while (0)
 #define SO_ISSUE_C(G)                                                                                          \
