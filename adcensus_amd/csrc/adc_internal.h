@@ -66,6 +66,12 @@ struct adc_handle {
     int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
     int32_t* ray_tab;     // [max_search][16] packed ray offsets (dy<<16 | dx&0xffff), NULL when a step is too close to a .5 tie
     int ray_tab_rows;
+    uint32_t* cost_rrec;  // [H][rrec_pitch] uint4 {bgrx, census lo, census hi, 0} of the RIGHT image, padded with out-of-image
+                          // markers (bgrx = ~0) on both sides; cost_lrec [H][W] the same for the LEFT image (fused cost, k_aggregate.hip)
+    uint32_t* cost_lrec;
+    int rrec_pitch, rrec_padl;
+    int fuse_cost;        // set by the pipeline: the first aggregation pass computes the matching cost itself
+    int agg_first_fused;  // the last aggregation run did so (pass timings: the regular passes are 1..)
     int fuse_wta;         // set by the pipeline: the last scanline pass also writes the left-view disparity map
     int wta_left_done;    // the scanline stage did so: adc_launch_wta only runs the right view
     float* med_hand;      // banded median: per-band hand-off rows [bands][med_hpitch], indexed by wavefront level
@@ -98,6 +104,7 @@ struct adc_handle {
 // All launch on h->stream, asynchronous, return hipError_t of the launch.
 hipError_t adc_launch_gray_census(adc_handle* h);
 hipError_t adc_launch_cost(adc_handle* h, float* vol_out);
+hipError_t adc_launch_cost_records(adc_handle* h);
 hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps
 hipError_t adc_launch_records(adc_handle* h); // arms + counts -> packed aggregation records
 hipError_t adc_launch_aggregate(adc_handle* h, int iterations); // vol_a -> vol_a via vol_b

@@ -62,6 +62,10 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->img_r, P * 3));
     HIP_OK(hipMalloc(&h->gray_l, P));
     HIP_OK(hipMalloc(&h->bgrx_l, P * 4));
+    h->rrec_padl = (p.dmin + p.D - 1 > 0 ? p.dmin + p.D - 1 : 0) + 1;
+    h->rrec_pitch = h->rrec_padl + p.W + (p.dmin < 0 ? -p.dmin : 0) + 1;
+    HIP_OK(hipMalloc(&h->cost_rrec, (size_t)p.H * h->rrec_pitch * 16));
+    HIP_OK(hipMalloc(&h->cost_lrec, P * 16));
     h->med_hpitch = ((p.W + 2 * p.H + 64 + 15) / 16) * 16;
     HIP_OK(hipMalloc(&h->med_hand, (size_t)((p.H + 63) / 64 + 1) * h->med_hpitch * sizeof(float)));
     HIP_OK(hipMalloc(&h->gray_r, P));
@@ -229,7 +233,7 @@ void adc_destroy(adc_handle* h)
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
+                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
                     h->chg_a, h->chg_b, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
@@ -287,12 +291,21 @@ static hipError_t run_heavy(adc_handle* h)
     }
     MARK(0, h->heavy);
     HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
-    HIP_OK(adc_launch_cost(h, h->vol_a));
+    // ADC_FUSE_COST (default on): the cost volume is never written -- the first aggregation pass computes each cost
+    // in registers from packed pixel records (k_agg_march<.., COSTIN>); otherwise K2 writes it and pass 1 reads it back
+    static const bool fuse_cost = [] { const char* e = getenv("ADC_FUSE_COST"); return e ? atoi(e) != 0 : true; }();
+    if (fuse_cost) HIP_OK(adc_launch_cost_records(h));
+    else HIP_OK(adc_launch_cost(h, h->vol_a));
     MARK(1, h->heavy);
     HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
     MARK(2, h->heavy);
     HIP_OK(adc_launch_records(h));
-    HIP_OK(adc_launch_aggregate(h, 4));          // aggregator_.Aggregate(4), :164
+    h->fuse_cost = fuse_cost ? 1 : 0;
+    {
+        const hipError_t e_ = adc_launch_aggregate(h, 4); // aggregator_.Aggregate(4), :164
+        h->fuse_cost = 0;
+        HIP_OK(e_);
+    }
     MARK(3, h->heavy);
     static const bool fuse_wta = [] { const char* e = getenv("ADC_FUSE_WTA"); return e ? atoi(e) != 0 : true; }();
     h->fuse_wta = fuse_wta ? 1 : 0;
@@ -336,8 +349,10 @@ static void collect_timings(adc_handle* h)
         h->stage_ms[i] = ms;
     }
     float tot = 0.f;
-    if (h->agg_launches > 0 && hipEventElapsedTime(&tot, h->ev_agg[0], h->ev_agg[h->agg_launches]) == hipSuccess)
-        h->agg_pass_ms = tot / (float)h->agg_launches;
+    // average duration of a REGULAR aggregation pass (read V + write V); a fused first pass (write-only) is left out
+    const int first = h->agg_first_fused ? 1 : 0;
+    if (h->agg_launches > first && hipEventElapsedTime(&tot, h->ev_agg[first], h->ev_agg[h->agg_launches]) == hipSuccess)
+        h->agg_pass_ms = tot / (float)(h->agg_launches - first);
     if (h->verbose) { // the reference's stage lines (ADCensusStereo.cpp:88-129)
         printf("computing cost! timing :	%lf s\n", (h->stage_ms[0]) / 1000.0);
         printf("cost aggregating! timing :	%lf s\n", (h->stage_ms[1] + h->stage_ms[2]) / 1000.0);
@@ -418,7 +433,7 @@ int adc_get_aggregate_pass_ms(adc_handle* h, float* avg_ms, int* launches)
 {
     if (!h) return 1;
     if (avg_ms) *avg_ms = h->agg_pass_ms;
-    if (launches) *launches = h->agg_launches;
+    if (launches) *launches = h->agg_launches - (h->agg_first_fused ? 1 : 0);
     return 0;
 }
 void* adc_get_stream(adc_handle* h) { return h ? (void*)h->stream : nullptr; }
@@ -494,9 +509,15 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     case ADC_RUN_GRAY_CENSUS: e = adc_launch_gray_census(h); break;
     case ADC_RUN_COST: e = adc_launch_cost(h, h->vol_a); break;
     case ADC_RUN_ARMS: e = adc_launch_arms(h); break;
-    case ADC_RUN_AGGREGATE:
-        e = adc_launch_records(h);
+    case ADC_RUN_AGGREGATE: // arg = iterations (default 4); arg >= 100: first pass with the fused cost computation
+        e = adc_launch_records(h); // (needs ADC_RUN_GRAY_CENSUS before; reads the images instead of ADC_BUF_COST_INIT)
+        if (e == hipSuccess && arg >= 100) {
+            e = adc_launch_cost_records(h);
+            h->fuse_cost = 1;
+            arg -= 100;
+        }
         if (e == hipSuccess) e = adc_launch_aggregate(h, arg > 0 ? arg : 4);
+        h->fuse_cost = 0;
         break;
     case ADC_RUN_SCANLINE: e = adc_launch_scanline(h, arg); break;
     case ADC_RUN_WTA: e = adc_launch_wta(h); break;

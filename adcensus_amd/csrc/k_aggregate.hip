@@ -80,12 +80,31 @@ __device__ __forceinline__ float agg_run(float acc, const float* q, int cnt)
 }
 
 // SMALL only gives the small-ring launch its own kernel name in profiles (the code is identical).
-template <bool VERT, bool DIVIDE, bool SMALL>
+// COSTIN (first pass of the production pipeline, rows, non-dividing): there is no input volume -- each entry of the
+// line, i.e. the AD-Census matching cost of pixel (x, y) for this wave's 64 disparities (cost_computor.cpp:82-121), is
+// computed in registers.  Lane l owns disparity d = d_first + l and needs the right-image pixel of column x - d: as the
+// wave marches in x that column moves one lane per step, so the window {bgrx, census} is a DPP wave_shr:1 shift with
+// the one new column (x - d_first) entering at lane 0; the new column and the left pixel of x arrive as uniform
+// 16-byte records (k_cost_records, rows padded with out-of-image markers), prefetched like the arm records.
+// AD = v_sad_u8 of the packed colours, Hamming = two v_bcnt on the xor of the census words, cost = A[ad] - C[hm] from
+// the host-built tables (in LDS behind the ring) -- bit-identical to k_cost.  Saves writing V and reading it back.
+struct AggCostIn {
+    const uint4* rrec; // right records, row pitch rpitch, first real column at index padl
+    const uint4* lrec; // left records [H][W]
+    const float* lut_ad;
+    const float* lut_census;
+    int rpitch, padl, dmin, D;
+};
+typedef unsigned long long agg_u64;
+
+template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN>
 __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
                                                   const uint32_t* __restrict__ rec, // {lo, hi, count16} per pixel, line-major
                                                   int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
-                                                  const int* __restrict__ armmax, int small_variant, int small_L)
+                                                  const int* __restrict__ armmax, int small_variant, int small_L,
+                                                  AggCostIn ci)
 {
+    static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
     // Two launches per pass: the window depth follows the data.  When no arm of this direction exceeds small_L
     // (e.g. noise-like images) the small-ring variant runs at 32 waves/CU and the full-ring variant exits at once,
     // otherwise the other way round (armmax[0] = max horizontal arm, armmax[1] = max vertical arm, from k_build_arms).
@@ -124,6 +143,40 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     float* dp = dst + pix0 * Dp + chunk * 64 + lane;
     const uint32_t* rp = rec + (long long)fixed * N; // records of this line, contiguous along m
 
+    // ---- fused cost state (COSTIN)
+    float* lutA = ring_all + R * 64; // A[766] then C[64] behind the ring
+    float* lutC = lutA + 768;
+    uint32_t wB = 0, wC0 = 0, wC1 = 0;          // this lane's right-image pixel {bgrx, census} for the current entry
+    const uint4* rrow = nullptr;                 // rrow[x] = right record of column x - d_first (lane 0's column)
+    const uint4* lrow = nullptr;
+    bool pad_lane = false;
+    if constexpr (COSTIN) {
+        for (int i = lane; i < 766; i += 64) lutA[i] = ci.lut_ad[i];
+        lutC[lane] = ci.lut_census[lane];
+        const int d_first = chunk * 64 + ci.dmin;
+        pad_lane = chunk * 64 + lane >= ci.D;
+        rrow = ci.rrec + (size_t)fixed * ci.rpitch + ci.padl - d_first;
+        lrow = ci.lrec + (size_t)fixed * W;
+        // window of the entry BEFORE the first one (column lo-1-d); the first real step shifts it into place
+        const uint4* rbase = ci.rrec + (size_t)fixed * ci.rpitch;
+        int gi = ci.padl - d_first + lo - 1 - lane;
+        gi = gi < 0 ? 0 : (gi >= ci.rpitch ? ci.rpitch - 1 : gi); // index 0 is a marker column (padl >= 1)
+        const uint4 g0 = rbase[gi];
+        wB = g0.x; wC0 = g0.y; wC1 = g0.z;
+    }
+// matching cost of the next entry: RA/RB = new right record {bgrx | census lo << 32, census hi}, LA/LB = left record
+#define AGG_COST(RA, RB, LA, LB, OUT)                                                                              \
+    do {                                                                                                           \
+        wB = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(RA), (int)wB, 0x138, 0xf, 0xf, false);          \
+        wC0 = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)((RA) >> 32), (int)wC0, 0x138, 0xf, 0xf, false); \
+        wC1 = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(RB), (int)wC1, 0x138, 0xf, 0xf, false);         \
+        const uint32_t ad_ = __builtin_amdgcn_sad_u8(wB, (uint32_t)(LA), 0u);                                      \
+        const uint32_t hm_ = __popc(wC0 ^ (uint32_t)((LA) >> 32)) + __popc(wC1 ^ (uint32_t)(LB));                  \
+        float cv_ = lutA[ad_ < 766u ? ad_ : 765u] - lutC[hm_ & 63u]; /* == ((1 - ea) + 1) - ec, cost_computor.cpp:117 */ \
+        cv_ = wB == 0xFFFFFFFFu ? 1.0f : cv_; /* right pixel outside the image (:101-104) */                        \
+        OUT = pad_lane ? 0.0f : cv_;                                                                               \
+    } while (0)
+
     int slot_w = 0;          // ring slot of the next entry to be written
     int slot_m = m0 - lo;    // ring slot of entry m0 (<= L < R)
     float* dpn = dp + (long long)m0 * fstep; // outputs leave in increasing m, starting at m0
@@ -161,6 +214,14 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 
     // ---- phase A: entries lo .. jB-1 that precede the first output's look-ahead (no output yet)
     const int jB = adc_imin(hi, m0 + L);
+    if constexpr (COSTIN) {
+        for (int j = lo; j < jB; j++) {
+            const uint4 rn = rrow[j], ln = lrow[j];
+            float v;
+            AGG_COST((agg_u64)rn.x | ((agg_u64)rn.y << 32), (agg_u64)rn.z, (agg_u64)ln.x | ((agg_u64)ln.y << 32), (agg_u64)ln.z, v);
+            AGG_PUSH(v);
+        }
+    } else {
     for (int j = lo; j < jB; j += AGG_PF) {
         float t[AGG_PF];
 #pragma unroll
@@ -169,14 +230,81 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         for (int u = 0; u < AGG_PF; u++)
             if (j + u < jB) AGG_PUSH(t[u]);
     }
+    }
 
     // ---- phase B (steady state): entry jj arrives, output m = jj - L leaves.
     // All compiler-tracked VMEM traffic of phase A is drained first, so the manual vmcnt bookkeeping
     // below starts from an empty queue.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int j = jB;
+    if constexpr (COSTIN) {
+        // same pipeline with the two pixel records in place of the data load.  VMEM ops per steady-state step, in
+        // program order: [R lo][R hi][L lo][L hi][arm record] ... [output store] = 6
+        if (j + 2 * AGG_PF <= hi) {
+            agg_u64 pRa[AGG_PF], pRb[AGG_PF], pLa[AGG_PF], pLb[AGG_PF];
+            uint32_t pr[AGG_PF];
+            const uint4* rn_ = rrow + j;           // next right record to prefetch
+            const uint4* ln_ = lrow + j;           // next left record
+            const uint32_t* rpn = rp + (j - L);    // record of the output that entry triggers (>= m0)
+#define AGG_ISSUEC(U)                                                                                             \
+    do {                                                                                                          \
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pRa[U]) : "v"(rn_) : "memory");                     \
+        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=v"(pRb[U]) : "v"(rn_) : "memory");            \
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pLa[U]) : "v"(ln_) : "memory");                     \
+        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=v"(pLb[U]) : "v"(ln_) : "memory");            \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pr[U]) : "v"(rpn) : "memory");                        \
+        rn_ += 1;                                                                                                 \
+        ln_ += 1;                                                                                                 \
+        rpn += 1;                                                                                                 \
+    } while (0)
+#pragma unroll
+            for (int u = 0; u < AGG_PF; u++) AGG_ISSUEC(u);
+#define AGG_STEPC(U, WAITN)                                                                                       \
+    do {                                                                                                          \
+        agg_u64 ra_, rb_, la_, lb_;                                                                               \
+        uint32_t rr_;                                                                                             \
+        asm volatile("s_waitcnt vmcnt(%10)\n\tv_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\t"        \
+                     "v_mov_b64 %3, %8\n\tv_mov_b32 %4, %9"                                                       \
+                     : "=&v"(ra_), "=&v"(rb_), "=&v"(la_), "=&v"(lb_), "=&v"(rr_)                                 \
+                     : "v"(pRa[U]), "v"(pRb[U]), "v"(pLa[U]), "v"(pLb[U]), "v"(pr[U]), "n"(WAITN) : "memory");    \
+        AGG_ISSUEC(U);                                                                                            \
+        float v_;                                                                                                 \
+        AGG_COST(ra_, rb_, la_, lb_, v_);                                                                         \
+        AGG_PUSH(v_);                                                                                             \
+        AGG_EMIT(j + (U)-L, rr_); /* exactly one compiler-issued VMEM op (the store) */                           \
+    } while (0)
+            // first iteration: younger ops = 5 per not yet taken prologue slot + 6 per finished step
+            static_assert(AGG_PF == 8, "the peeled first iteration below is written for AGG_PF == 8");
+            AGG_STEPC(0, 35); AGG_STEPC(1, 36); AGG_STEPC(2, 37); AGG_STEPC(3, 38);
+            AGG_STEPC(4, 39); AGG_STEPC(5, 40); AGG_STEPC(6, 41); AGG_STEPC(7, 42);
+            j += AGG_PF;
+            for (; j + 2 * AGG_PF <= hi; j += AGG_PF) { // steady state: 6 ops per younger step
+                AGG_STEPC(0, 42); AGG_STEPC(1, 42); AGG_STEPC(2, 42); AGG_STEPC(3, 42);
+                AGG_STEPC(4, 42); AGG_STEPC(5, 42); AGG_STEPC(6, 42); AGG_STEPC(7, 42);
+            }
+            // drain: the AGG_PF entries still in flight are entries j .. j+AGG_PF-1 (all < hi)
+#define AGG_DRAINC(U, WAIT)                                                                                       \
+    do {                                                                                                          \
+        agg_u64 ra_, rb_, la_, lb_;                                                                               \
+        uint32_t rr_;                                                                                             \
+        asm volatile(WAIT "v_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\tv_mov_b64 %3, %8\n\tv_mov_b32 %4, %9" \
+                     : "=&v"(ra_), "=&v"(rb_), "=&v"(la_), "=&v"(lb_), "=&v"(rr_)                                 \
+                     : "v"(pRa[U]), "v"(pRb[U]), "v"(pLa[U]), "v"(pLb[U]), "v"(pr[U]) : "memory");                \
+        float v_;                                                                                                 \
+        AGG_COST(ra_, rb_, la_, lb_, v_);                                                                         \
+        AGG_PUSH(v_);                                                                                             \
+        AGG_EMIT(j + (U)-L, rr_);                                                                                 \
+    } while (0)
+            AGG_DRAINC(0, "s_waitcnt vmcnt(0)\n\t"); AGG_DRAINC(1, ""); AGG_DRAINC(2, ""); AGG_DRAINC(3, "");
+            AGG_DRAINC(4, ""); AGG_DRAINC(5, ""); AGG_DRAINC(6, ""); AGG_DRAINC(7, "");
+            j += AGG_PF;
+#undef AGG_ISSUEC
+#undef AGG_STEPC
+#undef AGG_DRAINC
+        }
+    } else {
     float pf[AGG_PF];
     uint32_t pr[AGG_PF];
-    int j = jB;
     // The asm-prefetch loop needs every refill index valid without clamping: j + 2*AGG_PF <= hi.
     if (j + 2 * AGG_PF <= hi) {
         const float* spn = sp + (long long)j * fstep;       // next entry to prefetch
@@ -239,9 +367,16 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         }
         j += AGG_PF;
     }
+    }
     // ---- tail of phase B (< 2*AGG_PF entries): plain compiler-scheduled loads
     for (; j < hi; j++) {
-        const float v = sp[(long long)j * fstep];
+        float v;
+        if constexpr (COSTIN) {
+            const uint4 rn = rrow[j], ln = lrow[j];
+            AGG_COST((agg_u64)rn.x | ((agg_u64)rn.y << 32), (agg_u64)rn.z, (agg_u64)ln.x | ((agg_u64)ln.y << 32), (agg_u64)ln.z, v);
+        } else {
+            v = sp[(long long)j * fstep];
+        }
         AGG_PUSH(v);
         const int m = j - L;
         if (m >= m0) AGG_EMIT(m, rp[m]);
@@ -250,6 +385,7 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     for (int m = adc_imax(m0, hi - L); m < m1; m++) AGG_EMIT(m, rp[m]);
 #undef AGG_PUSH
 #undef AGG_EMIT
+#undef AGG_COST
 }
 
 static int env_int(const char* name, int dflt)
@@ -274,7 +410,7 @@ static int pick_nseg(long long nlines, int N, int L, int slots)
     return best;
 }
 
-template <bool VERT, bool DIVIDE>
+template <bool VERT, bool DIVIDE, bool COSTIN = false>
 static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool direct)
 {
     const AdcParams& p = h->p;
@@ -292,7 +428,8 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     for (int variant = 0; variant < 2; variant++) { // 0: full ring, 1: small ring (exits unless every arm <= small_L)
         if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
         const int Lv = variant ? small_L : L;
-        const size_t ldsv = (size_t)(2 * Lv + 1) * 64 * sizeof(float);
+        // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring
+        const size_t ldsv = (size_t)(2 * Lv + 1) * 64 * sizeof(float) + (COSTIN ? (768 + 64) * sizeof(float) : 0);
         const int waves_per_cu = adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
         int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
         if (nseg < 1) nseg = pick_nseg(nlines, N, Lv, 256 * waves_per_cu);
@@ -302,12 +439,18 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const long long waves = nlines * nseg;
         const int per_xcd = (int)((waves + 7) / 8);
         const int sv = (small_L > 0 && small_L < L) ? variant : 0, sl = (small_L > 0 && small_L < L) ? small_L : 0x7fffffff;
+        AggCostIn ci;
+        ci.rrec = reinterpret_cast<const uint4*>(h->cost_rrec);
+        ci.lrec = reinterpret_cast<const uint4*>(h->cost_lrec);
+        ci.lut_ad = h->lut_ad;
+        ci.lut_census = h->lut_census;
+        ci.rpitch = h->rrec_pitch; ci.padl = h->rrec_padl; ci.dmin = p.dmin; ci.D = p.D;
         if (variant)
-            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
-                               VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl);
+            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true, COSTIN>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+                               VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
         else
-            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, false>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
-                               VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl);
+            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, false, COSTIN>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+                               VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
     }
     return hipGetLastError();
 }
@@ -319,19 +462,27 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     static bool attr_set = false;
     if (!attr_set) {
         // allow > 64 KiB dynamic LDS for the ring (large cross_L1)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipError_t e = hipSuccess;
+    const int Lfull = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
+    const bool lds_fits = (size_t)(2 * Lfull + 1) * 64 * sizeof(float) + (768 + 64) * sizeof(float) <= 150 * 1024;
+    h->agg_first_fused = 0;
     bool horizontal_first = true; // cross_aggregator.cpp:100
     int launch = 0;
     for (int k = 0; k < iterations && e == hipSuccess; k++) {
         if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
         if (horizontal_first) {
-            e = launch_pass<false, false>(h, h->vol_a, h->vol_b, direct);
+            // first pass of the pipeline: the matching cost is computed inside the pass (no input volume)
+            const bool fused = k == 0 && h->fuse_cost && !direct && lds_fits;
+            if (k == 0) h->agg_first_fused = fused ? 1 : 0;
+            if (fused) e = launch_pass<false, false, true>(h, h->vol_a, h->vol_b, direct);
+            else e = launch_pass<false, false>(h, h->vol_a, h->vol_b, direct);
             launch++;
             if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
             if (e == hipSuccess) e = launch_pass<true, true>(h, h->vol_b, h->vol_a, direct); // / sup_h

@@ -154,6 +154,46 @@ hipError_t adc_launch_cost(adc_handle* h, float* vol_out)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------- packed pixel records (fused cost)
+// Inputs of the cost computation that is fused into the first aggregation pass (k_agg_march<.., COSTIN>):
+// per pixel {B | G<<8 | R<<16, census lo, census hi, 0}.  The right-image rows are padded on both sides with
+// out-of-image markers (bgrx = 0xFFFFFFFF -> cost 1.0, cost_computor.cpp:101-104), so the marching kernel needs
+// no bounds logic: row pitch = padl + W + padr.
+__global__ __launch_bounds__(256) void k_cost_records(const uint8_t* __restrict__ img_l, const uint8_t* __restrict__ img_r,
+                                                      const uint64_t* __restrict__ census_l,
+                                                      const uint64_t* __restrict__ census_r, uint4* __restrict__ lrec,
+                                                      uint4* __restrict__ rrec, int W, int H, int pitch, int padl)
+{
+    const int y = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < pitch) {
+        const int c = i - padl;
+        uint4 r = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        if (c >= 0 && c < W) {
+            const size_t p = (size_t)y * W + c;
+            const uint64_t cs = census_r[p];
+            r = make_uint4((uint32_t)img_r[3 * p] | ((uint32_t)img_r[3 * p + 1] << 8) | ((uint32_t)img_r[3 * p + 2] << 16),
+                           (uint32_t)cs, (uint32_t)(cs >> 32), 0u);
+        }
+        rrec[(size_t)y * pitch + i] = r;
+    }
+    if (i < W) {
+        const size_t p = (size_t)y * W + i;
+        const uint64_t cs = census_l[p];
+        lrec[p] = make_uint4((uint32_t)img_l[3 * p] | ((uint32_t)img_l[3 * p + 1] << 8) | ((uint32_t)img_l[3 * p + 2] << 16),
+                             (uint32_t)cs, (uint32_t)(cs >> 32), 0u);
+    }
+}
+
+hipError_t adc_launch_cost_records(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    hipLaunchKernelGGL(k_cost_records, dim3((h->rrec_pitch + 255) / 256, p.H), dim3(256), 0, h->heavy, h->img_l, h->img_r,
+                       h->census_l, h->census_r, reinterpret_cast<uint4*>(h->cost_lrec), reinterpret_cast<uint4*>(h->cost_rrec),
+                       p.W, p.H, h->rrec_pitch, h->rrec_padl);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------- volume pad / unpad (debug)
 __global__ void k_pad_volume(const float* __restrict__ src, float* __restrict__ dst, size_t P, int D, int Dp, int to_padded)
 {

@@ -62,6 +62,11 @@ def stage_report(left, right, opt, o, device=0):
         st.debug_write(A.BUF_VOLUME_A, o["cost_init"])
         st.debug_run(A.RUN_AGGREGATE, 4)
         rec("cost_aggr", st.debug_read(A.BUF_VOLUME_A), o["cost_aggr"])
+        # production variant: the first pass computes the matching cost itself from the images + census
+        # (arg >= 100; ignores the cost volume) -- must give the same aggregated volume
+        st.debug_write(A.BUF_VOLUME_A, np.zeros_like(o["cost_init"]))
+        st.debug_run(A.RUN_AGGREGATE, 104)
+        rec("cost_aggr(fused cost)", st.debug_read(A.BUF_VOLUME_A), o["cost_aggr"])
 
         st.debug_write(A.BUF_VOLUME_A, o["cost_aggr"])
         st.debug_run(A.RUN_SCANLINE, 4)
