@@ -164,14 +164,15 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         const uint4 g0 = rbase[gi];
         wB = g0.x; wC0 = g0.y; wC1 = g0.z;
     }
-// matching cost of the next entry: RA/RB = new right record {bgrx | census lo << 32, census hi}, LA/LB = left record
-#define AGG_COST(RA, RB, LA, LB, OUT)                                                                              \
+// matching cost of the next entry: (RB, RC0, RC1) = new right pixel {bgrx, census lo, census hi} entering at lane 0,
+// (LB, LC0, LC1) = left pixel of the entry (both wave-uniform)
+#define AGG_COST(RB, RC0, RC1, LB, LC0, LC1, OUT)                                                                  \
     do {                                                                                                           \
-        wB = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(RA), (int)wB, 0x138, 0xf, 0xf, false);          \
-        wC0 = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)((RA) >> 32), (int)wC0, 0x138, 0xf, 0xf, false); \
-        wC1 = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(RB), (int)wC1, 0x138, 0xf, 0xf, false);         \
-        const uint32_t ad_ = __builtin_amdgcn_sad_u8(wB, (uint32_t)(LA), 0u);                                      \
-        const uint32_t hm_ = __popc(wC0 ^ (uint32_t)((LA) >> 32)) + __popc(wC1 ^ (uint32_t)(LB));                  \
+        wB = (uint32_t)__builtin_amdgcn_update_dpp((int)(RB), (int)wB, 0x138, 0xf, 0xf, false);                    \
+        wC0 = (uint32_t)__builtin_amdgcn_update_dpp((int)(RC0), (int)wC0, 0x138, 0xf, 0xf, false);                 \
+        wC1 = (uint32_t)__builtin_amdgcn_update_dpp((int)(RC1), (int)wC1, 0x138, 0xf, 0xf, false);                 \
+        const uint32_t ad_ = __builtin_amdgcn_sad_u8(wB, (uint32_t)(LB), 0u);                                      \
+        const uint32_t hm_ = __popc(wC0 ^ (uint32_t)(LC0)) + __popc(wC1 ^ (uint32_t)(LC1));                        \
         float cv_ = lutA[ad_ < 766u ? ad_ : 765u] - lutC[hm_ & 63u]; /* == ((1 - ea) + 1) - ec, cost_computor.cpp:117 */ \
         cv_ = wB == 0xFFFFFFFFu ? 1.0f : cv_; /* right pixel outside the image (:101-104) */                        \
         OUT = pad_lane ? 0.0f : cv_;                                                                               \
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         for (int j = lo; j < jB; j++) {
             const uint4 rn = rrow[j], ln = lrow[j];
             float v;
-            AGG_COST((agg_u64)rn.x | ((agg_u64)rn.y << 32), (agg_u64)rn.z, (agg_u64)ln.x | ((agg_u64)ln.y << 32), (agg_u64)ln.z, v);
+            AGG_COST(rn.x, rn.y, rn.z, ln.x, ln.y, ln.z, v);
             AGG_PUSH(v);
         }
     } else {
@@ -238,69 +239,98 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int j = jB;
     if constexpr (COSTIN) {
-        // same pipeline with the two pixel records in place of the data load.  VMEM ops per steady-state step, in
-        // program order: [R lo][R hi][L lo][L hi][arm record] ... [output store] = 6
+        // Same pipeline without the data load: VMEM ops per steady-state step = [arm record load] ... [output store].
+        // The pixel records arrive in BULK: every 64 entries lane l loads the records of entry block_start + l (six
+        // dword loads per block, issued a whole block ahead), and each step picks its entry's six dwords with
+        // v_readlane (wave-uniform values).  The bulk loads make the hand-counted waits conservative (never unsafe).
         if (j + 2 * AGG_PF <= hi) {
-            agg_u64 pRa[AGG_PF], pRb[AGG_PF], pLa[AGG_PF], pLb[AGG_PF];
+            uint32_t cR0, cR1, cR2, cL0, cL1, cL2; // current block: records of entries bx0 + lane
+            uint32_t nR0, nR1, nR2, nL0, nL1, nL2; // next block (in flight)
             uint32_t pr[AGG_PF];
-            const uint4* rn_ = rrow + j;           // next right record to prefetch
-            const uint4* ln_ = lrow + j;           // next left record
-            const uint32_t* rpn = rp + (j - L);    // record of the output that entry triggers (>= m0)
-#define AGG_ISSUEC(U)                                                                                             \
+            const uint4* rbase_ = ci.rrec + (size_t)fixed * ci.rpitch;
+            const int roff_ = (int)(rrow - rbase_); // rrow[x] == rbase_[x + roff_]
+            int bx0 = j, bpos = 0;
+#define AGG_BULK_ISSUE(X0)                                                                                        \
     do {                                                                                                          \
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pRa[U]) : "v"(rn_) : "memory");                     \
-        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=v"(pRb[U]) : "v"(rn_) : "memory");            \
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pLa[U]) : "v"(ln_) : "memory");                     \
-        asm volatile("global_load_dwordx2 %0, %1, off offset:8" : "=v"(pLb[U]) : "v"(ln_) : "memory");            \
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pr[U]) : "v"(rpn) : "memory");                        \
-        rn_ += 1;                                                                                                 \
-        ln_ += 1;                                                                                                 \
-        rpn += 1;                                                                                                 \
+        int ir_ = (X0) + lane + roff_;                                                                            \
+        ir_ = ir_ < 0 ? 0 : (ir_ >= ci.rpitch ? ci.rpitch - 1 : ir_);                                             \
+        const int il_ = adc_imin((X0) + lane, W - 1);                                                             \
+        const uint4* pr_ = rbase_ + ir_;                                                                          \
+        const uint4* pl_ = lrow + il_;                                                                            \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(nR0) : "v"(pr_) : "memory");                          \
+        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(nR1) : "v"(pr_) : "memory");                 \
+        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(nR2) : "v"(pr_) : "memory");                 \
+        asm volatile("global_load_dword %0, %1, off" : "=v"(nL0) : "v"(pl_) : "memory");                          \
+        asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(nL1) : "v"(pl_) : "memory");                 \
+        asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(nL2) : "v"(pl_) : "memory");                 \
     } while (0)
+#define AGG_BULK_TAKE(WAIT)                                                                                       \
+    asm volatile(WAIT "v_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %9\n\t"           \
+                      "v_mov_b32 %4, %10\n\tv_mov_b32 %5, %11"                                                    \
+                 : "=&v"(cR0), "=&v"(cR1), "=&v"(cR2), "=&v"(cL0), "=&v"(cL1), "=&v"(cL2)                         \
+                 : "v"(nR0), "v"(nR1), "v"(nR2), "v"(nL0), "v"(nL1), "v"(nL2) : "memory")
+            AGG_BULK_ISSUE(bx0);
+            AGG_BULK_TAKE("s_waitcnt vmcnt(0)\n\t");
+            AGG_BULK_ISSUE(bx0 + 64);
+            const uint32_t* rpn = rp + (j - L);    // record of the output that entry triggers (>= m0)
 #pragma unroll
-            for (int u = 0; u < AGG_PF; u++) AGG_ISSUEC(u);
-#define AGG_STEPC(U, WAITN)                                                                                       \
+            for (int u = 0; u < AGG_PF; u++) {
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pr[u]) : "v"(rpn) : "memory");
+                rpn += 1;
+            }
+// next block: its loads were issued >= 64 steps (>= 128 VMEM operations) ago and at most 63 can be outstanding
+#define AGG_BULK_NEXT()                                                                                           \
+    if (bpos == 64) {                                                                                             \
+        AGG_BULK_TAKE("");                                                                                        \
+        bx0 += 64;                                                                                                \
+        bpos = 0;                                                                                                 \
+        AGG_BULK_ISSUE(bx0 + 64);                                                                                 \
+    }
+#define AGG_STEPC(U, WAITN, REFILL)                                                                               \
     do {                                                                                                          \
-        agg_u64 ra_, rb_, la_, lb_;                                                                               \
         uint32_t rr_;                                                                                             \
-        asm volatile("s_waitcnt vmcnt(%10)\n\tv_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\t"        \
-                     "v_mov_b64 %3, %8\n\tv_mov_b32 %4, %9"                                                       \
-                     : "=&v"(ra_), "=&v"(rb_), "=&v"(la_), "=&v"(lb_), "=&v"(rr_)                                 \
-                     : "v"(pRa[U]), "v"(pRb[U]), "v"(pLa[U]), "v"(pLb[U]), "v"(pr[U]), "n"(WAITN) : "memory");    \
-        AGG_ISSUEC(U);                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, %1" : "=&v"(rr_) : "v"(pr[U]), "n"(WAITN) : "memory"); \
+        if (REFILL) {                                                                                             \
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pr[U]) : "v"(rpn) : "memory");                    \
+            rpn += 1;                                                                                             \
+        }                                                                                                         \
+        const int li_ = bpos + (U);                                                                               \
+        const uint32_t rb_ = (uint32_t)__builtin_amdgcn_readlane((int)cR0, li_);                                  \
+        const uint32_t rc0_ = (uint32_t)__builtin_amdgcn_readlane((int)cR1, li_);                                 \
+        const uint32_t rc1_ = (uint32_t)__builtin_amdgcn_readlane((int)cR2, li_);                                 \
+        const uint32_t lb_ = (uint32_t)__builtin_amdgcn_readlane((int)cL0, li_);                                  \
+        const uint32_t lc0_ = (uint32_t)__builtin_amdgcn_readlane((int)cL1, li_);                                 \
+        const uint32_t lc1_ = (uint32_t)__builtin_amdgcn_readlane((int)cL2, li_);                                 \
         float v_;                                                                                                 \
-        AGG_COST(ra_, rb_, la_, lb_, v_);                                                                         \
+        AGG_COST(rb_, rc0_, rc1_, lb_, lc0_, lc1_, v_);                                                           \
         AGG_PUSH(v_);                                                                                             \
         AGG_EMIT(j + (U)-L, rr_); /* exactly one compiler-issued VMEM op (the store) */                           \
     } while (0)
-            // first iteration: younger ops = 5 per not yet taken prologue slot + 6 per finished step
+            // first iteration: younger ops = 1 per not yet taken prologue slot + 2 per finished step
             static_assert(AGG_PF == 8, "the peeled first iteration below is written for AGG_PF == 8");
-            AGG_STEPC(0, 35); AGG_STEPC(1, 36); AGG_STEPC(2, 37); AGG_STEPC(3, 38);
-            AGG_STEPC(4, 39); AGG_STEPC(5, 40); AGG_STEPC(6, 41); AGG_STEPC(7, 42);
+            AGG_STEPC(0, 7, true); AGG_STEPC(1, 8, true); AGG_STEPC(2, 9, true); AGG_STEPC(3, 10, true);
+            AGG_STEPC(4, 11, true); AGG_STEPC(5, 12, true); AGG_STEPC(6, 13, true); AGG_STEPC(7, 14, true);
             j += AGG_PF;
-            for (; j + 2 * AGG_PF <= hi; j += AGG_PF) { // steady state: 6 ops per younger step
-                AGG_STEPC(0, 42); AGG_STEPC(1, 42); AGG_STEPC(2, 42); AGG_STEPC(3, 42);
-                AGG_STEPC(4, 42); AGG_STEPC(5, 42); AGG_STEPC(6, 42); AGG_STEPC(7, 42);
+            bpos += AGG_PF;
+            for (; j + 2 * AGG_PF <= hi; j += AGG_PF) { // steady state: 2 ops per younger step (+ a bulk issue at times)
+                AGG_BULK_NEXT();
+                AGG_STEPC(0, 14, true); AGG_STEPC(1, 14, true); AGG_STEPC(2, 14, true); AGG_STEPC(3, 14, true);
+                AGG_STEPC(4, 14, true); AGG_STEPC(5, 14, true); AGG_STEPC(6, 14, true); AGG_STEPC(7, 14, true);
+                bpos += AGG_PF;
             }
-            // drain: the AGG_PF entries still in flight are entries j .. j+AGG_PF-1 (all < hi)
-#define AGG_DRAINC(U, WAIT)                                                                                       \
-    do {                                                                                                          \
-        agg_u64 ra_, rb_, la_, lb_;                                                                               \
-        uint32_t rr_;                                                                                             \
-        asm volatile(WAIT "v_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\tv_mov_b64 %3, %8\n\tv_mov_b32 %4, %9" \
-                     : "=&v"(ra_), "=&v"(rb_), "=&v"(la_), "=&v"(lb_), "=&v"(rr_)                                 \
-                     : "v"(pRa[U]), "v"(pRb[U]), "v"(pLa[U]), "v"(pLb[U]), "v"(pr[U]) : "memory");                \
-        float v_;                                                                                                 \
-        AGG_COST(ra_, rb_, la_, lb_, v_);                                                                         \
-        AGG_PUSH(v_);                                                                                             \
-        AGG_EMIT(j + (U)-L, rr_);                                                                                 \
-    } while (0)
-            AGG_DRAINC(0, "s_waitcnt vmcnt(0)\n\t"); AGG_DRAINC(1, ""); AGG_DRAINC(2, ""); AGG_DRAINC(3, "");
-            AGG_DRAINC(4, ""); AGG_DRAINC(5, ""); AGG_DRAINC(6, ""); AGG_DRAINC(7, "");
+            // drain: the AGG_PF records still in flight belong to entries j .. j+AGG_PF-1 (all < hi)
+            AGG_BULK_NEXT();
+            AGG_STEPC(0, 0, false); AGG_STEPC(1, 0, false); AGG_STEPC(2, 0, false); AGG_STEPC(3, 0, false);
+            AGG_STEPC(4, 0, false); AGG_STEPC(5, 0, false); AGG_STEPC(6, 0, false); AGG_STEPC(7, 0, false);
             j += AGG_PF;
-#undef AGG_ISSUEC
+            // The bulk loads of the block that is never used are still in flight: wait for them and only THEN let their
+            // destination registers die -- otherwise the compiler reuses those registers for the values of the
+            // steps above and the late-landing loads overwrite them (found as one wrong entry per row segment).
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(nR0), "v"(nR1), "v"(nR2), "v"(nL0), "v"(nL1), "v"(nL2) : "memory");
+#undef AGG_BULK_ISSUE
+#undef AGG_BULK_TAKE
+#undef AGG_BULK_NEXT
 #undef AGG_STEPC
-#undef AGG_DRAINC
         }
     } else {
     float pf[AGG_PF];
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         float v;
         if constexpr (COSTIN) {
             const uint4 rn = rrow[j], ln = lrow[j];
-            AGG_COST((agg_u64)rn.x | ((agg_u64)rn.y << 32), (agg_u64)rn.z, (agg_u64)ln.x | ((agg_u64)ln.y << 32), (agg_u64)ln.z, v);
+            AGG_COST(rn.x, rn.y, rn.z, ln.x, ln.y, ln.z, v);
         } else {
             v = sp[(long long)j * fstep];
         }

@@ -966,7 +966,12 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
         if (t0 >= nsteps) break;
         MEDB_TAKE("s_waitcnt vmcnt(21)\n\t");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the prefetch of the block past the end is never taken: its registers must stay reserved until it has landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]),
+                 "v"(ra[7]), "v"(ra[8]), "v"(ra[9]), "v"(ra[10]), "v"(ra[11]), "v"(ra[12]), "v"(ra[13]), "v"(ra[14]),
+                 "v"(ra[15]) : "memory");
+    asm volatile("" ::"v"(rx[0]), "v"(rx[1]), "v"(rx[2]), "v"(rx[3]), "v"(rx[4]), "v"(rx[5]), "v"(rx[6]), "v"(rx[7]),
+                 "v"(rx[8]), "v"(rx[9]), "v"(rx[10]), "v"(rx[11]), "v"(rx[12]), "v"(rx[13]), "v"(rx[14]), "v"(rx[15]) : "memory");
     if (last_row) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef MEDB_ISSUE
 #undef MEDB_TAKE

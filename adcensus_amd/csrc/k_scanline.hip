@@ -498,6 +498,15 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         }
         // final chunk: fewer than PF elements left, all of them in flight
         SO_LAST4(0) SO_LAST4(1) SO_LAST4(2) SO_LAST4(3)
+        // Slots past the end of the path were loaded (clamped) but never taken: keep their destination registers alive
+        // until those loads have landed, or the compiler may reuse them for the values of the steps above and a
+        // late-landing load overwrites them.
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(pfc[0]), "v"(pfc[1]), "v"(pfc[2]), "v"(pfc[3]), "v"(pfc[4]), "v"(pfc[5]),
+                     "v"(pfc[6]), "v"(pfc[7]), "v"(pfc[8]), "v"(pfc[9]), "v"(pfc[10]), "v"(pfc[11]), "v"(pfc[12]),
+                     "v"(pfc[13]), "v"(pfc[14]), "v"(pfc[15]) : "memory");
+        asm volatile("" ::"v"(pfr[0]), "v"(pfr[1]), "v"(pfr[2]), "v"(pfr[3]), "v"(pfr[4]), "v"(pfr[5]), "v"(pfr[6]),
+                     "v"(pfr[7]), "v"(pfr[8]), "v"(pfr[9]), "v"(pfr[10]), "v"(pfr[11]), "v"(pfr[12]), "v"(pfr[13]),
+                     "v"(pfr[14]), "v"(pfr[15]), "v"(pfw[0]), "v"(pfw[1]), "v"(pfw[2]), "v"(pfw[3]) : "memory");
 #undef SO_ISSUE_D
 #undef SO_ISSUE_C
 #undef SO_TAKE
