@@ -70,6 +70,8 @@ struct adc_handle {
                           // markers (bgrx = ~0) on both sides; cost_lrec [H][W] the same for the LEFT image (fused cost, k_aggregate.hip)
     uint32_t* cost_lrec;
     int rrec_pitch, rrec_padl;
+    int armmax_host[2];   // maximum horizontal / vertical arm of the current pair, read back by the pipeline
+    int armmax_valid;
     int fuse_cost;        // set by the pipeline: the first aggregation pass computes the matching cost itself
     int agg_first_fused;  // the last aggregation run did so (pass timings: the regular passes are 1..)
     int fuse_wta;         // set by the pipeline: the last scanline pass also writes the left-view disparity map
@@ -105,6 +107,7 @@ struct adc_handle {
 hipError_t adc_launch_gray_census(adc_handle* h);
 hipError_t adc_launch_cost(adc_handle* h, float* vol_out);
 hipError_t adc_launch_cost_records(adc_handle* h);
+int adc_agg_small_L(const adc_handle* h);
 hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps
 hipError_t adc_launch_records(adc_handle* h); // arms + counts -> packed aggregation records
 hipError_t adc_launch_aggregate(adc_handle* h, int iterations); // vol_a -> vol_a via vol_b

@@ -299,11 +299,26 @@ static hipError_t run_heavy(adc_handle* h)
     MARK(1, h->heavy);
     HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
     MARK(2, h->heavy);
+    {   // The maximum arm lengths decide the ring depth of the aggregation kernels and whether same-direction pass
+        // pairs can share a launch (k_aggregate.hip).  Reading two ints back costs one early host synchronisation
+        // (~0.15 ms into the pair; the queue refills while the first aggregation pass runs) and saves three volume
+        // round trips on short-arm images.  ADC_AGG_HOST_ARMS=0: no read-back, the kernels decide per launch.
+        static const bool host_arms = [] { const char* e = getenv("ADC_AGG_HOST_ARMS"); return e ? atoi(e) != 0 : true; }();
+        h->armmax_valid = 0;
+        if (host_arms && h->pin_flags) {
+            HIP_OK(hipMemcpyAsync(h->pin_flags + 4, h->armmax, 2 * sizeof(int), hipMemcpyDeviceToHost, h->heavy));
+            HIP_OK(hipStreamSynchronize(h->heavy));
+            h->armmax_host[0] = h->pin_flags[4];
+            h->armmax_host[1] = h->pin_flags[5];
+            h->armmax_valid = 1;
+        }
+    }
     HIP_OK(adc_launch_records(h));
     h->fuse_cost = fuse_cost ? 1 : 0;
     {
         const hipError_t e_ = adc_launch_aggregate(h, 4); // aggregator_.Aggregate(4), :164
         h->fuse_cost = 0;
+        h->armmax_valid = 0;
         HIP_OK(e_);
     }
     MARK(3, h->heavy);
@@ -511,6 +526,13 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     case ADC_RUN_ARMS: e = adc_launch_arms(h); break;
     case ADC_RUN_AGGREGATE: // arg = iterations (default 4); arg >= 100: first pass with the fused cost computation
         e = adc_launch_records(h); // (needs ADC_RUN_GRAY_CENSUS before; reads the images instead of ADC_BUF_COST_INIT)
+        // arg >= 200: additionally read the maximum arms back (needs ADC_RUN_ARMS before) so that the launcher picks
+        // the ring depth on the host and fuses same-direction pass pairs -- the production pipeline's path
+        if (e == hipSuccess && arg >= 200) {
+            e = hipMemcpy(h->armmax_host, h->armmax, 2 * sizeof(int), hipMemcpyDeviceToHost);
+            h->armmax_valid = e == hipSuccess ? 1 : 0;
+            arg -= 200;
+        }
         if (e == hipSuccess && arg >= 100) {
             e = adc_launch_cost_records(h);
             h->fuse_cost = 1;
@@ -518,6 +540,7 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
         }
         if (e == hipSuccess) e = adc_launch_aggregate(h, arg > 0 ? arg : 4);
         h->fuse_cost = 0;
+        h->armmax_valid = 0;
         break;
     case ADC_RUN_SCANLINE: e = adc_launch_scanline(h, arg); break;
     case ADC_RUN_WTA: e = adc_launch_wta(h); break;

@@ -97,7 +97,13 @@ struct AggCostIn {
 };
 typedef unsigned long long agg_u64;
 
-template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN>
+// PAIR: TWO consecutive passes of the same direction in one launch (the dividing second pass of an iteration and the
+// non-dividing first pass of the next one: V1+V2, H2+H3, V3+V4).  The first pass's outputs are not stored but pushed
+// into a second ring (and their arm records into a small record ring); as soon as output m of the first pass
+// exists, output m-L of the second pass can be summed from the second ring -- same ordered sums, same division, so
+// the result is bit-identical, but the intermediate volume never travels to HBM and back (8 passes -> 5 launches).
+// Needs two rings per wave, so it is used with the small ring only (armmax <= small_L, decided on the host).
+template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN, bool PAIR>
 __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
                                                   const uint32_t* __restrict__ rec, // {lo, hi, count16} per pixel, line-major
                                                   int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
@@ -105,10 +111,13 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
                                                   AggCostIn ci)
 {
     static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
-    // Two launches per pass: the window depth follows the data.  When no arm of this direction exceeds small_L
-    // (e.g. noise-like images) the small-ring variant runs at 32 waves/CU and the full-ring variant exits at once,
-    // otherwise the other way round (armmax[0] = max horizontal arm, armmax[1] = max vertical arm, from k_build_arms).
-    {
+    static_assert(!PAIR || (DIVIDE && !COSTIN), "a fused pair = dividing pass + the following non-dividing pass");
+    // small_variant >= 0 (host does not know the arms, debug path): two launches per pass, the window depth follows
+    // the data.  When no arm of this direction exceeds small_L (e.g. noise-like images) the small-ring variant runs at
+    // 32 waves/CU and the full-ring variant exits at once, otherwise the other way round (armmax[0] = max horizontal
+    // arm, armmax[1] = max vertical arm, from k_build_arms).  small_variant < 0: the host has read armmax and
+    // launches only the variant that applies.
+    if (small_variant >= 0) {
         const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
         if ((small_variant != 0) != fits_small) return;
     }
@@ -129,9 +138,12 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     const int fixed = line / chunks; // x (V pass) or y (H pass)
     const int chunk = line - fixed * chunks;
 
-    const int m0 = seg * seg_len;
-    const int m1 = adc_imin(N, m0 + seg_len);
-    if (m0 >= m1) return;
+    // [s0, s1) = the outputs this wave delivers; [m0, m1) = the outputs of the (first) pass it has to compute for them
+    const int s0 = seg * seg_len;
+    const int s1 = adc_imin(N, s0 + seg_len);
+    if (s0 >= s1) return;
+    const int m0 = PAIR ? adc_imax(0, s0 - L) : s0;
+    const int m1 = PAIR ? adc_imin(N, s1 + L) : s1;
     const int lo = adc_imax(0, m0 - L);
     const int hi = adc_imin(N, m1 + L);
 
@@ -180,7 +192,48 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 
     int slot_w = 0;          // ring slot of the next entry to be written
     int slot_m = m0 - lo;    // ring slot of entry m0 (<= L < R)
-    float* dpn = dp + (long long)m0 * fstep; // outputs leave in increasing m, starting at m0
+    float* dpn = dp + (long long)s0 * fstep; // outputs leave in increasing order, starting at s0
+    // ---- second stage (PAIR): ring of first-pass outputs + their records, behind the first ring
+    float* ring2 = ring_all + R * 64 + lane;
+    uint32_t* recring = reinterpret_cast<uint32_t*>(ring_all + 2 * R * 64);
+    int slot2_w = 0;           // slot of the next first-pass output to be written
+    int slot2_s = s0 - m0;     // slot of first-pass output s0 (the next second-pass output)
+    int mcur = m0;             // index of the next first-pass output
+// second-pass output: ordered sum of first-pass outputs over the pixel's own arm span, no division
+#define AGG_EMIT2()                                                                               \
+    do {                                                                                          \
+        const uint32_t r2_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)recring[slot2_s]);     \
+        const int b_lo_ = (int)(r2_ & 255u), b_hi_ = (int)((r2_ >> 8) & 255u);                    \
+        int i2_ = slot2_s - b_lo_;                                                                \
+        if (i2_ < 0) i2_ += R;                                                                    \
+        const int k_ = b_lo_ + b_hi_ + 1;                                                         \
+        float acc2_;                                                                              \
+        if (k_ == 1) {                                                                            \
+            acc2_ = 0.0f + ring2[i2_ * 64];                                                       \
+        } else {                                                                                  \
+            const int k1_ = adc_imin(k_, R - i2_);                                                \
+            acc2_ = agg_run(0.0f, ring2 + i2_ * 64, k1_);                                         \
+            if (k_ > k1_) acc2_ = agg_run(acc2_, ring2, k_ - k1_);                                \
+        }                                                                                         \
+        *(dpn) = acc2_;                                                                           \
+        dpn += fstep;                                                                             \
+        slot2_s = slot2_s + 1 == R ? 0 : slot2_s + 1;                                             \
+    } while (0)
+// what happens to a finished first-pass output
+#define AGG_OUT(ACC, RECV)                                                                        \
+    do {                                                                                          \
+        if constexpr (PAIR) {                                                                     \
+            ring2[slot2_w * 64] = (ACC);                                                          \
+            recring[slot2_w] = (RECV); /* wave-uniform value, same address in every lane */       \
+            slot2_w = slot2_w + 1 == R ? 0 : slot2_w + 1;                                         \
+            const int s_ = mcur - L; /* its look-ahead (<= L) is complete now */                  \
+            mcur++;                                                                               \
+            if (s_ >= s0 && s_ < s1) AGG_EMIT2();                                                 \
+        } else {                                                                                  \
+            *(dpn) = (ACC);                                                                       \
+            dpn += fstep;                                                                         \
+        }                                                                                         \
+    } while (0)
 
 #define AGG_PUSH(V)                                \
     do {                                           \
@@ -207,8 +260,7 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
             const uint32_t c_ = r_ >> 16;                                                         \
             if (c_ != 1u) acc_ = acc_ / (float)c_; /* cross_aggregator.cpp:389 (x/1 == x) */     \
         }                                                                                         \
-        *(dpn) = acc_;                                                                            \
-        dpn += fstep;                                                                             \
+        AGG_OUT(acc_, r_);                                                                        \
         (void)(M);                                                                                \
         slot_m = slot_m + 1 == R ? 0 : slot_m + 1;                                                \
     } while (0)
@@ -365,14 +417,15 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         // first iteration: the younger ops are the prologue loads of slots U+1.. (2 each) and the U steps
         // already done (3 each): 2*(AGG_PF-1-U) + 3*U = 2*AGG_PF - 2 + U
         static_assert(AGG_PF == 8, "the peeled first iteration below is written for AGG_PF == 8");
-        AGG_STEP(0, 14); AGG_STEP(1, 15); AGG_STEP(2, 16); AGG_STEP(3, 17);
-        AGG_STEP(4, 18); AGG_STEP(5, 19); AGG_STEP(6, 20); AGG_STEP(7, 21);
+        // (PAIR: a step may issue no store at all, so only the loads are counted -- a lower bound is always safe)
+        AGG_STEP(0, 14); AGG_STEP(1, PAIR ? 14 : 15); AGG_STEP(2, PAIR ? 14 : 16); AGG_STEP(3, PAIR ? 14 : 17);
+        AGG_STEP(4, PAIR ? 14 : 18); AGG_STEP(5, PAIR ? 14 : 19); AGG_STEP(6, PAIR ? 14 : 20); AGG_STEP(7, PAIR ? 14 : 21);
         j += AGG_PF;
         // steady state: younger ops = this slot's own store + 3 per younger step = 3*(AGG_PF-1)+1; we wait for
         // <= 3*(AGG_PF-1) outstanding (one stricter).  vmcnt retires in order (loads and stores) on gfx9-family.
         for (; j + 2 * AGG_PF <= hi; j += AGG_PF) {
 #pragma unroll
-            for (int u = 0; u < AGG_PF; u++) AGG_STEP(u, 3 * (AGG_PF - 1));
+            for (int u = 0; u < AGG_PF; u++) AGG_STEP(u, PAIR ? 2 * (AGG_PF - 1) : 3 * (AGG_PF - 1));
         }
 #undef AGG_STEP
         // the AGG_PF entries still in flight are entries j .. j+AGG_PF-1 (all < hi)
@@ -413,6 +466,12 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     }
     // ---- phase C: outputs whose +L look-ahead ends beyond the last entry (image end)
     for (int m = adc_imax(m0, hi - L); m < m1; m++) AGG_EMIT(m, rp[m]);
+    // ---- second pass: outputs whose look-ahead ends beyond the last first-pass output (image end)
+    if constexpr (PAIR) {
+        for (int s = adc_imax(s0, mcur - L); s < s1; s++) AGG_EMIT2();
+    }
+#undef AGG_EMIT2
+#undef AGG_OUT
 #undef AGG_PUSH
 #undef AGG_EMIT
 #undef AGG_COST
@@ -422,6 +481,14 @@ static int env_int(const char* name, int dflt)
 {
     const char* s = getenv(name);
     return s ? atoi(s) : dflt;
+}
+
+// arm length up to which the small-ring variant is used (ADC_AGG_SMALL_L, 0 disables it)
+int adc_agg_small_L(const adc_handle* h)
+{
+    static const int small_L_env = env_int("ADC_AGG_SMALL_L", 8);
+    const int L = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
+    return adc_imin(small_L_env, L);
 }
 
 // Picks the number of line segments: all waves of a "round" run concurrently (9 per CU), a pass costs
@@ -440,8 +507,10 @@ static int pick_nseg(long long nlines, int N, int L, int slots)
     return best;
 }
 
-template <bool VERT, bool DIVIDE, bool COSTIN = false>
-static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool direct)
+// which: 0 = the host does not know the arms: launch the full-ring and the small-ring variant, the kernel decides;
+//        1 = small ring only, 2 = full ring only (the host has read armmax).  PAIR needs which == 1.
+template <bool VERT, bool DIVIDE, bool COSTIN = false, bool PAIR = false>
+static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool direct, int which = 0)
 {
     const AdcParams& p = h->p;
     const int L = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
@@ -453,22 +522,25 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     }
     const int N = VERT ? p.H : p.W;
     const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / 64);
-    static const int small_L_env = env_int("ADC_AGG_SMALL_L", 8); // 0 disables the small-ring variant
-    const int small_L = adc_imin(small_L_env, L);
+    const int small_L = adc_agg_small_L(h);
     for (int variant = 0; variant < 2; variant++) { // 0: full ring, 1: small ring (exits unless every arm <= small_L)
         if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
+        if ((which == 1 && variant == 0 && small_L > 0 && small_L < L) || (which == 2 && variant == 1)) continue;
         const int Lv = variant ? small_L : L;
-        // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring
-        const size_t ldsv = (size_t)(2 * Lv + 1) * 64 * sizeof(float) + (COSTIN ? (768 + 64) * sizeof(float) : 0);
+        // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring, the pair variant a second
+        // ring and a record ring
+        const size_t ring_bytes = (size_t)(2 * Lv + 1) * 64 * sizeof(float);
+        const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + (PAIR ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
         const int waves_per_cu = adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
         int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
-        if (nseg < 1) nseg = pick_nseg(nlines, N, Lv, 256 * waves_per_cu);
+        if (nseg < 1) nseg = pick_nseg(nlines, N, PAIR ? 2 * Lv : Lv, 256 * waves_per_cu);
         int seg_len = (N + nseg - 1) / nseg;
         if (seg_len < 1) seg_len = 1;
         nseg = (N + seg_len - 1) / seg_len;
         const long long waves = nlines * nseg;
         const int per_xcd = (int)((waves + 7) / 8);
-        const int sv = (small_L > 0 && small_L < L) ? variant : 0, sl = (small_L > 0 && small_L < L) ? small_L : 0x7fffffff;
+        const bool both = which == 0 && small_L > 0 && small_L < L;
+        const int sv = both ? variant : -1, sl = both ? small_L : 0x7fffffff;
         AggCostIn ci;
         ci.rrec = reinterpret_cast<const uint4*>(h->cost_rrec);
         ci.lrec = reinterpret_cast<const uint4*>(h->cost_lrec);
@@ -476,10 +548,10 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         ci.lut_census = h->lut_census;
         ci.rpitch = h->rrec_pitch; ci.padl = h->rrec_padl; ci.dmin = p.dmin; ci.D = p.D;
         if (variant)
-            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true, COSTIN>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true, COSTIN, PAIR>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
                                VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
         else
-            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, false, COSTIN>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+            hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, false, COSTIN, PAIR>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
                                VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
     }
     return hipGetLastError();
@@ -489,43 +561,74 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
 hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
 {
     static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
+    static const bool pair_env = env_int("ADC_AGG_PAIR", 1) != 0;
     static bool attr_set = false;
     if (!attr_set) {
         // allow > 64 KiB dynamic LDS for the ring (large cross_L1)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipError_t e = hipSuccess;
     const int Lfull = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
     const bool lds_fits = (size_t)(2 * Lfull + 1) * 64 * sizeof(float) + (768 + 64) * sizeof(float) <= 150 * 1024;
+    const bool marching = !direct && (size_t)(2 * Lfull + 1) * 64 * sizeof(float) <= 150 * 1024;
     h->agg_first_fused = 0;
+    // armmax_host (valid when the pipeline / caller read the maximum arms back): pick the ring on the host
+    const int small_L = adc_agg_small_L(h);
+    const bool small_ok = small_L > 0 && small_L < Lfull;
+    int which_h = 0, which_v = 0; // 0 = let the kernels decide (two launches per pass)
+    if (h->armmax_valid && marching) {
+        which_h = (small_ok && h->armmax_host[0] <= small_L) ? 1 : 2;
+        which_v = (small_ok && h->armmax_host[1] <= small_L) ? 1 : 2;
+    }
+    // Pass sequence (cross_aggregator.cpp:100-118): iteration k = [first direction][second direction, divided by the
+    // support count]; the direction order alternates, so the dividing pass of iteration k and the first pass of
+    // iteration k+1 run along the SAME direction and can share one launch (PAIR) when the small ring is in use.
+    float* cur = h->vol_a; // holds the input of the next launch
+    float* oth = h->vol_b;
     bool horizontal_first = true; // cross_aggregator.cpp:100
     int launch = 0;
+    bool second_done = false; // the first pass of this iteration was already computed by the previous pair launch
     for (int k = 0; k < iterations && e == hipSuccess; k++) {
-        if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
-        if (horizontal_first) {
-            // first pass of the pipeline: the matching cost is computed inside the pass (no input volume)
-            const bool fused = k == 0 && h->fuse_cost && !direct && lds_fits;
-            if (k == 0) h->agg_first_fused = fused ? 1 : 0;
-            if (fused) e = launch_pass<false, false, true>(h, h->vol_a, h->vol_b, direct);
-            else e = launch_pass<false, false>(h, h->vol_a, h->vol_b, direct);
-            launch++;
+        const bool hf = horizontal_first;
+        if (!second_done) {
             if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
-            if (e == hipSuccess) e = launch_pass<true, true>(h, h->vol_b, h->vol_a, direct); // / sup_h
-        } else {
-            e = launch_pass<true, false>(h, h->vol_a, h->vol_b, direct);
+            if (hf) {
+                // first pass of the pipeline: the matching cost is computed inside the pass (no input volume)
+                const bool fused = k == 0 && h->fuse_cost && !direct && lds_fits;
+                if (k == 0) h->agg_first_fused = fused ? 1 : 0;
+                if (fused) e = launch_pass<false, false, true>(h, cur, oth, direct, which_h);
+                else e = launch_pass<false, false>(h, cur, oth, direct, which_h);
+            } else {
+                e = launch_pass<true, false>(h, cur, oth, direct, which_v);
+            }
+            { float* t = cur; cur = oth; oth = t; }
             launch++;
-            if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
-            if (e == hipSuccess) e = launch_pass<false, true>(h, h->vol_b, h->vol_a, direct); // / sup_v
         }
+        second_done = false;
+        if (e != hipSuccess) break;
+        if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
+        // second pass of the iteration (dividing): vertical after a horizontal first pass and vice versa
+        const bool pair = pair_env && marching && k + 1 < iterations && (hf ? which_v : which_h) == 1;
+        if (hf) {
+            if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, direct, 1);
+            else e = launch_pass<true, true>(h, cur, oth, direct, which_v); // / sup_h
+        } else {
+            if (pair) e = launch_pass<false, true, false, true>(h, cur, oth, direct, 1);
+            else e = launch_pass<false, true>(h, cur, oth, direct, which_h); // / sup_v
+        }
+        { float* t = cur; cur = oth; oth = t; }
         launch++;
+        second_done = pair;
         horizontal_first = !horizontal_first;
     }
     if (h->profiling) hipEventRecord(h->ev_agg[launch < 8 ? launch : 8], h->heavy);
     h->agg_launches = launch < 8 ? launch : 8;
+    // the result must be in vol_a (cost_aggr_): swap the two volume pointers if it ended up in the other one
+    if (cur != h->vol_a) { h->vol_b = h->vol_a; h->vol_a = cur; }
     return e;
 }

@@ -67,6 +67,14 @@ def stage_report(left, right, opt, o, device=0):
         st.debug_write(A.BUF_VOLUME_A, np.zeros_like(o["cost_init"]))
         st.debug_run(A.RUN_AGGREGATE, 104)
         rec("cost_aggr(fused cost)", st.debug_read(A.BUF_VOLUME_A), o["cost_aggr"])
+        # + ring depth chosen on the host from the maximum arms and same-direction pass pairs sharing a launch
+        st.debug_run(A.RUN_ARMS)  # (recomputes armmax; the arms themselves equal the oracle's, checked above)
+        st.debug_write(A.BUF_VOLUME_A, np.zeros_like(o["cost_init"]))
+        st.debug_run(A.RUN_AGGREGATE, 304)
+        rec("cost_aggr(fused cost + pass pairs)", st.debug_read(A.BUF_VOLUME_A), o["cost_aggr"])
+        st.debug_write(A.BUF_VOLUME_A, o["cost_init"])
+        st.debug_run(A.RUN_AGGREGATE, 204)
+        rec("cost_aggr(pass pairs)", st.debug_read(A.BUF_VOLUME_A), o["cost_aggr"])
 
         st.debug_write(A.BUF_VOLUME_A, o["cost_aggr"])
         st.debug_run(A.RUN_SCANLINE, 4)
