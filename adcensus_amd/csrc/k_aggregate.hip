@@ -562,6 +562,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
 {
     static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
     static const bool pair_env = env_int("ADC_AGG_PAIR", 1) != 0;
+    static const bool pair_full = env_int("ADC_AGG_PAIR_FULL", 0) != 0; // also with the full ring (2 x 17 KiB of LDS per wave)
     static bool attr_set = false;
     if (!attr_set) {
         // allow > 64 KiB dynamic LDS for the ring (large cross_L1)
@@ -570,6 +571,8 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipError_t e = hipSuccess;
@@ -613,12 +616,13 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
         if (e != hipSuccess) break;
         if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
         // second pass of the iteration (dividing): vertical after a horizontal first pass and vice versa
-        const bool pair = pair_env && marching && k + 1 < iterations && (hf ? which_v : which_h) == 1;
+        const int wsec = hf ? which_v : which_h;
+        const bool pair = pair_env && marching && k + 1 < iterations && (wsec == 1 || (pair_full && wsec == 2));
         if (hf) {
-            if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, direct, 1);
+            if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, direct, wsec);
             else e = launch_pass<true, true>(h, cur, oth, direct, which_v); // / sup_h
         } else {
-            if (pair) e = launch_pass<false, true, false, true>(h, cur, oth, direct, 1);
+            if (pair) e = launch_pass<false, true, false, true>(h, cur, oth, direct, wsec);
             else e = launch_pass<false, true>(h, cur, oth, direct, which_h); // / sup_v
         }
         { float* t = cur; cur = oth; oth = t; }
