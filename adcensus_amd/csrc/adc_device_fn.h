@@ -77,6 +77,26 @@ ADC_HD int adc_so_d2_column(int x, int dmin, int d, int W)
 // penalty class: 0 -> (p1,p2), 1 -> (p1/4,p2/4), 2 -> (p1/10,p2/10)  (scanline_optimizer.cpp:129-141)
 ADC_HD int adc_so_penalty_class(int d1, int d2, int tso) { return (d1 >= tso ? 1 : 0) + (d2 >= tso ? 1 : 0); }
 
+// ---- scanline penalty classes derived per lane (k_scanline.hip; CPU emulation: tests/emul/emul.cpp) ----
+// LDS byte offsets (class * 8) of the (P1,P2) pairs of this lane's VPL disparities.
+//   rb       VPL consecutive bytes of the right-image step map starting at column max(xr_last, 1) (+1 on R->L)
+//   c1byte   left-image step d1 of this pixel
+//   xr_last  x - dmin - (d0 + VPL-1): right-image column of the lane's LAST disparity (the smallest column)
+template <int VPL>
+ADC_HD void adc_so_class_offsets(uint32_t rb, int c1byte, int xr_last, int W, int tso, bool row_ok, int* off)
+{
+    const int c1 = c1byte >= tso ? 8 : 0;
+    const int a0 = xr_last > 1 ? xr_last : 1;
+    for (int k = 0; k < VPL; k++) {
+        const int xr = xr_last + (VPL - 1 - k);
+        const int j = (xr > 1 ? xr : 1) - a0; // 0 .. VPL-1: which of the fetched bytes is column max(xr, 1)
+        const int byte = (int)((rb >> (8 * j)) & 0xffu);
+        const int c2 = byte >= tso ? 8 : 0;
+        const bool use_r = row_ok && xr < W - 1;
+        off[k] = c1 + (use_r ? c2 : c1);
+    }
+}
+
 // ---- WTA sub-pixel (ADCensusStereo.cpp:227-240) ----
 ADC_HD float adc_subpixel(int best, float c1, float c2, float cmin)
 {

@@ -165,25 +165,7 @@ hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream)
     return hipGetLastError();
 }
 
-// LDS byte offsets (class * 8) of the (P1,P2) pairs of this lane's VPL disparities.
-//   rb       VPL consecutive bytes of the right-image step map starting at column max(xr_last, 1) (+1 on R->L)
-//   c1byte   left-image step d1 of this pixel
-//   xr_last  x - dmin - (d0 + VPL-1): right-image column of the lane's LAST disparity (the smallest column)
-template <int VPL>
-__device__ __forceinline__ void so_class_offsets(uint32_t rb, int c1byte, int xr_last, int W, int tso, bool row_ok, int* off)
-{
-    const int c1 = c1byte >= tso ? 8 : 0;
-    const int a0 = xr_last > 1 ? xr_last : 1;
-#pragma unroll
-    for (int k = 0; k < VPL; k++) {
-        const int xr = xr_last + (VPL - 1 - k);
-        const int j = (xr > 1 ? xr : 1) - a0; // 0 .. VPL-1: which of the fetched bytes is column max(xr, 1)
-        const int byte = (int)((rb >> (8 * j)) & 0xffu);
-        const int c2 = byte >= tso ? 8 : 0;
-        const bool use_r = row_ok && xr < W - 1;
-        off[k] = c1 + (use_r ? c2 : c1);
-    }
-}
+// (the class derivation itself, adc_so_class_offsets, lives in adc_device_fn.h: it is shared with the CPU emulation)
 
 // ------------------------------------------------------------------------------------- DP kernel
 #define SO_PF 16
@@ -344,7 +326,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     do {                                                                                                   \
         const int x_ = VERT ? g.path : mcur; /* mcur = coordinate of path element I (running counter) */   \
         int off_[VPL];                                                                                     \
-        so_class_offsets<VPL>((E).rb, (E).c1, x_ - cl_last, W, tso, W >= 3 && x_ - dmin >= 1, off_);       \
+        adc_so_class_offsets<VPL>((E).rb, (E).c1, x_ - cl_last, W, tso, W >= 3 && x_ - dmin >= 1, off_);       \
         const float up_ = upN; /* L(q, d0-1), sentinel at d=-1 */                                          \
         const float dn_ = dnN; /* L(q, d0+VPL), sentinel at d=D */                                         \
         float out_[VPL];                                                                                   \

@@ -191,6 +191,104 @@ void emul_scanline_pass(const float* src, float* dst, const uint8_t* cd_left, co
     }
 }
 
+// ------------------------------------------------------------------ k_scanline, lane structure of the penalty classes
+// Same DP, but the (P1,P2) class of every disparity is derived the way the kernel does it: lane l owns VPL consecutive
+// disparities, fetches VPL consecutive bytes of the right-image step map at column max(xr_last, 1) (+1 on R->L) and
+// maps them with adc_so_class_offsets (closed form of the sticky-d2 rule).
+} // extern "C"
+template <int VPL>
+static void scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
+                                int dmin, int D, int vert, int dir, int tso, float p1, float p2)
+{
+    const float P1c[3] = {p1, p1 / 4, p1 / 10}, P2c[3] = {p2, p2 / 4, p2 / 10};
+    const int npaths = vert ? W : H, plen = vert ? H : W, Dp = 64 * VPL;
+    std::vector<uint8_t> rmap((size_t)W * H + 64, 0); // the kernel's map has slack behind the last element
+    std::copy(cd_right, cd_right + (size_t)W * H, rmap.begin());
+    std::vector<float> Lp(Dp), out(Dp);
+    std::vector<int> cls(Dp);
+    for (int path = 0; path < npaths; path++) {
+        auto coord = [&](int i, int& x, int& y) {
+            const int m = dir > 0 ? i : plen - 1 - i;
+            if (vert) { x = path; y = m; } else { x = m; y = path; }
+        };
+        int x, y;
+        coord(0, x, y);
+        float minLp = ADC_LARGE_FLOAT;
+        for (int d = 0; d < Dp; d++) {
+            const float c = d < D ? src[((size_t)y * W + x) * D + d] : ADC_LARGE_FLOAT;
+            if (d < D) dst[((size_t)y * W + x) * D + d] = c;
+            Lp[d] = c;
+            minLp = c < minLp ? c : minLp;
+        }
+        for (int i = 1; i < plen; i++) {
+            coord(i, x, y);
+            const int sx = vert ? x : (dir > 0 ? x : x + 1);
+            const int sy = vert ? (dir > 0 ? y : y + 1) : y;
+            const int d1 = cd_left[(size_t)sy * W + sx];
+            const int shift = vert ? 0 : (dir > 0 ? 0 : 1);
+            for (int lane = 0; lane < 64; lane++) {
+                const int cl_last = lane * VPL + VPL - 1 + dmin, xr_last = x - cl_last;
+                const size_t off = (size_t)sy * W + (xr_last > 1 ? xr_last : 1) + shift;
+                uint32_t rb = 0;
+                for (int j = 0; j < VPL; j++) rb |= (uint32_t)rmap[off + j] << (8 * j);
+                int o8[VPL];
+                adc_so_class_offsets<VPL>(rb, d1, xr_last, W, tso, W >= 3 && x - dmin >= 1, o8);
+                for (int k = 0; k < VPL; k++) cls[lane * VPL + k] = o8[k] / 8;
+            }
+            float omin = ADC_LARGE_FLOAT;
+            for (int d = 0; d < Dp; d++) {
+                const float P1 = P1c[cls[d]], P2 = P2c[cls[d]];
+                const float lm1 = d > 0 ? Lp[d - 1] : ADC_LARGE_FLOAT;
+                const float lp1 = d < Dp - 1 ? Lp[d + 1] : ADC_LARGE_FLOAT;
+                const float l1 = Lp[d], l2 = lm1 + P1, l3 = lp1 + P1, l4 = minLp + P2;
+                const float m12 = l2 < l1 ? l2 : l1, m123 = l3 < m12 ? l3 : m12, mm = l4 < m123 ? l4 : m123;
+                const float cs = ((d < D ? src[((size_t)y * W + x) * D + d] : 0.0f) + mm) * 0.5f;
+                out[d] = d < D ? cs : ADC_LARGE_FLOAT; // padding lanes hold the sentinel
+                omin = out[d] < omin ? out[d] : omin;
+            }
+            for (int d = 0; d < Dp; d++) { if (d < D) dst[((size_t)y * W + x) * D + d] = out[d]; Lp[d] = out[d]; }
+            minLp = omin;
+        }
+    }
+}
+extern "C" {
+void emul_scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
+                              int dmin, int D, int vert, int dir, int tso, float p1, float p2)
+{
+    if (D <= 64) scanline_pass_lanes<1>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
+    else if (D <= 128) scanline_pass_lanes<2>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
+    else scanline_pass_lanes<4>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
+}
+
+// ------------------------------------------------------------------ k_wta_right_band
+// A "wave" owns 64 consecutive right pixels; lane l walks the columns base + dmin + t, looking at disparity index t - l,
+// with the reference's own sequential scan (strict '<', neighbours of the running minimum remembered).
+void emul_wta_right_band(const float* vol, float* disp, int W, int H, int dmin, int D)
+{
+    for (int y = 0; y < H; y++)
+        for (int base = 0; base < W; base += 64)
+            for (int lane = 0; lane < 64; lane++) {
+                const int x = base + lane;
+                float minc = ADC_LARGE_FLOAT, prev = 0.f, c1 = 0.f, c2 = 0.f;
+                int best = 0;
+                bool capture = false;
+                for (int t = 0; t < 63 + D; t++) {
+                    const int c = base + dmin + t, di = t - lane;
+                    if (di < 0 || di >= D) continue;
+                    const float cost = (c >= 0 && c < W) ? vol[((size_t)y * W + c) * D + di] : ADC_LARGE_FLOAT;
+                    if (capture) { c2 = cost; capture = false; }
+                    if (cost < minc) { minc = cost; best = di + dmin; c1 = prev; capture = true; }
+                    prev = cost;
+                }
+                if (x >= W) continue;
+                float out;
+                if (best == dmin || best == dmin + D - 1) out = (float)best;
+                else if (best - 1 - dmin < 0 || best + 1 - dmin >= D) out = (float)best;
+                else out = adc_subpixel(best, c1, c2, minc);
+                disp[(size_t)y * W + x] = out;
+            }
+}
+
 // ------------------------------------------------------------------ k_wta
 void emul_wta(const float* vol, float* disp, int W, int H, int dmin, int D, int right)
 {

@@ -67,6 +67,13 @@ def test_scanline_closed_form(emul, dumps, name):
                                 opt.so_tso, C.c_float(opt.so_p1), C.c_float(opt.so_p2))
         a, b = b, a
     assert same(a, o["cost_so"])
+    # the kernel's per-lane class derivation (bytes of the right-image step map + closed-form sticky-d2 rule)
+    a, b = o["cost_aggr"].copy(), np.empty_like(o["cost_aggr"])
+    for vert, dr in ((0, 1), (0, -1), (1, 1), (1, -1)):
+        emul.emul_scanline_pass_lanes(P(a), P(b), P(lv if vert else lh), P(rv if vert else rh), w, h, dmin, D, vert, dr,
+                                      opt.so_tso, C.c_float(opt.so_p1), C.c_float(opt.so_p2))
+        a, b = b, a
+    assert same(a, o["cost_so"])
 
 
 @pytest.mark.parametrize("name", EMUL_CASES)
@@ -79,6 +86,13 @@ def test_wta(emul, dumps, name):
     emul.emul_wta(P(o["cost_so"]), P(dr), w, h, dmin, D, 1)
     assert same(dl, o["disp_left_wta"])
     assert same(dr, o["disp_right_wta"])
+    # diagonal-band form of the right view (k_wta_right_band): per-lane sequential scan
+    db = np.empty((h, w), np.float32)
+    emul.emul_wta_right_band(P(o["cost_so"]), P(db), w, h, dmin, D)
+    mask = np.ones((h, w), bool)
+    if dmin > 0:
+        mask[:, w - dmin:] = False  # reference reads out of bounds there (documented, tests/gpu_harness.py)
+    assert same(db[mask], o["disp_right_wta"][mask])
 
 
 @pytest.mark.parametrize("name", EMUL_CASES)
