@@ -21,6 +21,8 @@ def same(a, b):
 
 EMUL_CASES = ["cone_crop_d40", "s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8", "q_40x1_d8",
               "q_3x3_d2", "s2_150x100_neg"]
+# + disparity ranges that put 2 and 4 disparities into a lane (scanline class derivation, winner-takes-all)
+LANE_CASES = EMUL_CASES + ["s2_320x180_d128", "s2_200x120_d200"]
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +55,7 @@ def test_marching_ring_aggregation(emul, dumps, name, pf, hseg, vseg):
     assert same(a, o["cost_aggr"])
 
 
-@pytest.mark.parametrize("name", EMUL_CASES)
+@pytest.mark.parametrize("name", LANE_CASES)
 def test_scanline_closed_form(emul, dumps, name):
     left, right, opt, o = dumps(name)
     h, w = left.shape[:2]
@@ -76,7 +78,7 @@ def test_scanline_closed_form(emul, dumps, name):
     assert same(a, o["cost_so"])
 
 
-@pytest.mark.parametrize("name", EMUL_CASES)
+@pytest.mark.parametrize("name", LANE_CASES)
 def test_wta(emul, dumps, name):
     left, right, opt, o = dumps(name)
     h, w = left.shape[:2]
