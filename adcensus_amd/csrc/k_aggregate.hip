@@ -526,7 +526,9 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     for (int variant = 0; variant < 2; variant++) { // 0: full ring, 1: small ring (exits unless every arm <= small_L)
         if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
         if ((which == 1 && variant == 0 && small_L > 0 && small_L < L) || (which == 2 && variant == 1)) continue;
-        const int Lv = variant ? small_L : L;
+        // the ring only has to be as deep as the longest arm of this direction when the host knows it (which == 1)
+        const int Lknown = adc_imax(1, h->armmax_host[VERT ? 1 : 0]);
+        const int Lv = variant ? ((which == 1 && h->armmax_valid) ? adc_imin(small_L, Lknown) : small_L) : L;
         // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring, the pair variant a second
         // ring and a record ring
         const size_t ring_bytes = (size_t)(2 * Lv + 1) * 64 * sizeof(float);
