@@ -86,10 +86,11 @@ void adc_destroy(adc_handle* h);
 int adc_match(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left);
 
 /* Same pipeline, device-resident buffers (already in HBM); asynchronous on the handle's
- * stream; call adc_wait() before reading d_disp_left.  "Asynchronous" = returns with the GPU work
- * queued: the call itself waits twice for short, early parts of the pipeline (the maximum arm lengths,
- * ~0.15 ms in, which select the aggregation kernels; the work-list sizes of the region voting), never for
- * the bulk of the work. */
+ * stream; call adc_wait() before reading d_disp_left.  The call returns with the tail of the pipeline
+ * (interpolation, median, download) still queued, but it does synchronise internally where the host has to
+ * decide something: once early (the maximum arm lengths, ~0.15 ms in, select the aggregation kernels) and
+ * once per batch of region-voting rounds (when do_filling is set).  To overlap several pairs on one GPU, drive
+ * several handles from several host threads (bench.py --inflight N). */
 int adc_match_device(adc_handle* h, const void* d_bgr_left, const void* d_bgr_right, void* d_disp_left);
 
 /* Host buffers, asynchronous (pinned staging inside the handle); adc_wait() completes it and
