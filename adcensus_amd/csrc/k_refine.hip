@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ l
 
 // Step 2: one wave per entry to evaluate: all 64 lanes sweep the cross region (4 region rows x 16 columns
 // per trip) into an LDS histogram, wave arg-max with lowest-bin tie-break, in-place (chaotic) update.
+// IRV_U = region rows per 16-lane group and trip, IRV_J = 16-column chunks per row and trip (wider rows loop): the
+// number of gathers in flight per lane (IRV_U*IRV_J) trades trips per vote against registers, i.e. waves per SIMD.
+template <int IRV_U, int IRV_J>
 __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ work, int n_full, float* disp,
                                                   const uint8_t* __restrict__ elig, const uchar4* __restrict__ arms,
                                                   int32_t* __restrict__ chg, int32_t* __restrict__ counters, int W, int H, int dmin,
@@ -248,31 +251,31 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
             // i.e. 20 gathers per lane in flight at once -- the vote is latency-bound (one wave, few dependent
             // round trips), so the trip count is what matters: <= 5 trips for the largest region of the default
             // arm length instead of 18
-            for (int r0 = 0; r0 < rend; r0 += 16) {
-                int yt[4], l2[4], r2[4];
+            for (int r0 = 0; r0 < rend; r0 += 4 * IRV_U) {
+                int yt[IRV_U], l2[IRV_U], r2[IRV_U];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < IRV_U; u++) {
                     const int r = r0 + 4 * u + sub;
                     const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
                     yt[u] = y - top + rbase + r;
                     l2[u] = (int)(arm2 & 255u);
                     r2[u] = r < rend ? (int)((arm2 >> 8) & 255u) : -0x10000; // no column of a row past the end is <= r2
                 }
-                for (int cb = 0;; cb += 80) { // one iteration unless an arm exceeds 39
-                    int2 st[4][5];
+                for (int cb = 0;; cb += 16 * IRV_J) { // one iteration unless a row is wider than 16*IRV_J
+                    int2 st[IRV_U][IRV_J];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < IRV_U; u++)
 #pragma unroll
-                        for (int j = 0; j < 5; j++) {
+                        for (int j = 0; j < IRV_J; j++) {
                             const int s2 = -l2[u] + sl + cb + 16 * j;
                             const int q = s2 <= r2[u] ? yt[u] * W + x + s2 : p; // clamped: loads stay unconditional
                             st[u][j] = state[q];
                         }
                     bool more = false;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < IRV_U; u++) {
 #pragma unroll
-                        for (int j = 0; j < 5; j++) {
+                        for (int j = 0; j < IRV_J; j++) {
                             const int s2 = -l2[u] + sl + cb + 16 * j;
                             const int q = yt[u] * W + x + s2;
                             const bool in = s2 <= r2[u];
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
                                 if (b >= 0 && b < D) atomicAdd(&hist[b], 1);
                             }
                         }
-                        more |= (-l2[u] + cb + 80) <= r2[u];
+                        more |= (-l2[u] + cb + 16 * IRV_J) <= r2[u];
                     }
                     if (!__any(more)) break;
                 }
@@ -332,7 +335,8 @@ hipError_t adc_run_region_voting(adc_handle* h)
     const int tiles = ((p.W + IRV_TILE - 1) / IRV_TILE) * ((p.H + IRV_TILE - 1) / IRV_TILE);
     const int Lmax = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
     const int min_region = Lmax <= 127 ? p.opt.irv_ts : -1; // u16 support counts cannot wrap for L <= 127
-    const int BATCH = 8; // rounds launched per host check (a converged pass turns the rest into no-ops)
+    static const int shape = [] { const char* e = getenv("ADC_IRV_SHAPE"); return e ? atoi(e) : 22; }();
+    const int BATCH0 = 8; // rounds launched per host check at the start of a pass (a converged pass turns the rest into no-ops)
     h->vote_rounds = 0;
     h->vote_evals = 0;
     hipError_t e = hipSuccess;
@@ -356,24 +360,35 @@ hipError_t adc_run_region_voting(adc_handle* h)
             if (n == 0) continue;
             if ((e = hipMemsetAsync(chg, 0, (size_t)tiles * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             const unsigned vote_blocks_full = (unsigned)adc_imin((n + 3) / 4, 256 * 8);
-            const unsigned vote_blocks = (unsigned)adc_imin((n + 3) / 4, 256 * 8);
             const unsigned check_blocks = (unsigned)((n + 255) / 256);
             bool done = false;
-            for (int r0 = 0; !done; r0 += BATCH) {
+            int hint = n; // dirty entries expected per round of the next batch (sizes the vote grid; any size is correct)
+            for (int r0 = 0, BATCH = BATCH0; !done; r0 += BATCH) {
+                // two batches of 8 rounds, then 16 per host check: the long tail consists of short rounds, where the host
+                // round trip (~50 us) costs more than a few no-op launches after convergence
+                BATCH = r0 < 16 ? BATCH0 : 2 * BATCH0;
                 if (r0 > 0) { // recycle the flag / count rings for this batch (the previous round's flag must stay)
-                    // BATCH divides 64 and r0 is a multiple of BATCH: the batch's ring entries are contiguous
+                    // r0 is a multiple of the batch size, which divides 64: the batch's ring entries are contiguous
                     hipMemsetAsync(h->vote_counters + IRV_FLAG(r0), 0, BATCH * sizeof(int32_t), h->stream);
                     hipMemsetAsync(h->vote_counters + IRV_NDIRTY(r0), 0, BATCH * sizeof(int32_t), h->stream);
                 }
+                const unsigned vote_blocks = (unsigned)adc_imax(64, adc_imin((hint + hint / 4 + 3) / 4, 256 * 8));
                 for (int round = r0; round < r0 + BATCH; round++) {
                     if (round > 0)
                         hipLaunchKernelGGL(k_irv_check, dim3(check_blocks), dim3(256), 0, h->stream, h->vote_list, n, chg,
                                            reinterpret_cast<const uchar4*>(h->irv_bbox), h->vote_dirty, h->vote_counters, p.W,
                                            p.H, round, h->vote_fin);
-                    hipLaunchKernelGGL(k_irv_vote, dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), 0, h->stream,
-                                       round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,
-                                       reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,
-                                       p.opt.irv_ts, p.opt.irv_th, round, h->vote_fin, reinterpret_cast<int2*>(h->irv_state));
+#define IRV_VOTE(U_, J_)                                                                                              \
+    hipLaunchKernelGGL((k_irv_vote<U_, J_>), dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), 0, h->stream, \
+                       round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,                              \
+                       reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,        \
+                       p.opt.irv_ts, p.opt.irv_th, round, h->vote_fin, reinterpret_cast<int2*>(h->irv_state))
+                    if (shape == 45) IRV_VOTE(4, 5);
+                    else if (shape == 23) IRV_VOTE(2, 3);
+                    else IRV_VOTE(2, 2); // default: 62 VGPRs -> 8 waves per SIMD.  Measured on the structured 1080p pair
+                                         // (refinement stage): 4x5 12.1 ms, 4x3 9.9, 2x3 9.0, 2x2 8.4, 1x2 8.7 -- the votes are
+                                         // latency-bound, so waves in flight beat gathers in flight per wave
+#undef IRV_VOTE
                 }
                 if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 136 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
                 if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
@@ -384,6 +399,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
                         fprintf(stderr, " %d%s", round == 0 ? n : host_cnt[IRV_NDIRTY(round)], host_cnt[IRV_FLAG(round)] ? "*" : "");
                     fprintf(stderr, "\n");
                 }
+                hint = adc_imax(1, host_cnt[IRV_NDIRTY(r0 + BATCH - 1)]);
                 for (int round = r0; round < r0 + BATCH; round++) {
                     h->vote_rounds++;
                     h->vote_evals += round == 0 ? n : host_cnt[IRV_NDIRTY(round)]; // votes evaluated (statistics)
