@@ -1,0 +1,55 @@
+"""GPU tier at BASELINE.json's FULL size (1920x1080, D=128): the whole Match against the reference CPU program
+(~20 s of host time per pair), repeatability, and the equality of the aggregation paths (plain 8 passes vs fused
+cost + pass pairs) through the stage-level debug surface.  Exercises what the small cases cannot: many segments per
+line, all 17 median bands, hundreds of voting rounds, multi-round grids."""
+import numpy as np
+import pytest
+
+from adcensus_amd import workloads
+from oracle import pyoracle
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+W, H, D = 1920, 1080, 128
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("workload", ["noise", "structured"])
+def test_full_size_match_equals_reference(hip, oracle, workload):
+    A = hip
+    left, right = (workloads.noise_pair(W, H, 12345) if workload == "noise"
+                   else workloads.structured_pair(W, H, D, seed=777))
+    opt = pyoracle.Option(max_disparity=D)
+    want, _ = oracle.match(left, right, opt)
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(W, H, cases.to_product_option(opt))
+    got = np.zeros((H, W), np.float32)
+    assert st.Match(left, right, got)
+    bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    assert bad == 0, "%s: %d of %d pixels differ from the reference" % (workload, bad, W * H)
+    again = np.zeros((H, W), np.float32)
+    assert st.Match(left, right, again) and _same(again, got)  # repeatable (no order dependence between waves)
+    st.Release()
+
+
+def test_full_size_aggregation_paths_agree(hip):
+    """plain 8-pass aggregation == fused cost + host-chosen ring + pass pairs, bit for bit, on the noise pair
+    (short arms: small ring, pairs) and on the structured pair (long arms: full ring)."""
+    A = hip
+    for left, right in (workloads.noise_pair(W, H, 12345), workloads.structured_pair(W, H, D, seed=777)):
+        st = A.ADCensusStereo(device=0)
+        assert st.Initialize(W, H, A.ADCensusOption(max_disparity=D))
+        st.debug_set_images(left, right)
+        st.debug_run(A.RUN_GRAY_CENSUS)
+        st.debug_run(A.RUN_COST)
+        st.debug_run(A.RUN_ARMS)
+        st.debug_run(A.RUN_AGGREGATE, 4)
+        plain = st.debug_read(A.BUF_VOLUME_A).copy()
+        st.debug_run(A.RUN_COST)  # (overwritten on purpose: the fused variant must not read it)
+        st.debug_run(A.RUN_AGGREGATE, 304)
+        assert _same(st.debug_read(A.BUF_VOLUME_A), plain)
+        st.Release()
