@@ -79,7 +79,28 @@ __device__ __forceinline__ float agg_run(float acc, const float* q, int cnt)
     return acc;
 }
 
-// SMALL only gives the small-ring launch its own kernel name in profiles (the code is identical).
+// Compact form for the small-ring kernels (spans of at most 2*8+1 entries): same ordered sum, a fraction of the code --
+// the fully unrolled form above is inlined four times per step of the pair kernel and made its steady-state loop
+// ~38 KB of instructions.
+__device__ __forceinline__ float agg_run_compact(float acc, const float* q, int cnt)
+{
+#pragma nounroll
+    for (; cnt >= 4; cnt -= 4, q += 256) {
+        const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192];
+        acc += t0; acc += t1; acc += t2; acc += t3;
+    }
+#pragma nounroll
+    for (; cnt > 0; cnt--, q += 64) acc += q[0];
+    return acc;
+}
+template <bool SMALL_>
+__device__ __forceinline__ float agg_sum(float acc, const float* q, int cnt)
+{
+    if constexpr (SMALL_) return agg_run_compact(acc, q, cnt);
+    else return agg_run(acc, q, cnt);
+}
+
+// SMALL: the small-ring launch (own kernel name in profiles; compact summation code).
 // COSTIN (first pass of the production pipeline, rows, non-dividing): there is no input volume -- each entry of the
 // line, i.e. the AD-Census matching cost of pixel (x, y) for this wave's 64 disparities (cost_computor.cpp:82-121), is
 // computed in registers.  Lane l owns disparity d = d_first + l and needs the right-image pixel of column x - d: as the
@@ -212,8 +233,8 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
             acc2_ = 0.0f + ring2[i2_ * 64];                                                       \
         } else {                                                                                  \
             const int k1_ = adc_imin(k_, R - i2_);                                                \
-            acc2_ = agg_run(0.0f, ring2 + i2_ * 64, k1_);                                         \
-            if (k_ > k1_) acc2_ = agg_run(acc2_, ring2, k_ - k1_);                                \
+            acc2_ = agg_sum<SMALL>(0.0f, ring2 + i2_ * 64, k1_);                                  \
+            if (k_ > k1_) acc2_ = agg_sum<SMALL>(acc2_, ring2, k_ - k1_);                         \
         }                                                                                         \
         *(dpn) = acc2_;                                                                           \
         dpn += fstep;                                                                             \
@@ -253,8 +274,8 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
             acc_ = 0.0f + ring[idx_ * 64]; /* arms 0/0: the sum is the pixel itself */            \
         } else {                                                                                  \
             const int n1_ = adc_imin(n_, R - idx_);                                               \
-            acc_ = agg_run(0.0f, ring + idx_ * 64, n1_); /* order t = -arm .. +arm */            \
-            if (n_ > n1_) acc_ = agg_run(acc_, ring, n_ - n1_); /* wrapped part of the ring */   \
+            acc_ = agg_sum<SMALL>(0.0f, ring + idx_ * 64, n1_); /* order t = -arm .. +arm */     \
+            if (n_ > n1_) acc_ = agg_sum<SMALL>(acc_, ring, n_ - n1_); /* wrapped part */         \
         }                                                                                         \
         if (DIVIDE) {                                                                             \
             const uint32_t c_ = r_ >> 16;                                                         \
