@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libadcensus_hip.so")
+LIB_PATH = os.environ.get("ADC_HIP_LIB") or os.path.join(_HERE, "lib", "libadcensus_hip.so")  # (override: A/B builds, tools/)
 
 # stage / buffer ids (include/adcensus_c_api.h)
 STAGES = ["cost", "arms", "aggregate", "scanline", "wta", "refine"]
