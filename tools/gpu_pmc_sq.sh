@@ -7,5 +7,5 @@ i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
   rm -rf "$REPO/gpurun_out/pmcsq_$i"
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$REPO/gpurun_out/pmcsq_$i" -o pmc -- python "$REPO/bench.py" --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline > "$REPO/gpurun_out/pmcsq_$i.log" 2>&1; echo "pass $i rc=$?"
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$REPO/gpurun_out/pmcsq_$i" -o pmc -- python "$REPO/bench.py" --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --workload ${WL:-noise} > "$REPO/gpurun_out/pmcsq_$i.log" 2>&1; echo "pass $i rc=$?"
 done
