@@ -53,6 +53,9 @@ __global__ __launch_bounds__(256) void k_agg_direct(const float* __restrict__ sr
 // float4-copy rate (4.8-5.4 TB/s on MI355X); the full step is bound by its dependent chain
 // (LDS write -> LDS reads -> ordered adds -> store) at 9 waves per CU.
 #define AGG_PF 8
+#ifndef ADC_K4_DIAG
+#define ADC_K4_DIAG 0 // timing experiments only (wrong results): 1 = no span sums, 2 = no division, 3 = spans capped at 4
+#endif
 
 // ordered partial sum over cnt consecutive ring entries starting at q (lane-private column, stride 64 floats)
 __device__ __forceinline__ float agg_run(float acc, const float* q, int cnt)
@@ -94,7 +97,7 @@ __device__ __forceinline__ float agg_run_compact(float acc, const float* q, int 
     return acc;
 }
 template <bool SMALL_>
-__device__ __forceinline__ float agg_sum(float acc, const float* q, int cnt)
+__device__ __forceinline__ float agg_sum(float acc, const float* q, int cnt, int /*slot*/)
 {
     if constexpr (SMALL_) return agg_run_compact(acc, q, cnt);
     else return agg_run(acc, q, cnt);
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
             acc2_ = 0.0f + ring2[i2_ * 64];                                                       \
         } else {                                                                                  \
             const int k1_ = adc_imin(k_, R - i2_);                                                \
-            acc2_ = agg_sum<SMALL>(0.0f, ring2 + i2_ * 64, k1_);                                  \
-            if (k_ > k1_) acc2_ = agg_sum<SMALL>(acc2_, ring2, k_ - k1_);                         \
+            acc2_ = agg_sum<SMALL>(0.0f, ring2 + i2_ * 64, k1_, i2_);                             \
+            if (k_ > k1_) acc2_ = agg_sum<SMALL>(acc2_, ring2, k_ - k1_, 0);                      \
         }                                                                                         \
         *(dpn) = acc2_;                                                                           \
         dpn += fstep;                                                                             \
@@ -268,16 +271,16 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         const int a_lo_ = (int)(r_ & 255u), a_hi_ = (int)((r_ >> 8) & 255u);                      \
         int idx_ = slot_m - a_lo_;                                                                \
         if (idx_ < 0) idx_ += R;                                                                  \
-        const int n_ = a_lo_ + a_hi_ + 1;                                                         \
+        const int n_ = ADC_K4_DIAG == 1 ? 1 : (ADC_K4_DIAG == 3 ? adc_imin(4, a_lo_ + a_hi_ + 1) : a_lo_ + a_hi_ + 1); \
         float acc_;                                                                               \
         if (n_ == 1) {                                                                            \
             acc_ = 0.0f + ring[idx_ * 64]; /* arms 0/0: the sum is the pixel itself */            \
         } else {                                                                                  \
             const int n1_ = adc_imin(n_, R - idx_);                                               \
-            acc_ = agg_sum<SMALL>(0.0f, ring + idx_ * 64, n1_); /* order t = -arm .. +arm */     \
-            if (n_ > n1_) acc_ = agg_sum<SMALL>(acc_, ring, n_ - n1_); /* wrapped part */         \
+            acc_ = agg_sum<SMALL>(0.0f, ring + idx_ * 64, n1_, idx_); /* order t = -arm .. +arm */ \
+            if (n_ > n1_) acc_ = agg_sum<SMALL>(acc_, ring, n_ - n1_, 0); /* wrapped part */      \
         }                                                                                         \
-        if (DIVIDE) {                                                                             \
+        if (DIVIDE && ADC_K4_DIAG != 2) {                                                         \
             const uint32_t c_ = r_ >> 16;                                                         \
             if (c_ != 1u) acc_ = acc_ / (float)c_; /* cross_aggregator.cpp:389 (x/1 == x) */     \
         }                                                                                         \
