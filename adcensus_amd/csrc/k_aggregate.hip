@@ -53,6 +53,9 @@ __global__ __launch_bounds__(256) void k_agg_direct(const float* __restrict__ sr
 // float4-copy rate (4.8-5.4 TB/s on MI355X); the full step is bound by its dependent chain
 // (LDS write -> LDS reads -> ordered adds -> store) at 9 waves per CU.
 #define AGG_PF 8
+#ifndef ADC_K4_TAILLOOP
+#define ADC_K4_TAILLOOP 0 // A/B switch: 1 = element-wise tail loop in the compact span sum
+#endif
 #ifndef ADC_K4_DIAG
 #define ADC_K4_DIAG 0 // timing experiments only (wrong results): 1 = no span sums, 2 = no division, 3 = spans capped at 4
 #endif
@@ -92,8 +95,22 @@ __device__ __forceinline__ float agg_run_compact(float acc, const float* q, int 
         const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192];
         acc += t0; acc += t1; acc += t2; acc += t3;
     }
+#if ADC_K4_TAILLOOP
 #pragma nounroll
     for (; cnt > 0; cnt--, q += 64) acc += q[0];
+#else
+    // the last 1..3 entries with all their reads in flight at once (an element-wise loop pays one LDS round trip and
+    // four scalar instructions per entry; on short-arm images almost every span ends here)
+    if (cnt == 3) {
+        const float t0 = q[0], t1 = q[64], t2 = q[128];
+        acc += t0; acc += t1; acc += t2;
+    } else if (cnt == 2) {
+        const float t0 = q[0], t1 = q[64];
+        acc += t0; acc += t1;
+    } else if (cnt == 1) {
+        acc += q[0];
+    }
+#endif
     return acc;
 }
 template <bool SMALL_>
