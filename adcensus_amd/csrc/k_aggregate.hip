@@ -88,11 +88,16 @@ __device__ __forceinline__ float agg_run(float acc, const float* q, int cnt)
 // Compact form for the small-ring kernels (spans of at most 2*8+1 entries): same ordered sum, a fraction of the code --
 // the fully unrolled form above is inlined four times per step of the pair kernel and made its steady-state loop
 // ~38 KB of instructions.
-__device__ __forceinline__ float agg_run_compact(float acc, const float* q, int cnt)
+// (V = float, or a pair of floats when a lane owns two disparities: the two sums are independent chains)
+typedef float agg_f2 __attribute__((ext_vector_type(2)));
+template <int VPL> struct AggT { typedef float V; };
+template <> struct AggT<2> { typedef agg_f2 V; };
+template <class V>
+__device__ __forceinline__ V agg_run_compact(V acc, const V* q, int cnt)
 {
 #pragma nounroll
     for (; cnt >= 4; cnt -= 4, q += 256) {
-        const float t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192];
+        const V t0 = q[0], t1 = q[64], t2 = q[128], t3 = q[192];
         acc += t0; acc += t1; acc += t2; acc += t3;
     }
 #if ADC_K4_TAILLOOP
@@ -102,10 +107,10 @@ __device__ __forceinline__ float agg_run_compact(float acc, const float* q, int 
     // the last 1..3 entries with all their reads in flight at once (an element-wise loop pays one LDS round trip and
     // four scalar instructions per entry; on short-arm images almost every span ends here)
     if (cnt == 3) {
-        const float t0 = q[0], t1 = q[64], t2 = q[128];
+        const V t0 = q[0], t1 = q[64], t2 = q[128];
         acc += t0; acc += t1; acc += t2;
     } else if (cnt == 2) {
-        const float t0 = q[0], t1 = q[64];
+        const V t0 = q[0], t1 = q[64];
         acc += t0; acc += t1;
     } else if (cnt == 1) {
         acc += q[0];
@@ -113,11 +118,14 @@ __device__ __forceinline__ float agg_run_compact(float acc, const float* q, int 
 #endif
     return acc;
 }
-template <bool SMALL_>
-__device__ __forceinline__ float agg_sum(float acc, const float* q, int cnt, int /*slot*/)
+template <bool SMALL_, class V>
+__device__ __forceinline__ V agg_sum(V acc, const V* q, int cnt, int /*slot*/)
 {
-    if constexpr (SMALL_) return agg_run_compact(acc, q, cnt);
-    else return agg_run(acc, q, cnt);
+    if constexpr (SMALL_) return agg_run_compact<V>(acc, q, cnt);
+    else {
+        static_assert(SMALL_ || sizeof(V) == sizeof(float), "the full ring is used with one disparity per lane");
+        return agg_run(acc, q, cnt);
+    }
 }
 
 // SMALL: the small-ring launch (own kernel name in profiles; compact summation code).
@@ -144,7 +152,10 @@ typedef unsigned long long agg_u64;
 // exists, output m-L of the second pass can be summed from the second ring -- same ordered sums, same division, so
 // the result is bit-identical, but the intermediate volume never travels to HBM and back (8 passes -> 5 launches).
 // Needs two rings per wave, so it is used with the small ring only (armmax <= small_L, decided on the host).
-template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN, bool PAIR>
+// VPL = disparities per lane (1, or 2 with the small ring when Dp is a multiple of 128): with two, a wave owns 512
+// contiguous bytes of every pixel of its line, all wave-uniform work of a step (records, ring slots, branches, waits) is
+// shared by twice the data and the two sums of a lane are independent chains.
+template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN, bool PAIR, int VPL = 1>
 __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
                                                   const uint32_t* __restrict__ rec, // {lo, hi, count16} per pixel, line-major
                                                   int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
@@ -153,6 +164,9 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 {
     static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
     static_assert(!PAIR || (DIVIDE && !COSTIN), "a fused pair = dividing pass + the following non-dividing pass");
+    static_assert(VPL == 1 || (VPL == 2 && SMALL && !COSTIN), "two disparities per lane: small ring, no fused cost");
+    typedef typename AggT<VPL>::V V;
+    const V vzero = (V)(0.0f);
     // small_variant >= 0 (host does not know the arms, debug path): two launches per pass, the window depth follows
     // the data.  When no arm of this direction exceeds small_L (e.g. noise-like images) the small-ring variant runs at
     // 32 waves/CU and the full-ring variant exits at once, otherwise the other way round (armmax[0] = max horizontal
@@ -165,9 +179,9 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     extern __shared__ __attribute__((aligned(16))) float ring_all[];
     const int R = 2 * L + 1;
     const int lane = threadIdx.x;
-    float* ring = ring_all + lane; // entry s at ring[s*64]; each lane only reads what it wrote
+    V* ring = reinterpret_cast<V*>(ring_all) + lane; // entry s at ring[s*64]; each lane only reads what it wrote
 
-    const int chunks = Dp >> 6;                 // 64-float chunks per pixel
+    const int chunks = Dp / (64 * VPL);         // (64*VPL)-float chunks per pixel
     const int N = VERT ? H : W;                 // length of a line
     const int nlines = (VERT ? W : H) * chunks; // independent lines
     // XCD-aware mapping: hardware places block b on XCD b % 8; give each XCD a contiguous band of lines
@@ -192,12 +206,12 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     const long long pix_step = VERT ? (long long)W : 1LL;
     const long long pix0 = VERT ? (long long)fixed : (long long)fixed * W;
     const long long fstep = pix_step * Dp;
-    const float* sp = src + pix0 * Dp + chunk * 64 + lane;
-    float* dp = dst + pix0 * Dp + chunk * 64 + lane;
+    const float* sp = src + pix0 * Dp + chunk * (64 * VPL) + lane * VPL;
+    float* dp = dst + pix0 * Dp + chunk * (64 * VPL) + lane * VPL;
     const uint32_t* rp = rec + (long long)fixed * N; // records of this line, contiguous along m
 
     // ---- fused cost state (COSTIN)
-    float* lutA = ring_all + R * 64; // A[766] then C[64] behind the ring
+    float* lutA = ring_all + R * 64; // A[766] then C[64] behind the ring (COSTIN: VPL == 1)
     float* lutC = lutA + 768;
     uint32_t wB = 0, wC0 = 0, wC1 = 0;          // this lane's right-image pixel {bgrx, census} for the current entry
     const uint4* rrow = nullptr;                 // rrow[x] = right record of column x - d_first (lane 0's column)
@@ -235,8 +249,8 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     int slot_m = m0 - lo;    // ring slot of entry m0 (<= L < R)
     float* dpn = dp + (long long)s0 * fstep; // outputs leave in increasing order, starting at s0
     // ---- second stage (PAIR): ring of first-pass outputs + their records, behind the first ring
-    float* ring2 = ring_all + R * 64 + lane;
-    uint32_t* recring = reinterpret_cast<uint32_t*>(ring_all + 2 * R * 64);
+    V* ring2 = reinterpret_cast<V*>(ring_all) + R * 64 + lane;
+    uint32_t* recring = reinterpret_cast<uint32_t*>(reinterpret_cast<V*>(ring_all) + 2 * R * 64);
     int slot2_w = 0;           // slot of the next first-pass output to be written
     int slot2_s = s0 - m0;     // slot of first-pass output s0 (the next second-pass output)
     int mcur = m0;             // index of the next first-pass output
@@ -248,15 +262,15 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         int i2_ = slot2_s - b_lo_;                                                                \
         if (i2_ < 0) i2_ += R;                                                                    \
         const int k_ = b_lo_ + b_hi_ + 1;                                                         \
-        float acc2_;                                                                              \
+        V acc2_;                                                                                  \
         if (k_ == 1) {                                                                            \
-            acc2_ = 0.0f + ring2[i2_ * 64];                                                       \
+            acc2_ = vzero + ring2[i2_ * 64];                                                      \
         } else {                                                                                  \
             const int k1_ = adc_imin(k_, R - i2_);                                                \
-            acc2_ = agg_sum<SMALL>(0.0f, ring2 + i2_ * 64, k1_, i2_);                             \
-            if (k_ > k1_) acc2_ = agg_sum<SMALL>(acc2_, ring2, k_ - k1_, 0);                      \
+            acc2_ = agg_sum<SMALL, V>(vzero, ring2 + i2_ * 64, k1_, i2_);                         \
+            if (k_ > k1_) acc2_ = agg_sum<SMALL, V>(acc2_, ring2, k_ - k1_, 0);                   \
         }                                                                                         \
-        *(dpn) = acc2_;                                                                           \
+        *reinterpret_cast<V*>(dpn) = acc2_;                                                       \
         dpn += fstep;                                                                             \
         slot2_s = slot2_s + 1 == R ? 0 : slot2_s + 1;                                             \
     } while (0)
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
             mcur++;                                                                               \
             if (s_ >= s0 && s_ < s1) AGG_EMIT2();                                                 \
         } else {                                                                                  \
-            *(dpn) = (ACC);                                                                       \
+            *reinterpret_cast<V*>(dpn) = (ACC);                                                   \
             dpn += fstep;                                                                         \
         }                                                                                         \
     } while (0)
@@ -289,13 +303,13 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         int idx_ = slot_m - a_lo_;                                                                \
         if (idx_ < 0) idx_ += R;                                                                  \
         const int n_ = ADC_K4_DIAG == 1 ? 1 : (ADC_K4_DIAG == 3 ? adc_imin(4, a_lo_ + a_hi_ + 1) : a_lo_ + a_hi_ + 1); \
-        float acc_;                                                                               \
+        V acc_;                                                                                   \
         if (n_ == 1) {                                                                            \
-            acc_ = 0.0f + ring[idx_ * 64]; /* arms 0/0: the sum is the pixel itself */            \
+            acc_ = vzero + ring[idx_ * 64]; /* arms 0/0: the sum is the pixel itself */           \
         } else {                                                                                  \
             const int n1_ = adc_imin(n_, R - idx_);                                               \
-            acc_ = agg_sum<SMALL>(0.0f, ring + idx_ * 64, n1_, idx_); /* order t = -arm .. +arm */ \
-            if (n_ > n1_) acc_ = agg_sum<SMALL>(acc_, ring, n_ - n1_, 0); /* wrapped part */      \
+            acc_ = agg_sum<SMALL, V>(vzero, ring + idx_ * 64, n1_, idx_); /* t = -arm .. +arm */   \
+            if (n_ > n1_) acc_ = agg_sum<SMALL, V>(acc_, ring, n_ - n1_, 0); /* wrapped part */   \
         }                                                                                         \
         if (DIVIDE && ADC_K4_DIAG != 2) {                                                         \
             const uint32_t c_ = r_ >> 16;                                                         \
@@ -317,9 +331,9 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         }
     } else {
     for (int j = lo; j < jB; j += AGG_PF) {
-        float t[AGG_PF];
+        V t[AGG_PF];
 #pragma unroll
-        for (int u = 0; u < AGG_PF; u++) t[u] = sp[(long long)adc_imin(j + u, jB - 1) * fstep];
+        for (int u = 0; u < AGG_PF; u++) t[u] = *reinterpret_cast<const V*>(sp + (long long)adc_imin(j + u, jB - 1) * fstep);
 #pragma unroll
         for (int u = 0; u < AGG_PF; u++)
             if (j + u < jB) AGG_PUSH(t[u]);
@@ -426,15 +440,21 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 #undef AGG_STEPC
         }
     } else {
-    float pf[AGG_PF];
+    V pf[AGG_PF];
     uint32_t pr[AGG_PF];
+// data load of one entry (VPL floats per lane) into a prefetch slot
+#define AGG_LDV(DST, PTR)                                                                                         \
+    do {                                                                                                          \
+        if constexpr (VPL == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory");  \
+        else asm volatile("global_load_dword %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory");                     \
+    } while (0)
     // The asm-prefetch loop needs every refill index valid without clamping: j + 2*AGG_PF <= hi.
     if (j + 2 * AGG_PF <= hi) {
         const float* spn = sp + (long long)j * fstep;       // next entry to prefetch
         const uint32_t* rpn = rp + (j - L);                 // record of the output that entry triggers (>= m0)
 #pragma unroll
         for (int u = 0; u < AGG_PF; u++) {
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pf[u]) : "v"(spn) : "memory");
+            AGG_LDV(pf[u], spn);
             asm volatile("global_load_dword %0, %1, off" : "=v"(pr[u]) : "v"(rpn) : "memory");
             spn += fstep;
             rpn += 1;
@@ -442,13 +462,17 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 // one steady-state step; WAITN = number of VMEM ops younger than slot U's two loads that may stay in flight
 #define AGG_STEP(U, WAITN)                                                                                       \
     do {                                                                                                         \
-        float v_;                                                                                                \
+        V v_;                                                                                                    \
         uint32_t rr_;                                                                                            \
         /* wait and read the landed registers in ONE statement: a separate "+v" wait lets hipcc copy the      */ \
         /* (not yet landed) registers ABOVE the wait (tied-operand copies), i.e. read garbage                 */ \
-        asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                              \
-                     : "=&v"(v_), "=&v"(rr_) : "v"(pf[U]), "v"(pr[U]), "n"(WAITN) : "memory");                   \
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pf[U]) : "v"(spn) : "memory");                       \
+        if constexpr (VPL == 2)                                                                                  \
+            asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b32 %1, %3"                          \
+                         : "=&v"(v_), "=&v"(rr_) : "v"(pf[U]), "v"(pr[U]), "n"(WAITN) : "memory");               \
+        else                                                                                                     \
+            asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                          \
+                         : "=&v"(v_), "=&v"(rr_) : "v"(pf[U]), "v"(pr[U]), "n"(WAITN) : "memory");               \
+        AGG_LDV(pf[U], spn);                                                                                     \
         asm volatile("global_load_dword %0, %1, off" : "=v"(pr[U]) : "v"(rpn) : "memory");                       \
         spn += fstep;                                                                                            \
         rpn += 1;                                                                                                \
@@ -472,18 +496,22 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         // the AGG_PF entries still in flight are entries j .. j+AGG_PF-1 (all < hi)
         // drain: the AGG_PF entries still in flight are entries j .. j+AGG_PF-1 (all < hi); read them inside the
         // same statement as the wait (see AGG_STEP)
-        float df[AGG_PF];
+        V df[AGG_PF];
         uint32_t dr[AGG_PF];
-        asm volatile("s_waitcnt vmcnt(0)\n\t"
-                     "v_mov_b32 %0, %16\n\tv_mov_b32 %1, %17\n\tv_mov_b32 %2, %18\n\tv_mov_b32 %3, %19\n\t"
-                     "v_mov_b32 %4, %20\n\tv_mov_b32 %5, %21\n\tv_mov_b32 %6, %22\n\tv_mov_b32 %7, %23\n\t"
-                     "v_mov_b32 %8, %24\n\tv_mov_b32 %9, %25\n\tv_mov_b32 %10, %26\n\tv_mov_b32 %11, %27\n\t"
-                     "v_mov_b32 %12, %28\n\tv_mov_b32 %13, %29\n\tv_mov_b32 %14, %30\n\tv_mov_b32 %15, %31"
-                     : "=&v"(df[0]), "=&v"(df[1]), "=&v"(df[2]), "=&v"(df[3]), "=&v"(df[4]), "=&v"(df[5]), "=&v"(df[6]), "=&v"(df[7]),
-                       "=&v"(dr[0]), "=&v"(dr[1]), "=&v"(dr[2]), "=&v"(dr[3]), "=&v"(dr[4]), "=&v"(dr[5]), "=&v"(dr[6]), "=&v"(dr[7])
-                     : "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]), "v"(pf[7]),
-                       "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(pr[4]), "v"(pr[5]), "v"(pr[6]), "v"(pr[7])
-                     : "memory");
+#define AGG_DRAIN(MOVD)                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)\n\t"                                                                                   \
+                     MOVD " %0, %16\n\t" MOVD " %1, %17\n\t" MOVD " %2, %18\n\t" MOVD " %3, %19\n\t"                            \
+                     MOVD " %4, %20\n\t" MOVD " %5, %21\n\t" MOVD " %6, %22\n\t" MOVD " %7, %23\n\t"                            \
+                     "v_mov_b32 %8, %24\n\tv_mov_b32 %9, %25\n\tv_mov_b32 %10, %26\n\tv_mov_b32 %11, %27\n\t"                   \
+                     "v_mov_b32 %12, %28\n\tv_mov_b32 %13, %29\n\tv_mov_b32 %14, %30\n\tv_mov_b32 %15, %31"                      \
+                     : "=&v"(df[0]), "=&v"(df[1]), "=&v"(df[2]), "=&v"(df[3]), "=&v"(df[4]), "=&v"(df[5]), "=&v"(df[6]), "=&v"(df[7]), \
+                       "=&v"(dr[0]), "=&v"(dr[1]), "=&v"(dr[2]), "=&v"(dr[3]), "=&v"(dr[4]), "=&v"(dr[5]), "=&v"(dr[6]), "=&v"(dr[7])  \
+                     : "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(pf[4]), "v"(pf[5]), "v"(pf[6]), "v"(pf[7]),         \
+                       "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(pr[4]), "v"(pr[5]), "v"(pr[6]), "v"(pr[7])          \
+                     : "memory")
+        if constexpr (VPL == 2) AGG_DRAIN("v_mov_b64");
+        else AGG_DRAIN("v_mov_b32");
+#undef AGG_DRAIN
 #pragma unroll
         for (int u = 0; u < AGG_PF; u++) {
             AGG_PUSH(df[u]);
@@ -494,12 +522,12 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     }
     // ---- tail of phase B (< 2*AGG_PF entries): plain compiler-scheduled loads
     for (; j < hi; j++) {
-        float v;
+        V v;
         if constexpr (COSTIN) {
             const uint4 rn = rrow[j], ln = lrow[j];
             AGG_COST(rn.x, rn.y, rn.z, ln.x, ln.y, ln.z, v);
         } else {
-            v = sp[(long long)j * fstep];
+            v = *reinterpret_cast<const V*>(sp + (long long)j * fstep);
         }
         AGG_PUSH(v);
         const int m = j - L;
@@ -511,6 +539,7 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
     if constexpr (PAIR) {
         for (int s = adc_imax(s0, mcur - L); s < s1; s++) AGG_EMIT2();
     }
+#undef AGG_LDV
 #undef AGG_EMIT2
 #undef AGG_OUT
 #undef AGG_PUSH
@@ -562,8 +591,9 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         return hipGetLastError();
     }
     const int N = VERT ? p.H : p.W;
-    const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / 64);
     const int small_L = adc_agg_small_L(h);
+    // two disparities per lane with the small ring (ADC_AGG_VPL2=0 switches it off)
+    static const bool vpl2_env = env_int("ADC_AGG_VPL2", 1) != 0;
     for (int variant = 0; variant < 2; variant++) { // 0: full ring, 1: small ring (exits unless every arm <= small_L)
         if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
         if ((which == 1 && variant == 0 && small_L > 0 && small_L < L) || (which == 2 && variant == 1)) continue;
@@ -572,7 +602,9 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const int Lv = variant ? ((which == 1 && h->armmax_valid) ? adc_imin(small_L, Lknown) : small_L) : L;
         // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring, the pair variant a second
         // ring and a record ring
-        const size_t ring_bytes = (size_t)(2 * Lv + 1) * 64 * sizeof(float);
+        const int vpl = (variant == 1 && !COSTIN && vpl2_env && p.Dp % 128 == 0) ? 2 : 1;
+        const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
+        const size_t ring_bytes = (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
         const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + (PAIR ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
         const int waves_per_cu = adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
         int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
@@ -590,7 +622,11 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         ci.lut_ad = h->lut_ad;
         ci.lut_census = h->lut_census;
         ci.rpitch = h->rrec_pitch; ci.padl = h->rrec_padl; ci.dmin = p.dmin; ci.D = p.D;
-        if (variant)
+        if (variant && vpl == 2) {
+            if constexpr (!COSTIN)
+                hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true, false, PAIR, 2>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+                                   VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
+        } else if (variant)
             hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true, COSTIN, PAIR>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
                                VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
         else
