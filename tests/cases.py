@@ -56,12 +56,15 @@ _CASES = {
     "q_40x1_d8": (lambda: workloads.quantized_noise_pair(40, 1, 8, seed=19), dict(max_disparity=8)),
     "q_3x3_d2": (lambda: workloads.quantized_noise_pair(3, 3, 2, seed=20), dict(max_disparity=2)),
     "noise_128x72_d64": (lambda: workloads.noise_pair(128, 72, seed=21), dict(max_disparity=64)),
+    # short arms + D a multiple of 128: small aggregation ring with two disparities per lane, pass pairs (1 and 2 chunks)
+    "noise_160x90_d128": (lambda: workloads.noise_pair(160, 90, seed=23), dict(max_disparity=128)),
+    "noise_150x40_d256": (lambda: workloads.noise_pair(150, 40, seed=24), dict(max_disparity=256)),
     "s2_150x100_neg": (lambda: workloads.structured_pair(150, 100, 48, seed=22), dict(min_disparity=-8, max_disparity=40)),
 }
 GOLDEN_CASES = list(_CASES.keys())
 # subset that the CPU-only tier recomputes with the port (kept small: the whole CPU suite must run in minutes)
 FAST_CASES = ["cone_crop_d40", "s2_96x64_d32", "q_257x131_d64", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8",
-              "q_40x1_d8", "q_3x3_d2", "noise_128x72_d64", "s2_150x100_neg", "s2_200x120_d200"]
+              "q_40x1_d8", "q_3x3_d2", "noise_128x72_d64", "s2_150x100_neg", "s2_200x120_d200", "noise_160x90_d128"]
 
 
 def make_case(name):
