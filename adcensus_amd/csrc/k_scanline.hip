@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     const int npaths = VERT ? W : H;
     SoGeom g;
     g.W = W; g.H = H; g.dir = dir; g.lane = lane;
-    g.path = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+    g.path = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (int)(blockDim.x >> 6) + wave);
     if (g.path >= npaths) return;
     g.plen = VERT ? H : W;
     g.d0 = lane * VPL; // first disparity index of this lane
@@ -543,13 +543,20 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
 {
     const AdcParams& p = h->p;
     const int npaths = vert ? p.W : p.H;
-    const unsigned blocks = (unsigned)((npaths + 3) / 4);
+    // Waves per workgroup (ADC_SO_WPB_ROW / ADC_SO_WPB_COL: 1, 2 or 4).  A 1080p row pass has 1080 paths for 1024 SIMDs:
+    // with 4-wave workgroups 14 CUs end up with eight waves and set the kernel time (two waves per SIMD take ~660
+    // instead of ~520 cycles per step; 1024 rows: 0.42 ms, 1028 rows: 0.61 ms); single-wave workgroups spread the 56
+    // extra waves over 56 CUs (scanline stage 2.15 -> 1.97 ms).  Column passes (1920 paths) measured best with 4.
+    static const int wpb_row = [] { const char* e = getenv("ADC_SO_WPB_ROW"); const int v = e ? atoi(e) : 1; return v == 1 || v == 2 ? v : 4; }();
+    static const int wpb_col = [] { const char* e = getenv("ADC_SO_WPB_COL"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
+    const int wpb = vert ? wpb_col : wpb_row;
+    const unsigned blocks = (unsigned)((npaths + wpb - 1) / wpb);
     const int pass = (vert ? 2 : 0) + (dir > 0 ? 0 : 1);
     const SoC1Layout L = so_c1_layout(p.W, p.H);
     const uint32_t* c1w = reinterpret_cast<const uint32_t*>(h->so_cls) + L.off[pass];
     const uint8_t* rmap = vert ? h->cdiff_rv : h->cdiff_rh;
 #define SO_LAUNCH(VERT_, DPP_, WTA_)                                                                                   \
-    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(256), 0, h->heavy, src, dst, c1w,      \
+    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, \
                        L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1],         \
                        h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2], disp)
     const bool dpp = so_use_dpp();
