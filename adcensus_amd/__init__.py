@@ -98,6 +98,8 @@ def lib():
     L.adc_memcpy_h2d.restype = C.c_int
     L.adc_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
     L.adc_memcpy_d2h.restype = C.c_int
+    L.adc_device_copy_ms.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.adc_device_copy_ms.restype = C.c_double
     L.adc_debug_read.argtypes = [vp, C.c_int, vp]
     L.adc_debug_read.restype = C.c_int
     L.adc_debug_write.argtypes = [vp, C.c_int, vp]

@@ -455,6 +455,24 @@ void* adc_get_stream(adc_handle* h) { return h ? (void*)h->stream : nullptr; }
 int adc_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : 1; }
 void* adc_device_malloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
 void adc_device_free(void* p) { if (p) hipFree(p); }
+double adc_device_copy_ms(void* dst, const void* src, size_t bytes, int reps)
+{
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+    double best = -1.0;
+    for (int r = 0; r < (reps < 1 ? 1 : reps) + 1; r++) { // first copy = warm-up
+        hipEventRecord(e0, 0);
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, 0) != hipSuccess) { best = -1.0; break; }
+        hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) { best = -1.0; break; }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0 && (best < 0 || ms < best)) best = ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return best;
+}
 int adc_memcpy_h2d(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1; }
 int adc_memcpy_d2h(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1; }
 

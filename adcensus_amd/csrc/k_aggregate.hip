@@ -593,7 +593,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     const int N = VERT ? p.H : p.W;
     const int small_L = adc_agg_small_L(h);
     // two disparities per lane with the small ring (ADC_AGG_VPL2=0 switches it off)
-    static const bool vpl2_env = env_int("ADC_AGG_VPL2", 1) != 0;
+    static const int vpl2_env = env_int("ADC_AGG_VPL2", 1); // 1 = every small-ring launch, 2 = pass pairs only
     for (int variant = 0; variant < 2; variant++) { // 0: full ring, 1: small ring (exits unless every arm <= small_L)
         if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
         if ((which == 1 && variant == 0 && small_L > 0 && small_L < L) || (which == 2 && variant == 1)) continue;
@@ -602,7 +602,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const int Lv = variant ? ((which == 1 && h->armmax_valid) ? adc_imin(small_L, Lknown) : small_L) : L;
         // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring, the pair variant a second
         // ring and a record ring
-        const int vpl = (variant == 1 && !COSTIN && vpl2_env && p.Dp % 128 == 0) ? 2 : 1;
+        const int vpl = (variant == 1 && !COSTIN && (vpl2_env == 1 || (vpl2_env == 2 && PAIR)) && p.Dp % 128 == 0) ? 2 : 1;
         const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
         const size_t ring_bytes = (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
         const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + (PAIR ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);

@@ -543,6 +543,10 @@ __device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_di
 // targets, with ~4.5 steps per ray).  Offsets of steps 1..4 live in registers, the next list entries are
 // prefetched, 4 steps' disparities are fetched per round trip (loads past the hit are clamped to the pixel itself
 // and ignored), the colour of the hit is fetched once at the end.
+#ifndef ADC_INTERP_MASKED
+#define ADC_INTERP_MASKED 0
+#endif
+template <int NS>
 __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
                                                          const float* __restrict__ din, float* __restrict__ dout,
                                                          const uint32_t* __restrict__ bgr, const int32_t* __restrict__ tab,
@@ -555,9 +559,9 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
     const int nslot = (gridDim.x * 256) >> 4;
     const bool mismatch = which == ADC_LABEL_MISMATCH;
     const int nr = (n + 3) & ~3; // whole waves iterate together (4 pixels per wave)
-    int t0[4];
+    int t0[NS];
 #pragma unroll
-    for (int j = 0; j < 4; j++) t0[j] = tab[(1 + j < max_search ? 1 + j : (max_search > 1 ? max_search - 1 : 0)) * 16 + s];
+    for (int j = 0; j < NS; j++) t0[j] = tab[(1 + j < max_search ? 1 + j : (max_search > 1 ? max_search - 1 : 0)) * 16 + s];
     int pn = slot < n ? list[slot] : 0;
     for (int e = slot; e < nr; e += nslot) {
         const bool live = e < n;
@@ -567,36 +571,40 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
         float hit = ADC_INVALID_FLOAT; // first valid disparity along this ray
         int hitq = p;
         bool walking = live;
-        int q[4];
-        bool in[4];
-        float d[4];
+        int q[NS];
+        bool in[NS];
+        float d[NS];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NS; j++) {
             const int yy = y + (t0[j] >> 16), xx = x + (int)(short)(t0[j] & 0xffff);
             in[j] = (1 + j < max_search) && yy >= 0 && yy < H && xx >= 0 && xx < W;
             q[j] = in[j] ? yy * W + xx : p;
             d[j] = din[q[j]];
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NS; j++) {
             if (walking) {
                 if (!in[j]) walking = false; // left the image (or the search range): the ray ends without a hit
                 else if (d[j] != ADC_INVALID_FLOAT) { hit = d[j]; hitq = q[j]; walking = false; }
             }
         }
-        for (int m0 = 5; m0 < max_search && __any(walking); m0 += 4) {
+        for (int m0 = NS + 1; m0 < max_search && __any(walking); m0 += NS) {
             const int pw = walking ? p : -1;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < NS; j++) {
                 const int m = m0 + j < max_search ? m0 + j : max_search - 1; // table has max_search rows (row 0 unused)
                 const int o = tab[m * 16 + s];
                 const int yy = y + (o >> 16), xx = x + (int)(short)(o & 0xffff);
                 in[j] = (m0 + j < max_search) && yy >= 0 && yy < H && xx >= 0 && xx < W;
                 q[j] = (in[j] && pw >= 0) ? yy * W + xx : p; // finished rays re-read their own pixel (one line)
+#if ADC_INTERP_MASKED
+                d[j] = pw >= 0 ? din[q[j]] : ADC_INVALID_FLOAT; // (A/B: finished rays issue no gather at all)
+#else
                 d[j] = din[q[j]];
+#endif
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < NS; j++) {
                 if (walking) {
                     if (!in[j]) walking = false;
                     else if (d[j] != ADC_INVALID_FLOAT) { hit = d[j]; hitq = q[j]; walking = false; }
@@ -650,8 +658,15 @@ hipError_t adc_launch_interpolation(adc_handle* h)
             if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
             if (h->ray_tab && max_search == h->ray_tab_rows) {
                 if (k == 0) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
-                hipLaunchKernelGGL(k_interpolate_tab, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
-                                   h->disp_tmp, h->bgrx_l, h->ray_tab, p.W, p.H, which, max_search);
+                static const int ns = [] { const char* e = getenv("ADC_INTERP_NS"); return e ? atoi(e) : 4; }(); // ray steps per trip
+#define INTERP_TAB(NS_)                                                                                                \
+    hipLaunchKernelGGL(k_interpolate_tab<NS_>, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters,    \
+                       h->disp_l, h->disp_tmp, h->bgrx_l, h->ray_tab, p.W, p.H, which, max_search)
+                if (ns == 8) INTERP_TAB(8);
+                else if (ns == 16) INTERP_TAB(16);
+                else if (ns == 2) INTERP_TAB(2);
+                else INTERP_TAB(4);
+#undef INTERP_TAB
             }
             else
                 hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,

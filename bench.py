@@ -147,6 +147,21 @@ def main():
         if prof:
             for k in prof[0][0]:
                 stage[k] = round(float(np.mean([p[0][k] for p in prof])), 4)
+        # practical ceiling next to the 8 TB/s peak: a plain device-to-device copy of one volume (read V + write V),
+        # measured after the timed region on two scratch buffers
+        copy_gbps = None
+        try:
+            nb = int(V)
+            ca, cb = lib.adc_device_malloc(nb), lib.adc_device_malloc(nb)
+            if ca and cb:
+                ms = lib.adc_device_copy_ms(cb, ca, nb, 5)
+                if ms > 0:
+                    copy_gbps = round(2.0 * nb / (ms * 1e-3) / 1e9, 1)
+            for q in (ca, cb):
+                if q:
+                    lib.adc_device_free(q)
+        except Exception:
+            copy_gbps = None
         out = {
             "metric": "stereo pairs/s at 1920x1080 D=128 (ADCensusStereo::Match)" if (W, H, D) == (1920, 1080, 128)
                       else "stereo pairs/s at %dx%d D=%d (ADCensusStereo::Match)" % (W, H, D),
@@ -160,7 +175,9 @@ def main():
             "roofline": {"kernel": "k_agg_march (one aggregation launch: %s)" % ("pass pair, 2 passes of work" if npass in (4, 5) else "one pass"), "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(a.workload, (W, H, D)),
-                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(agg_ms, 5)},
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(agg_ms, 5),
+                         "device_copy_GBps": copy_gbps,
+                         "frac_of_device_copy": round(achieved / copy_gbps, 4) if copy_gbps else None},
         }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pairs[0], D, a.cpu_rows, H)

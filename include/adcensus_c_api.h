@@ -126,6 +126,10 @@ void* adc_device_malloc(size_t bytes);
 void  adc_device_free(void* p);
 int   adc_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int   adc_memcpy_d2h(void* dst, const void* src, size_t bytes);
+/* Measured device-to-device copy time of `bytes` bytes (hipMemcpyAsync on the null stream, best of `reps`), in ms;
+ * negative on error.  bench.py reports 2*bytes/time next to the 8 TB/s peak: the practical HBM ceiling of this device
+ * for a pass that reads one volume and writes another. */
+double adc_device_copy_ms(void* dst, const void* src, size_t bytes, int reps);
 
 /* -------------------------------------------------------------------------------------------
  * Test-only debug surface (parity tests drive single stages with oracle-provided inputs).
