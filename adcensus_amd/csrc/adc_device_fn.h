@@ -97,6 +97,26 @@ ADC_HD void adc_so_class_offsets(uint32_t rb, int c1byte, int xr_last, int W, in
     }
 }
 
+// Interior form: when every lane of the wave has xr_last >= 1 and no right-image column reaches W-1, the general
+// rule above reduces to "byte j = VPL-1-k, always use the right image":
+//   x >= dmin + Dpad (Dpad = the disparity range rounded up to VPL)  =>  xr_last >= 1 for every lane that owns a real
+//                      disparity, hence a0 = xr_last, j = VPL-1-k, and row_ok holds (x - dmin >= Dpad >= 1, W >= 3);
+//   x - dmin < W - 1   =>  xr = x - d <= x - dmin < W - 1 for every real disparity, hence use_r.
+// (Lanes that own padding disparities only may differ from the general rule; their results are never used.)
+ADC_HD bool adc_so_interior(int x, int W, int dmin, int Dpad)
+{
+    return W >= 3 && x >= dmin + Dpad && x - dmin < W - 1;
+}
+template <int VPL>
+ADC_HD void adc_so_class_offsets_interior(uint32_t rb, int c1byte, int tso, int* off)
+{
+    const int c1 = c1byte >= tso ? 8 : 0; // wave-uniform
+    for (int k = 0; k < VPL; k++) {
+        const int byte = (int)((rb >> (8 * (VPL - 1 - k))) & 0xffu);
+        off[k] = byte >= tso ? c1 + 8 : c1;
+    }
+}
+
 // ---- WTA sub-pixel (ADCensusStereo.cpp:227-240) ----
 ADC_HD float adc_subpixel(int best, float c1, float c2, float cmin)
 {

@@ -223,6 +223,9 @@ __device__ __forceinline__ uint32_t so_rmap_load(const uint8_t* __restrict__ rma
 // final costs while they are still in registers and written to `disp`: the path minimum the recurrence needs anyway IS
 // the winning cost, the winner is the lowest set bit of a ballot, its two neighbours come with two readlanes -- the
 // separate pass that re-reads the whole volume disappears.
+#ifndef SO_INTERIOR
+#define SO_INTERIOR 1 // A/B switch: 0 = always the general class rule
+#endif
 template <int VPL, bool VERT, bool DPP, bool WTA>
 __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src, float* __restrict__ dst,
                                                   const uint32_t* __restrict__ c1w, int ngr,
@@ -321,12 +324,16 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     if (g.plen <= 1) return;
 
     int mcur = dir > 0 ? 1 : g.plen - 2; // coordinate of path element 1, advanced by every SO_STEP
+    const int dpad = (D + VPL - 1) / VPL * VPL;
 // one DP step for path element I with inputs E (a macro keeps every array in registers)
 #define SO_STEP(I, E)                                                                                      \
     do {                                                                                                   \
         const int x_ = VERT ? g.path : mcur; /* mcur = coordinate of path element I (running counter) */   \
         int off_[VPL];                                                                                     \
-        adc_so_class_offsets<VPL>((E).rb, (E).c1, x_ - cl_last, W, tso, W >= 3 && x_ - dmin >= 1, off_);       \
+        if (SO_INTERIOR && adc_so_interior(x_, W, dmin, dpad)) /* wave-uniform: 2 instead of ~10 VALU per class */ \
+            adc_so_class_offsets_interior<VPL>((E).rb, (E).c1, tso, off_);                                 \
+        else                                                                                               \
+            adc_so_class_offsets<VPL>((E).rb, (E).c1, x_ - cl_last, W, tso, W >= 3 && x_ - dmin >= 1, off_);   \
         const float up_ = upN; /* L(q, d0-1), sentinel at d=-1 */                                          \
         const float dn_ = dnN; /* L(q, d0+VPL), sentinel at d=D */                                         \
         float out_[VPL];                                                                                   \

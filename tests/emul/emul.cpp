@@ -232,7 +232,10 @@ static void scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_
                 uint32_t rb = 0;
                 for (int j = 0; j < VPL; j++) rb |= (uint32_t)rmap[off + j] << (8 * j);
                 int o8[VPL];
-                adc_so_class_offsets<VPL>(rb, d1, xr_last, W, tso, W >= 3 && x - dmin >= 1, o8);
+                // the kernel takes the interior form whenever the wave-uniform test allows it
+                const int Dpad = (D + VPL - 1) / VPL * VPL;
+                if (adc_so_interior(x, W, dmin, Dpad)) adc_so_class_offsets_interior<VPL>(rb, d1, tso, o8);
+                else adc_so_class_offsets<VPL>(rb, d1, xr_last, W, tso, W >= 3 && x - dmin >= 1, o8);
                 for (int k = 0; k < VPL; k++) cls[lane * VPL + k] = o8[k] / 8;
             }
             float omin = ADC_LARGE_FLOAT;
