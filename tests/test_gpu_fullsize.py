@@ -36,6 +36,23 @@ def test_full_size_match_equals_reference(hip, oracle, workload):
     st.Release()
 
 
+@pytest.mark.parametrize("workload", ["noise", "structured"])
+def test_kitti_size_match_equals_reference(hip, oracle, workload):
+    """BASELINE.json configs[2]: KITTI-size 1242x375, D=128 (odd width, 375 rows = 5.9 median bands, 375 scanline rows)."""
+    A = hip
+    w, h, d = 1242, 375, 128
+    left, right = (workloads.noise_pair(w, h, 4242) if workload == "noise" else workloads.structured_pair(w, h, d, seed=4243))
+    opt = pyoracle.Option(max_disparity=d)
+    want, _ = oracle.match(left, right, opt)
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(w, h, cases.to_product_option(opt))
+    got = np.zeros((h, w), np.float32)
+    assert st.Match(left, right, got)
+    bad = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+    assert bad == 0, "%s: %d of %d pixels differ from the reference" % (workload, bad, w * h)
+    st.Release()
+
+
 def test_full_size_aggregation_paths_agree(hip):
     """plain 8-pass aggregation == fused cost + host-chosen ring + pass pairs, bit for bit, on the noise pair
     (short arms: small ring, pairs) and on the structured pair (long arms: full ring)."""
