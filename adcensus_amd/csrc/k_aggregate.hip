@@ -155,13 +155,58 @@ typedef unsigned long long agg_u64;
 // VPL = disparities per lane (1, or 2 with the small ring when Dp is a multiple of 128): with two, a wave owns 512
 // contiguous bytes of every pixel of its line, all wave-uniform work of a step (records, ring slots, branches, waits) is
 // shared by twice the data and the two sums of a lane are independent chains.
-template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN, bool PAIR, int VPL = 1>
-__global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
-                                                  const uint32_t* __restrict__ rec, // {lo, hi, count16} per pixel, line-major
-                                                  int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
-                                                  const int* __restrict__ armmax, int small_variant, int small_L,
-                                                  AggCostIn ci)
+// REGRING (full ring, plain pass): the ring lives in REGISTERS -- VGPRs v56..v127, outside the range the compiler may
+// allocate for this kernel (amdgpu_num_vgpr) -- and is addressed with the VGPR index mode (s_set_gpr_idx_on: the
+// ring slots are wave-uniform, M0 holds the index).  A span entry costs one indexed v_add_f32 and one s_add on M0
+// instead of an LDS round trip, there is no LDS allocation at all, and 128 VGPRs allow 16 waves per CU where the
+// 17 KiB LDS ring allowed 9.  Same entries, same order, same adds: bit-identical (tools/ubench/regring.hip).
+#define AGG_RING_V0 56
+#define AGG_RING_REGS 72
+#define AGG_RING_CLOBBERS                                                                                             \
+    "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72",  \
+        "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88",    \
+        "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103",       \
+        "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117",    \
+        "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+// ring[slot] = v
+__device__ __forceinline__ void agg_reg_push(int slot, float v)
 {
+    asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v56, %1\n\ts_set_gpr_idx_off" ::"s"(slot), "v"(v)
+                 : "m0", AGG_RING_CLOBBERS);
+}
+// acc += ring[idx], ring[idx+1], ... (cnt entries, no wrap), in this order: blocks of 16 indexed adds entered late
+// through a computed jump (one block = v_add_f32_e32 + s_add_u32 on M0 = 8 bytes; 12 = the three scalar instructions
+// between the value s_getpc returns and the first block)
+__device__ __forceinline__ float agg_reg_sum(float acc, int idx, int cnt)
+{
+#define AGG_RADD "v_add_f32_e32 %0, v56, %0\n\ts_add_u32 m0, m0, 1\n\t"
+    while (cnt > 0) {
+        const int c = cnt < 16 ? cnt : 16;
+        const int off = 12 + 8 * (16 - c);
+        asm volatile("s_set_gpr_idx_on %1, gpr_idx(SRC0)\n\t"
+                     "s_getpc_b64 vcc\n\t"
+                     "s_add_u32 vcc_lo, vcc_lo, %2\n\t"
+                     "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+                     "s_setpc_b64 vcc\n\t" AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD
+                         AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD "s_set_gpr_idx_off"
+                     : "+v"(acc)
+                     : "s"(idx), "s"(off)
+                     : "m0", "scc", "vcc", AGG_RING_CLOBBERS);
+        idx += c;
+        cnt -= c;
+    }
+#undef AGG_RADD
+    return acc;
+}
+
+template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN, bool PAIR, int VPL, bool REGRING>
+__device__ __forceinline__ void agg_march_body(const float* __restrict__ src, float* __restrict__ dst,
+                                               const uint32_t* __restrict__ rec, // {lo, hi, count16} per pixel, line-major
+                                               int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
+                                               const int* __restrict__ armmax, int small_variant, int small_L,
+                                               const AggCostIn& ci)
+{
+    static_assert(!REGRING || (!SMALL && !COSTIN && !PAIR && VPL == 1), "register ring: plain full-ring pass");
     static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
     static_assert(!PAIR || (DIVIDE && !COSTIN), "a fused pair = dividing pass + the following non-dividing pass");
     static_assert(VPL == 1 || (VPL == 2 && SMALL && !COSTIN), "two disparities per lane: small ring, no fused cost");
@@ -292,7 +337,8 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 
 #define AGG_PUSH(V)                                \
     do {                                           \
-        ring[slot_w * 64] = (V);                   \
+        if constexpr (REGRING) agg_reg_push(slot_w, (V)); \
+        else ring[slot_w * 64] = (V);              \
         slot_w = slot_w + 1 == R ? 0 : slot_w + 1; \
     } while (0)
 
@@ -304,7 +350,11 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
         if (idx_ < 0) idx_ += R;                                                                  \
         const int n_ = ADC_K4_DIAG == 1 ? 1 : (ADC_K4_DIAG == 3 ? adc_imin(4, a_lo_ + a_hi_ + 1) : a_lo_ + a_hi_ + 1); \
         V acc_;                                                                                   \
-        if (n_ == 1) {                                                                            \
+        if constexpr (REGRING) {                                                                  \
+            const int n1_ = adc_imin(n_, R - idx_);                                               \
+            acc_ = agg_reg_sum(vzero, idx_, n1_);                                                 \
+            if (n_ > n1_) acc_ = agg_reg_sum(acc_, 0, n_ - n1_);                                  \
+        } else if (n_ == 1) {                                                                     \
             acc_ = vzero + ring[idx_ * 64]; /* arms 0/0: the sum is the pixel itself */           \
         } else {                                                                                  \
             const int n1_ = adc_imin(n_, R - idx_);                                               \
@@ -547,6 +597,26 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
 #undef AGG_COST
 }
 
+template <bool VERT, bool DIVIDE, bool SMALL, bool COSTIN, bool PAIR, int VPL = 1>
+__global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src, float* __restrict__ dst,
+                                                  const uint32_t* __restrict__ rec, int W, int H, int Dp, int L, int seg_len,
+                                                  int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant,
+                                                  int small_L, AggCostIn ci)
+{
+    agg_march_body<VERT, DIVIDE, SMALL, COSTIN, PAIR, VPL, false>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax,
+                                                                  small_variant, small_L, ci);
+}
+
+// full ring in registers (2L+1 <= AGG_RING_REGS): the compiler keeps to v0..v55, the ring owns v56..v127
+template <bool VERT, bool DIVIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AGG_RING_V0))) void k_agg_regring(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ rec, int W, int H, int Dp, int L,
+    int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L, AggCostIn ci)
+{
+    agg_march_body<VERT, DIVIDE, false, false, false, 1, true>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax,
+                                                                small_variant, small_L, ci);
+}
+
 static int env_int(const char* name, int dflt)
 {
     const char* s = getenv(name);
@@ -604,9 +674,12 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         // ring and a record ring
         const int vpl = (variant == 1 && !COSTIN && (vpl2_env == 1 || (vpl2_env == 2 && PAIR)) && p.Dp % 128 == 0) ? 2 : 1;
         const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
-        const size_t ring_bytes = (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
+        // full ring of a plain pass: in registers when it fits (ADC_AGG_REGRING=0: LDS ring)
+        static const bool regring_env = env_int("ADC_AGG_REGRING", 1) != 0;
+        const bool regring = variant == 0 && !COSTIN && !PAIR && regring_env && 2 * Lv + 1 <= AGG_RING_REGS;
+        const size_t ring_bytes = regring ? 0 : (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
         const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + (PAIR ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
-        const int waves_per_cu = adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
+        const int waves_per_cu = regring ? 16 : adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
         int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
         if (nseg < 1) nseg = pick_nseg(nlines, N, PAIR ? 2 * Lv : Lv, 256 * waves_per_cu);
         int seg_len = (N + nseg - 1) / nseg;
@@ -622,7 +695,11 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         ci.lut_ad = h->lut_ad;
         ci.lut_census = h->lut_census;
         ci.rpitch = h->rrec_pitch; ci.padl = h->rrec_padl; ci.dmin = p.dmin; ci.D = p.D;
-        if (variant && vpl == 2) {
+        if (regring) {
+            if constexpr (!COSTIN && !PAIR)
+                hipLaunchKernelGGL((k_agg_regring<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), 0, h->heavy, src, dst,
+                                   VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
+        } else if (variant && vpl == 2) {
             if constexpr (!COSTIN)
                 hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true, false, PAIR, 2>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
                                    VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
