@@ -206,7 +206,7 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
                                                const int* __restrict__ armmax, int small_variant, int small_L,
                                                const AggCostIn& ci)
 {
-    static_assert(!REGRING || (!SMALL && !COSTIN && !PAIR && VPL == 1), "register ring: plain full-ring pass");
+    static_assert(!REGRING || (!SMALL && !PAIR && VPL == 1), "register ring: full-ring pass (plain or with the fused cost)");
     static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
     static_assert(!PAIR || (DIVIDE && !COSTIN), "a fused pair = dividing pass + the following non-dividing pass");
     static_assert(VPL == 1 || (VPL == 2 && SMALL && !COSTIN), "two disparities per lane: small ring, no fused cost");
@@ -256,7 +256,7 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
     const uint32_t* rp = rec + (long long)fixed * N; // records of this line, contiguous along m
 
     // ---- fused cost state (COSTIN)
-    float* lutA = ring_all + R * 64; // A[766] then C[64] behind the ring (COSTIN: VPL == 1)
+    float* lutA = ring_all + (REGRING ? 0 : R * 64); // A[766] then C[64] behind the LDS ring (COSTIN: VPL == 1)
     float* lutC = lutA + 768;
     uint32_t wB = 0, wC0 = 0, wC1 = 0;          // this lane's right-image pixel {bgrx, census} for the current entry
     const uint4* rrow = nullptr;                 // rrow[x] = right record of column x - d_first (lane 0's column)
@@ -617,6 +617,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AGG_RING_V0))) v
                                                                 small_variant, small_L, ci);
 }
 
+// the same for the first pass of the pipeline (fused matching cost; its two tables stay in LDS)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AGG_RING_V0))) void k_agg_regring_cost(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ rec, int W, int H, int Dp, int L,
+    int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L, AggCostIn ci)
+{
+    agg_march_body<false, false, false, true, false, 1, true>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax,
+                                                               small_variant, small_L, ci);
+}
+
 static int env_int(const char* name, int dflt)
 {
     const char* s = getenv(name);
@@ -676,7 +685,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
         // full ring of a plain pass: in registers when it fits (ADC_AGG_REGRING=0: LDS ring)
         static const bool regring_env = env_int("ADC_AGG_REGRING", 1) != 0;
-        const bool regring = variant == 0 && !COSTIN && !PAIR && regring_env && 2 * Lv + 1 <= AGG_RING_REGS;
+        const bool regring = variant == 0 && !PAIR && regring_env && 2 * Lv + 1 <= AGG_RING_REGS;
         const size_t ring_bytes = regring ? 0 : (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
         const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + (PAIR ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
         const int waves_per_cu = regring ? 16 : adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
@@ -696,7 +705,10 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         ci.lut_census = h->lut_census;
         ci.rpitch = h->rrec_pitch; ci.padl = h->rrec_padl; ci.dmin = p.dmin; ci.D = p.D;
         if (regring) {
-            if constexpr (!COSTIN && !PAIR)
+            if constexpr (COSTIN)
+                hipLaunchKernelGGL(k_agg_regring_cost, dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
+                                   VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
+            else if constexpr (!PAIR)
                 hipLaunchKernelGGL((k_agg_regring<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), 0, h->heavy, src, dst,
                                    VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
         } else if (variant && vpl == 2) {
