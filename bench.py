@@ -168,7 +168,7 @@ def main():
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d D=%d%s" % (a.workload, W, H, D, {(1920, 1080, 128): " (BASELINE.json configs[3])",
+            "config": {"workload": "%s %dx%d D=%d%s" % (a.workload, W, H, D, {(1920, 1080, 128): " (BASELINE.json configs[3])" if a.workload == "noise" else " (size of BASELINE.json configs[3], SURVEY 8d structured pair)",
                                                                             (1242, 375, 128): " (size of BASELINE.json configs[2])",
                                                                             (450, 375, 64): " (size of BASELINE.json configs[1])"}.get((W, H, D), "")),
                        "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs)" % world},
