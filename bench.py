@@ -8,11 +8,12 @@ HBM (adc_match_device); the disparity map stays in HBM.  N>1: one process per GP
 RCCL is used only for the barrier and the max-over-ranks reduction of the elapsed time).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the aggregation pass kernel (k_agg_march): algorithmic bytes per launch
+  roofline     -- the aggregation pass kernel (k_agg_march; k_agg_regring on long-arm images): algorithmic bytes per launch
                   (2*V + 4*P arms [+ 2*P counts on dividing passes], V = 4*W*H*D) / its average
                   launch duration measured with HIP events on the handle's own stream inside the
                   timed region, vs 8 TB/s HBM3E (regular passes only: the first pass, which computes the
-                  matching cost itself and only writes, is not part of the average).
+                  matching cost itself and only writes, is not part of the average); device_copy_GBps =
+                  a device-to-device copy of one volume measured after the timed region (practical ceiling).
   cpu_baseline -- the reference CPU path (oracle/_ref, kind "reference"; the plain-C port if absent)
                   timed on this host, 1 thread, on a bounded row-strip sample of the same pair.
 """
@@ -174,7 +175,8 @@ def main():
                        "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs)" % world},
             "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
             "stage_ms": stage,
-            "roofline": {"kernel": "k_agg_march (one aggregation launch: %s)" % ("pass pair, 2 passes of work" if npass in (4, 5) else "one pass"), "bound": "hbm",
+            "roofline": {"kernel": "%s (one aggregation launch: %s)" % (("k_agg_march", "pass pair, 2 passes of work") if npass in (4, 5)
+                                                                                    else ("k_agg_regring / k_agg_march", "one pass")), "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(a.workload, (W, H, D)),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(agg_ms, 5),
