@@ -119,7 +119,7 @@ __device__ __forceinline__ V agg_run_compact(V acc, const V* q, int cnt)
     return acc;
 }
 template <bool SMALL_, class V>
-__device__ __forceinline__ V agg_sum(V acc, const V* q, int cnt, int /*slot*/)
+__device__ __forceinline__ V agg_sum(V acc, const V* q, int cnt)
 {
     if constexpr (SMALL_) return agg_run_compact<V>(acc, q, cnt);
     else {
@@ -312,8 +312,8 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
             acc2_ = vzero + ring2[i2_ * 64];                                                      \
         } else {                                                                                  \
             const int k1_ = adc_imin(k_, R - i2_);                                                \
-            acc2_ = agg_sum<SMALL, V>(vzero, ring2 + i2_ * 64, k1_, i2_);                         \
-            if (k_ > k1_) acc2_ = agg_sum<SMALL, V>(acc2_, ring2, k_ - k1_, 0);                   \
+            acc2_ = agg_sum<SMALL, V>(vzero, ring2 + i2_ * 64, k1_);                              \
+            if (k_ > k1_) acc2_ = agg_sum<SMALL, V>(acc2_, ring2, k_ - k1_);                      \
         }                                                                                         \
         *reinterpret_cast<V*>(dpn) = acc2_;                                                       \
         dpn += fstep;                                                                             \
@@ -358,8 +358,8 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
             acc_ = vzero + ring[idx_ * 64]; /* arms 0/0: the sum is the pixel itself */           \
         } else {                                                                                  \
             const int n1_ = adc_imin(n_, R - idx_);                                               \
-            acc_ = agg_sum<SMALL, V>(vzero, ring + idx_ * 64, n1_, idx_); /* t = -arm .. +arm */   \
-            if (n_ > n1_) acc_ = agg_sum<SMALL, V>(acc_, ring, n_ - n1_, 0); /* wrapped part */   \
+            acc_ = agg_sum<SMALL, V>(vzero, ring + idx_ * 64, n1_); /* t = -arm .. +arm */         \
+            if (n_ > n1_) acc_ = agg_sum<SMALL, V>(acc_, ring, n_ - n1_); /* wrapped part */      \
         }                                                                                         \
         if (DIVIDE && ADC_K4_DIAG != 2) {                                                         \
             const uint32_t c_ = r_ >> 16;                                                         \

@@ -543,9 +543,6 @@ __device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_di
 // targets, with ~4.5 steps per ray).  Offsets of steps 1..4 live in registers, the next list entries are
 // prefetched, 4 steps' disparities are fetched per round trip (loads past the hit are clamped to the pixel itself
 // and ignored), the colour of the hit is fetched once at the end.
-#ifndef ADC_INTERP_MASKED
-#define ADC_INTERP_MASKED 0
-#endif
 template <int NS>
 __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
                                                          const float* __restrict__ din, float* __restrict__ dout,
@@ -597,11 +594,7 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
                 const int yy = y + (o >> 16), xx = x + (int)(short)(o & 0xffff);
                 in[j] = (m0 + j < max_search) && yy >= 0 && yy < H && xx >= 0 && xx < W;
                 q[j] = (in[j] && pw >= 0) ? yy * W + xx : p; // finished rays re-read their own pixel (one line)
-#if ADC_INTERP_MASKED
-                d[j] = pw >= 0 ? din[q[j]] : ADC_INVALID_FLOAT; // (A/B: finished rays issue no gather at all)
-#else
-                d[j] = din[q[j]];
-#endif
+                d[j] = din[q[j]]; // (masking the gathers of finished rays instead was measured: no change)
             }
 #pragma unroll
             for (int j = 0; j < NS; j++) {

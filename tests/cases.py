@@ -44,6 +44,8 @@ _CASES = {
     "cone_params": (cone_pair, dict(lambda_ad=7, lambda_census=20, cross_L1=20, cross_L2=9, cross_t1=25, cross_t2=8,
                                     so_p1=0.8, so_p2=2.5, so_tso=11, irv_ts=12, irv_th=0.3, lrcheck_thres=1.5)),
     "cone_crop_d40": (lambda: _crop(cone_pair(), 100, 231, 120, 377), dict(max_disparity=40)),
+    # cross_L1 = 40: the aggregation ring (81 entries) does not fit the register ring -> LDS full ring
+    "cone_crop_L40": (lambda: _crop(cone_pair(), 100, 231, 120, 377), dict(max_disparity=40, cross_L1=40)),
     # small synthetic cases: odd sizes, W < D, census-skip sizes, 1-pixel-wide/high, VPL = 2 and 4
     "s2_96x64_d32": (lambda: workloads.structured_pair(96, 64, 32, seed=11), dict(max_disparity=32)),
     "s2_320x180_d128": (lambda: workloads.structured_pair(320, 180, 128, seed=12), dict(max_disparity=128)),

@@ -7,7 +7,7 @@ from tests import cases, gpu_harness
 pytestmark = pytest.mark.gpu
 
 STAGE_CASES = ["s2_96x64_d32", "q_257x131_d64", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8", "q_40x1_d8",
-               "q_3x3_d2", "noise_128x72_d64", "noise_160x90_d128", "noise_150x40_d256", "s2_150x100_neg", "s2_320x180_d128", "s2_200x120_d200", "cone_crop_d40",
+               "q_3x3_d2", "noise_128x72_d64", "noise_160x90_d128", "noise_150x40_d256", "s2_150x100_neg", "s2_320x180_d128", "s2_200x120_d200", "cone_crop_d40", "cone_crop_L40",
                "cone", "cone_neg", "cone_d16", "cone_nolr", "cone_nofill", "cone_dda", "cone_params"]
 
 
