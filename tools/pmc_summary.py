@@ -12,7 +12,7 @@ out = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open("gpurun_out/pmc_%s_%s/pmc_counter_collection.csv" % (wl, C))):
-        if r["Counter_Name"] == C and "k_agg_march" in r["Kernel_Name"]:
+        if r["Counter_Name"] == C and ("k_agg_march" in r["Kernel_Name"] or "k_agg_regring" in r["Kernel_Name"]):
             agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]) * 1024.0)
     out[C] = {k: sum(v) / len(v) for k, v in agg.items()}
 per = {}
@@ -22,7 +22,13 @@ for k in out["FETCH_SIZE"]:
 per = {k: v for k, v in per.items() if v["write_bytes"] > 1e6}  # drop the variant that exits immediately
 
 
-def costin(name):  # k_agg_march<VERT, DIVIDE, SMALL, COSTIN, PAIR>: the fused first pass only writes the volume
+def costin(name):  # k_agg_march<VERT, DIVIDE, SMALL, COSTIN, PAIR, VPL>: the fused first pass only writes the volume
+    if "k_agg_regring_cost" in name:
+        return True
+    if "<" not in name:
+        return False
+    if "k_agg_regring" in name:
+        return False
     args = name[name.index("<") + 1:name.rindex(">")].split(",")
     return len(args) >= 4 and args[3].strip() == "true"
 
