@@ -175,27 +175,35 @@ __device__ __forceinline__ void agg_reg_push(int slot, float v)
                  : "m0", AGG_RING_CLOBBERS);
 }
 // acc += ring[idx], ring[idx+1], ... (cnt entries, no wrap), in this order: blocks of 16 indexed adds entered late
-// through a computed jump (one block = v_add_f32_e32 + s_add_u32 on M0 = 8 bytes; 12 = the three scalar instructions
-// between the value s_getpc returns and the first block)
+// through a computed jump.  The index register M0 is set ONCE per block: the adds name the registers v40..v55 and the
+// hardware adds M0 = idx + c to the register number, so block position p reads v[40 + p + idx + c]; entering at position
+// 16 - c makes that v[56 + idx] ... v[56 + idx + c - 1].  (v40..v55 only appear as encodings: every register actually
+// read lies in the ring.)  One add = 4 bytes; 12 = the three scalar instructions between the value s_getpc returns and
+// the first add.  A first version advanced M0 with an s_add per entry: 13 more scalar instructions per step on a
+// kernel whose scalar unit is saturated (SQ counters).
 __device__ __forceinline__ float agg_reg_sum(float acc, int idx, int cnt)
 {
-#define AGG_RADD "v_add_f32_e32 %0, v56, %0\n\ts_add_u32 m0, m0, 1\n\t"
+    static_assert(AGG_RING_V0 == 56, "the add block below names v40..v55 = AGG_RING_V0 - 16 + position");
     while (cnt > 0) {
         const int c = cnt < 16 ? cnt : 16;
-        const int off = 12 + 8 * (16 - c);
+        const int off = 12 + 4 * (16 - c);
+        const int m = idx + c;
         asm volatile("s_set_gpr_idx_on %1, gpr_idx(SRC0)\n\t"
                      "s_getpc_b64 vcc\n\t"
                      "s_add_u32 vcc_lo, vcc_lo, %2\n\t"
                      "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
-                     "s_setpc_b64 vcc\n\t" AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD
-                         AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD AGG_RADD "s_set_gpr_idx_off"
+                     "s_setpc_b64 vcc\n\t"
+                     "v_add_f32_e32 %0, v40, %0\n\tv_add_f32_e32 %0, v41, %0\n\tv_add_f32_e32 %0, v42, %0\n\tv_add_f32_e32 %0, v43, %0\n\t"
+                     "v_add_f32_e32 %0, v44, %0\n\tv_add_f32_e32 %0, v45, %0\n\tv_add_f32_e32 %0, v46, %0\n\tv_add_f32_e32 %0, v47, %0\n\t"
+                     "v_add_f32_e32 %0, v48, %0\n\tv_add_f32_e32 %0, v49, %0\n\tv_add_f32_e32 %0, v50, %0\n\tv_add_f32_e32 %0, v51, %0\n\t"
+                     "v_add_f32_e32 %0, v52, %0\n\tv_add_f32_e32 %0, v53, %0\n\tv_add_f32_e32 %0, v54, %0\n\tv_add_f32_e32 %0, v55, %0\n\t"
+                     "s_set_gpr_idx_off"
                      : "+v"(acc)
-                     : "s"(idx), "s"(off)
+                     : "s"(m), "s"(off)
                      : "m0", "scc", "vcc", AGG_RING_CLOBBERS);
         idx += c;
         cnt -= c;
     }
-#undef AGG_RADD
     return acc;
 }
 
