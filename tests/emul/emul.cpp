@@ -141,6 +141,135 @@ void emul_aggregate_pass(const float* src, float* dst, const uint8_t* arms, cons
     }
 }
 
+// Pass PAIR (k_agg_march<.., PAIR>): the dividing pass of an iteration and the non-dividing first pass of the next one
+// run along the same direction and share one launch.  Mirrors the kernel: the first pass's outputs go to a second ring
+// (their records to a record ring) instead of memory; when first-pass output m exists, second-pass output m - L is
+// summed from the second ring.  A segment [s0, s1) of second-pass outputs needs first-pass outputs [s0-L, s1+L) and
+// entries [s0-2L, s1+2L) (clipped to the line).
+static void agg_line_pair(const float* src, float* dst, const uint32_t* rp, int W, int H, int D, int d, bool vert, int fixed,
+                          int L, int s0, int s1, int PF)
+{
+    const int R = 2 * L + 1;
+    const int N = vert ? H : W;
+    const int m0 = std::max(0, s0 - L), m1 = std::min(N, s1 + L);
+    const int lo = std::max(0, m0 - L), hi = std::min(N, m1 + L);
+    std::vector<float> ring(R, NAN), ring2(R, NAN), pf(PF, NAN), t(PF, NAN);
+    std::vector<uint32_t> recring(R, 0), pr(PF);
+    auto pix_of = [&](int m) -> size_t { return vert ? (size_t)m * W + fixed : (size_t)fixed * W + m; };
+    int slot_w = 0, slot_m = m0 - lo;
+    int slot2_w = 0, slot2_s = s0 - m0, mcur = m0, snext = s0;
+    auto push = [&](float v) { ring[slot_w] = v; slot_w = slot_w + 1 == R ? 0 : slot_w + 1; };
+    auto emit2 = [&]() {
+        const uint32_t r2 = recring[slot2_s];
+        const int b_lo = r2 & 255u, b_hi = (r2 >> 8) & 255u;
+        int i2 = slot2_s - b_lo;
+        if (i2 < 0) i2 += R;
+        const int k = b_lo + b_hi + 1;
+        const int k1 = std::min(k, R - i2);
+        float acc2 = agg_run(0.0f, ring2.data() + i2, k1);
+        if (k > k1) acc2 = agg_run(acc2, ring2.data(), k - k1);
+        dst[pix_of(snext) * D + d] = acc2; // outputs leave in increasing order, starting at s0
+        snext++;
+        slot2_s = slot2_s + 1 == R ? 0 : slot2_s + 1;
+    };
+    auto emit = [&](uint32_t r) {
+        const int a_lo = r & 255u, a_hi = (r >> 8) & 255u;
+        int idx = slot_m - a_lo;
+        if (idx < 0) idx += R;
+        const int n = a_lo + a_hi + 1;
+        const int n1 = std::min(n, R - idx);
+        float acc = agg_run(0.0f, ring.data() + idx, n1);
+        if (n > n1) acc = agg_run(acc, ring.data(), n - n1);
+        const uint32_t c = r >> 16;
+        if (c != 1u) acc = acc / (float)c; // the first pass of the pair is the dividing one
+        ring2[slot2_w] = acc;
+        recring[slot2_w] = r;
+        slot2_w = slot2_w + 1 == R ? 0 : slot2_w + 1;
+        const int s = mcur - L; // its look-ahead (<= L) is complete now
+        mcur++;
+        if (s >= s0 && s < s1) emit2();
+        slot_m = slot_m + 1 == R ? 0 : slot_m + 1;
+    };
+    const int jB = std::min(hi, m0 + L);
+    for (int j = lo; j < jB; j += PF) {
+        for (int u = 0; u < PF; u++) t[u] = src[pix_of(std::min(j + u, jB - 1)) * D + d];
+        for (int u = 0; u < PF; u++)
+            if (j + u < jB) push(t[u]);
+    }
+    int j = jB;
+    if (j + 2 * PF <= hi) {
+        int nxt = j;
+        for (int u = 0; u < PF; u++, nxt++) { pf[u] = src[pix_of(nxt) * D + d]; pr[u] = rp[nxt - L]; }
+        for (; j + 2 * PF <= hi; j += PF)
+            for (int u = 0; u < PF; u++, nxt++) {
+                const float v = pf[u];
+                const uint32_t r = pr[u];
+                pf[u] = src[pix_of(nxt) * D + d];
+                pr[u] = rp[nxt - L];
+                push(v);
+                emit(r);
+            }
+        for (int u = 0; u < PF; u++) { push(pf[u]); emit(pr[u]); }
+        j += PF;
+    }
+    for (; j < hi; j++) {
+        push(src[pix_of(j) * D + d]);
+        const int m = j - L;
+        if (m >= m0) emit(rp[m]);
+    }
+    for (int m = std::max(m0, hi - L); m < m1; m++) emit(rp[m]);
+    for (int sx = std::max(s0, mcur - L); sx < s1; sx++) emit2(); // look-ahead cut by the end of the line
+}
+
+void emul_aggregate_pair(const float* src, float* dst, const uint8_t* arms, const uint16_t* sup, int W, int H, int D, int vert,
+                         int L, int nseg, int PF)
+{
+    const int N = vert ? H : W;
+    int seg_len = (N + nseg - 1) / nseg;
+    if (seg_len < 1) seg_len = 1;
+    nseg = (N + seg_len - 1) / seg_len;
+    const int nfixed = vert ? W : H;
+    std::vector<uint32_t> rec((size_t)W * H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const uint8_t* a = arms + p * 4;
+            if (vert) rec[(size_t)x * H + y] = (uint32_t)a[2] | ((uint32_t)a[3] << 8) | ((uint32_t)sup[p] << 16);
+            else rec[p] = (uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)sup[p] << 16);
+        }
+    for (int seg = 0; seg < nseg; seg++) {
+        const int s0 = seg * seg_len, s1 = std::min(N, s0 + seg_len);
+        for (int f = 0; f < nfixed; f++)
+            for (int d = 0; d < D; d++)
+                agg_line_pair(src, dst, rec.data() + (size_t)f * N, W, H, D, d, vert != 0, f, L, s0, s1, PF);
+    }
+}
+
+// Register ring (k_agg_regring): model of the span addressing of agg_reg_sum.  vgpr[] stands for the wave's VGPR file
+// (one lane); the ring occupies vgpr[56 .. 56+R).  A block of 16 adds names the registers v40+p (p = 0..15), the
+// hardware adds M0 to the register number; with M0 = idx + c and entry at position 16 - c the adds read
+// vgpr[56+idx] .. vgpr[56+idx+c-1] in this order.  Returns the ordered sum and, in *lowest / *highest, the lowest and
+// highest register number actually read (must stay inside the ring).
+float emul_regring_span(const float* vgpr, int idx, int cnt, int* lowest, int* highest)
+{
+    float acc = 0.0f;
+    *lowest = 1 << 30;
+    *highest = -1;
+    while (cnt > 0) {
+        const int c = cnt < 16 ? cnt : 16;
+        const int m0reg = idx + c; // M0[7:0]
+        for (int p = 16 - c; p < 16; p++) { // computed jump: skip the first 16 - c adds
+            const int reg = 40 + p + m0reg;
+            acc += vgpr[reg];
+            *lowest = reg < *lowest ? reg : *lowest;
+            *highest = reg > *highest ? reg : *highest;
+        }
+        idx += c;
+        cnt -= c;
+    }
+    return acc;
+}
+
 // ------------------------------------------------------------------ k_scanline (per disparity, no lanes)
 void emul_scanline_pass(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H, int dmin,
                         int D, int vert, int dir, int tso, float p1, float p2)

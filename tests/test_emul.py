@@ -55,6 +55,48 @@ def test_marching_ring_aggregation(emul, dumps, name, pf, hseg, vseg):
     assert same(a, o["cost_aggr"])
 
 
+@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2"])
+@pytest.mark.parametrize("pf,hseg,vseg", [(8, 1, 1), (8, 3, 2), (3, 2, 5)])
+def test_marching_ring_pass_pairs(emul, dumps, name, pf, hseg, vseg):
+    """Production launch sequence on short-arm images: H0 | V0+V1 | H1+H2 | V2+V3 | H3 (8 passes in 5 launches); a pair =
+    dividing pass + the next iteration's first pass through a second ring, segment halos of 2L."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D = opt.max_disparity - opt.min_disparity
+    L = max(0, min(opt.cross_L1, 255))
+    a, b = o["cost_init"].copy(), np.empty_like(o["cost_init"])
+    emul.emul_aggregate_pass(P(a), P(b), P(o["arms"]), P(o["sup_count_h"]), w, h, D, 0, 0, L, hseg, pf)  # H0
+    a, b = b, a
+    for vert, sup in ((1, o["sup_count_h"]), (0, o["sup_count_v"]), (1, o["sup_count_h"])):  # the three pairs
+        emul.emul_aggregate_pair(P(a), P(b), P(o["arms"]), P(sup), w, h, D, vert, L, vseg if vert else hseg, pf)
+        a, b = b, a
+    emul.emul_aggregate_pass(P(a), P(b), P(o["arms"]), P(o["sup_count_v"]), w, h, D, 0, 1, L, hseg, pf)  # H3 (dividing)
+    a, b = b, a
+    assert same(a, o["cost_aggr"])
+
+
+def test_register_ring_span_addressing(emul):
+    """agg_reg_sum: one M0 value per block of 16 adds with static register numbers v40..v55, entered late -- every read
+    lands on ring[idx .. idx+cnt) (registers v56+) in increasing order, for every start slot and span length."""
+    import ctypes as C
+    emul.emul_regring_span.restype = C.c_float
+    emul.emul_regring_span.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.default_rng(3)
+    R = 69
+    vgpr = np.full(256, np.nan, np.float32)  # anything outside the ring poisons the sum
+    ring = (rng.random(R, dtype=np.float32) * 7 + 0.1).astype(np.float32)
+    vgpr[56:56 + R] = ring
+    lo, hi = C.c_int(), C.c_int()
+    for idx in range(R):
+        for cnt in range(1, R - idx + 1):  # a run never wraps (the wrap is a second run)
+            got = emul.emul_regring_span(vgpr.ctypes.data, idx, cnt, C.byref(lo), C.byref(hi))
+            want = np.float32(0.0)
+            for v in ring[idx:idx + cnt]:
+                want = np.float32(want + v)
+            assert np.float32(got).view(np.uint32) == want.view(np.uint32), (idx, cnt)
+            assert lo.value == 56 + idx and hi.value == 56 + idx + cnt - 1 and hi.value < 128
+
+
 @pytest.mark.parametrize("name", LANE_CASES)
 def test_scanline_closed_form(emul, dumps, name):
     left, right, opt, o = dumps(name)
