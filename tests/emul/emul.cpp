@@ -245,6 +245,72 @@ void emul_aggregate_pair(const float* src, float* dst, const uint8_t* arms, cons
     }
 }
 
+// Fused matching cost (k_agg_march<.., COSTIN>): model of the lane window.  A wave owns 64 disparities d_first + lane
+// of one image row; lane l needs the right-image pixel of column x - d.  Marching in x, that column moves one lane
+// per step: the window {bgrx, census} is shifted by one lane (DPP wave_shr:1) and the one new column x - d_first
+// enters at lane 0.  Right rows are stored with padl marker records (bgrx = 0xFFFFFFFF -> cost 1.0) in front and
+// markers behind, so no bounds logic exists; the window of the entry BEFORE the first one is gathered (clamped) at the
+// start of a segment.  cost = A[sad_u8] - C[popcount(census xor)] with the host-built tables.
+void emul_cost_window(const uint8_t* img_l, const uint8_t* img_r, const uint64_t* cen_l, const uint64_t* cen_r, float* cost,
+                      int W, int H, int dmin, int D, int lambda_ad, int lambda_census, int seg_len)
+{
+    float A[768] = {0}, C[64];
+    for (int k = 0; k <= 765; k++) A[k] = (1.0f - expf(-((float)k / 3.0f) / (float)lambda_ad)) + 1.0f;
+    for (int hm = 0; hm < 64; hm++) C[hm] = expf(-(float)hm / (float)lambda_census);
+    const int padl = (dmin + D - 1 > 0 ? dmin + D - 1 : 0) + 1;
+    const int pitch = padl + W + (dmin < 0 ? -dmin : 0) + 1;
+    struct Rec { uint32_t b, c0, c1; };
+    auto pack = [](const uint8_t* px) { return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16); };
+    auto sad_u8 = [](uint32_t a, uint32_t b) {
+        uint32_t s_ = 0;
+        for (int i = 0; i < 4; i++) { const int x = (a >> (8 * i)) & 255, y = (b >> (8 * i)) & 255; s_ += x > y ? x - y : y - x; }
+        return s_;
+    };
+    std::vector<Rec> rrow(pitch), lrow(W);
+    const int Dp = (D + 63) / 64 * 64;
+    if (seg_len < 1) seg_len = W;
+    for (int y = 0; y < H; y++) {
+        for (int i = 0; i < pitch; i++) {
+            const int c = i - padl;
+            rrow[i] = Rec{0xFFFFFFFFu, 0u, 0u};
+            if (c >= 0 && c < W) {
+                const size_t p = (size_t)y * W + c;
+                rrow[i] = Rec{pack(img_r + 3 * p), (uint32_t)cen_r[p], (uint32_t)(cen_r[p] >> 32)};
+            }
+        }
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            lrow[x] = Rec{pack(img_l + 3 * p), (uint32_t)cen_l[p], (uint32_t)(cen_l[p] >> 32)};
+        }
+        for (int chunk = 0; chunk < Dp / 64; chunk++) {
+            const int d_first = chunk * 64 + dmin;
+            for (int lo = 0; lo < W; lo += seg_len) { // a segment restarts the window (the kernel's entry range [lo, hi))
+                const int hi = std::min(W, lo + seg_len);
+                Rec win[64];
+                for (int lane = 0; lane < 64; lane++) { // window of entry lo - 1
+                    int gi = padl - d_first + lo - 1 - lane;
+                    gi = gi < 0 ? 0 : (gi >= pitch ? pitch - 1 : gi); // index 0 is a marker column (padl >= 1)
+                    win[lane] = rrow[gi];
+                }
+                for (int x = lo; x < hi; x++) {
+                    for (int lane = 63; lane > 0; lane--) win[lane] = win[lane - 1]; // wave_shr:1
+                    win[0] = rrow[padl - d_first + x];                                 // column x - d_first
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int d = chunk * 64 + lane;
+                        if (d >= D) continue; // padding lanes write 0 into the padded volume
+                        const uint32_t ad = sad_u8(win[lane].b, lrow[x].b);
+                        const uint32_t hm = (uint32_t)__builtin_popcount(win[lane].c0 ^ lrow[x].c0) +
+                                            (uint32_t)__builtin_popcount(win[lane].c1 ^ lrow[x].c1);
+                        float cv = A[ad < 766u ? ad : 765u] - C[hm & 63u];
+                        if (win[lane].b == 0xFFFFFFFFu) cv = 1.0f;
+                        cost[((size_t)y * W + x) * D + d] = cv;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Register ring (k_agg_regring): model of the span addressing of agg_reg_sum.  vgpr[] stands for the wave's VGPR file
 // (one lane); the ring occupies vgpr[56 .. 56+R).  A block of 16 adds names the registers v40+p (p = 0..15), the
 // hardware adds M0 to the register number; with M0 = idx + c and entry at position 16 - c the adds read

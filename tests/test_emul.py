@@ -75,6 +75,21 @@ def test_marching_ring_pass_pairs(emul, dumps, name, pf, hseg, vseg):
     assert same(a, o["cost_aggr"])
 
 
+@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2", "s2_150x100_neg",
+                                  "s2_200x120_d200"])
+@pytest.mark.parametrize("seg", [0, 7, 50])
+def test_fused_cost_lane_window(emul, dumps, name, seg):
+    """The matching cost as the fused first aggregation pass computes it (shifting lane window over padded right-image
+    records, packed-colour SAD, census popcount, host tables) == the reference's cost volume, bit for bit."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    got = np.full((h, w, D), np.nan, np.float32)
+    emul.emul_cost_window(P(left), P(right), P(o["census_left"]), P(o["census_right"]), P(got), w, h, dmin, D,
+                          opt.lambda_ad, opt.lambda_census, seg)
+    assert same(got, o["cost_init"])
+
+
 def test_register_ring_span_addressing(emul):
     """agg_reg_sum: one M0 value per block of 16 adds with static register numbers v40..v55, entered late -- every read
     lands on ring[idx .. idx+cnt) (registers v56+) in increasing order, for every start slot and span length."""
