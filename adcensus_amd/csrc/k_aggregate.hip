@@ -693,7 +693,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
         // full ring of a plain pass: in registers when it fits (ADC_AGG_REGRING=0: LDS ring)
         static const bool regring_env = env_int("ADC_AGG_REGRING", 1) != 0;
-        const bool regring = variant == 0 && !PAIR && regring_env && 2 * Lv + 1 <= AGG_RING_REGS;
+        const bool regring = variant == 0 && !PAIR && regring_env && Lv >= 1 && 2 * Lv + 1 <= AGG_RING_REGS;
         const size_t ring_bytes = regring ? 0 : (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
         const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + (PAIR ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
         const int waves_per_cu = regring ? 16 : adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
