@@ -22,7 +22,7 @@ STAGES = ["cost", "arms", "aggregate", "scanline", "wta", "refine"]
  BUF_VOLUME_A, BUF_DISP_LEFT, BUF_DISP_RIGHT, BUF_OUTLIER_LABEL) = range(11)
 (RUN_GRAY_CENSUS, RUN_COST, RUN_ARMS, RUN_AGGREGATE, RUN_SCANLINE, RUN_WTA, RUN_LRCHECK, RUN_REGION_VOTING,
  RUN_INTERPOLATION, RUN_DISCONTINUITY, RUN_MEDIAN) = range(11)
-MAX_DISP_RANGE = 256
+MAX_DISP_RANGE = 1024
 
 
 class ADCensusOption(C.Structure):
@@ -108,6 +108,8 @@ def lib():
     L.adc_debug_set_images.restype = C.c_int
     L.adc_debug_run.argtypes = [vp, C.c_int, C.c_int]
     L.adc_debug_run.restype = C.c_int
+    L.adc_debug_counter.argtypes = [vp, C.c_int]
+    L.adc_debug_counter.restype = C.c_int64
     L.adc_debug_voting_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.adc_debug_voting_stats.restype = C.c_int
     _lib = L
@@ -257,6 +259,9 @@ class ADCensusStereo:
         rc = lib().adc_debug_run(self._h, stage, arg)
         if rc != 0:
             raise RuntimeError("adc_debug_run(%d) failed: %s" % (stage, last_error()))
+
+    def debug_counter(self, which):
+        return int(lib().adc_debug_counter(self._h, which))
 
     def voting_stats(self):
         r, e = C.c_int64(0), C.c_int64(0)

@@ -82,15 +82,16 @@ ADC_HD int adc_so_penalty_class(int d1, int d2, int tso) { return (d1 >= tso ? 1
 //   rb       VPL consecutive bytes of the right-image step map starting at column max(xr_last, 1) (+1 on R->L)
 //   c1byte   left-image step d1 of this pixel
 //   xr_last  x - dmin - (d0 + VPL-1): right-image column of the lane's LAST disparity (the smallest column)
+// (rb = the fetched bytes as little-endian dwords: byte j = (rb[j >> 2] >> (8 * (j & 3))) & 0xff)
 template <int VPL>
-ADC_HD void adc_so_class_offsets(uint32_t rb, int c1byte, int xr_last, int W, int tso, bool row_ok, int* off)
+ADC_HD void adc_so_class_offsets(const uint32_t* rb, int c1byte, int xr_last, int W, int tso, bool row_ok, int* off)
 {
     const int c1 = c1byte >= tso ? 8 : 0;
     const int a0 = xr_last > 1 ? xr_last : 1;
     for (int k = 0; k < VPL; k++) {
         const int xr = xr_last + (VPL - 1 - k);
         const int j = (xr > 1 ? xr : 1) - a0; // 0 .. VPL-1: which of the fetched bytes is column max(xr, 1)
-        const int byte = (int)((rb >> (8 * j)) & 0xffu);
+        const int byte = (int)((rb[j >> 2] >> (8 * (j & 3))) & 0xffu);
         const int c2 = byte >= tso ? 8 : 0;
         const bool use_r = row_ok && xr < W - 1;
         off[k] = c1 + (use_r ? c2 : c1);
@@ -108,11 +109,12 @@ ADC_HD bool adc_so_interior(int x, int W, int dmin, int Dpad)
     return W >= 3 && x >= dmin + Dpad && x - dmin < W - 1;
 }
 template <int VPL>
-ADC_HD void adc_so_class_offsets_interior(uint32_t rb, int c1byte, int tso, int* off)
+ADC_HD void adc_so_class_offsets_interior(const uint32_t* rb, int c1byte, int tso, int* off)
 {
     const int c1 = c1byte >= tso ? 8 : 0; // wave-uniform
     for (int k = 0; k < VPL; k++) {
-        const int byte = (int)((rb >> (8 * (VPL - 1 - k))) & 0xffu);
+        const int j = VPL - 1 - k;
+        const int byte = (int)((rb[j >> 2] >> (8 * (j & 3))) & 0xffu);
         off[k] = byte >= tso ? c1 + 8 : c1;
     }
 }

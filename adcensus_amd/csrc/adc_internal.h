@@ -25,7 +25,7 @@
 struct AdcParams {
     int W, H;
     int dmin, dmax, D; // D = dmax - dmin
-    int VPL;           // disparities per lane (1,2,4)
+    int VPL;           // disparities per lane (1,2,4,8,16)
     int Dp;            // padded disparity count = 64*VPL
     adc_option opt;
 };
@@ -78,17 +78,20 @@ struct adc_handle {
     int wta_left_done;    // the scanline stage did so: adc_launch_wta only runs the right view
     float* med_hand;      // banded median: per-band hand-off rows [bands][med_hpitch], indexed by wavefront level
     int med_hpitch;
+    int force_median_fallback; // test hook (ADC_DEBUG_FORCE_MEDIAN_FALLBACK via adc_debug_run): adc_wait takes the fallback path
+    int median_fallbacks;      // how often adc_wait had to redo the median
     int32_t* pin_flags;   // pinned host word: error flag of the banded median's hand-off (read back after every Match)
     uint32_t* bgrx_l;     // left image packed B | G<<8 | R<<16 per pixel (interpolation gathers)
     int32_t* irv_state;  // int2 per pixel: {disparity bits, eligibility / finality stamp} of the current voting pass
     int32_t* vote_fin;   // finality stamps of the current voting pass (round+1 when the value became final)
     int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...
-    uint8_t *chg_a, *chg_b; // changed-tile maps (previous / next round)
+    uint8_t* chg_a;      // change-tile map of the voting rounds (int32 stamp per 8x8 tile)
     uint8_t* edge;       // discontinuity adjustment edge mask
     // pinned staging for adc_match / adc_match_async
     uint8_t* pin_in;  // 2 * 3*W*H
     float* pin_out;   // W*H
     float* async_dst;
+    void* device_dst;  // adc_match_device: the caller's device buffer (re-filled by the median fallback)
     // profiling
     int profiling, verbose;
     hipEvent_t ev[ADC_STAGE_COUNT + 1];
@@ -120,6 +123,7 @@ hipError_t adc_run_region_voting(adc_handle* h); // contains host-side convergen
 hipError_t adc_launch_interpolation(adc_handle* h);
 hipError_t adc_launch_discontinuity(adc_handle* h);
 hipError_t adc_launch_median(adc_handle* h);
+hipError_t adc_median_fallback(adc_handle* h); // after a hand-off time-out of the banded filter (adc_wait)
 // layout helpers for the debug surface
 hipError_t adc_launch_pad_volume(adc_handle* h, const float* src_HWD, float* dst_HWDp);
 hipError_t adc_launch_unpad_volume(adc_handle* h, const float* src_HWDp, float* dst_HWD);

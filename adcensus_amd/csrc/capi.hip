@@ -62,7 +62,9 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->img_r, P * 3));
     HIP_OK(hipMalloc(&h->gray_l, P));
     HIP_OK(hipMalloc(&h->bgrx_l, P * 4));
-    h->rrec_padl = (p.dmin + p.D - 1 > 0 ? p.dmin + p.D - 1 : 0) + 1;
+    // sized from the PADDED range: the fused-cost pass also marches over padding chunks / lanes (d >= D), whose
+    // right-image column x - d lies up to dmin + Dp - 1 columns to the left of the row
+    h->rrec_padl = (p.dmin + p.Dp - 1 > 0 ? p.dmin + p.Dp - 1 : 0) + 1;
     h->rrec_pitch = h->rrec_padl + p.W + (p.dmin < 0 ? -p.dmin : 0) + 1;
     HIP_OK(hipMalloc(&h->cost_rrec, (size_t)p.H * h->rrec_pitch * 16));
     HIP_OK(hipMalloc(&h->cost_lrec, P * 16));
@@ -77,10 +79,11 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->armmax, 4 * sizeof(int)));
     HIP_OK(hipMalloc(&h->rec_h, P * 4));
     HIP_OK(hipMalloc(&h->rec_v, P * 4));
-    HIP_OK(hipMalloc(&h->cdiff_lh, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
-    HIP_OK(hipMalloc(&h->cdiff_lv, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
-    HIP_OK(hipMalloc(&h->cdiff_rh, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
-    HIP_OK(hipMalloc(&h->cdiff_rv, P + 64)); // + slack: the scanline kernels fetch up to 4 bytes from the last element
+    // + slack: the scanline kernels fetch up to VPL (<= 16) bytes starting at a column <= W-1 (+1 on R->L passes)
+    HIP_OK(hipMalloc(&h->cdiff_lh, P + 64));
+    HIP_OK(hipMalloc(&h->cdiff_lv, P + 64));
+    HIP_OK(hipMalloc(&h->cdiff_rh, P + 64));
+    HIP_OK(hipMalloc(&h->cdiff_rv, P + 64));
     HIP_OK(hipMalloc(&h->so_cls, adc_so_cls_bytes(p.W, p.H)));
     HIP_OK(hipMalloc(&h->vol_a, VB));
     HIP_OK(hipMalloc(&h->vol_b, VB));
@@ -100,15 +103,13 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
     const size_t tiles = (size_t)((p.W + 7) / 8) * ((p.H + 7) / 8);
     HIP_OK(hipMalloc(&h->chg_a, tiles * 4));
-    HIP_OK(hipMalloc(&h->chg_b, tiles * 4));
     HIP_OK(hipMalloc(&h->edge, P));
     HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_flags, 64, hipHostMallocDefault));
     memset(h->pin_flags, 0, 64);
     HIP_OK(hipMemset(h->label, 0, P));
-    HIP_OK(hipMemset(h->chg_a, 0, tiles));
-    HIP_OK(hipMemset(h->chg_b, 0, tiles));
+    HIP_OK(hipMemset(h->chg_a, 0, tiles * 4));
     HIP_OK(hipMemset(h->vol_a, 0, VB));
     HIP_OK(hipMemset(h->vol_b, 0, VB));
     return hipSuccess;
@@ -203,7 +204,7 @@ adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int
     h->device = dev;
     h->p.W = width; h->p.H = height;
     h->p.dmin = opt->min_disparity; h->p.dmax = opt->max_disparity; h->p.D = (int)range;
-    h->p.VPL = range <= 64 ? 1 : (range <= 128 ? 2 : 4);
+    h->p.VPL = range <= 64 ? 1 : (range <= 128 ? 2 : (range <= 256 ? 4 : (range <= 512 ? 8 : 16)));
     h->p.Dp = 64 * h->p.VPL;
     h->p.opt = *opt;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
@@ -234,7 +235,7 @@ void adc_destroy(adc_handle* h)
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
-                    h->chg_a, h->chg_b, h->edge};
+                    h->chg_a, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
     if (h->pin_out) hipHostFree(h->pin_out);
@@ -387,6 +388,7 @@ int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, voi
     if (hipMemcpyAsync(h->img_r, d_right, P * 3, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
     if (run_pipeline(h) != hipSuccess) return 2;
     if (hipMemcpyAsync(d_disp, h->disp_l, P * 4, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
+    h->device_dst = d_disp;
     return 0;
 }
 
@@ -410,11 +412,19 @@ int adc_wait(adc_handle* h)
     if (!h) return 1;
     hipSetDevice(h->device);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("adc_wait", hipGetLastError()); return 2; }
-    if (h->pin_flags && h->pin_flags[0] != 0) { // a median band gave up waiting for its upstream band: the map is incomplete
+    if (h->pin_flags && (h->pin_flags[0] != 0 || h->force_median_fallback)) {
+        // a median band gave up waiting for its upstream band: the map is incomplete -- redo the filter with the
+        // single-workgroup kernel (no inter-workgroup dependency) and deliver that result
         h->pin_flags[0] = 0;
-        g_last_error = "adc_wait: median filter hand-off timed out";
-        return 2;
+        const size_t P = (size_t)h->p.W * h->p.H;
+        hipError_t e = adc_median_fallback(h);
+        if (e == hipSuccess && h->async_dst) e = hipMemcpy(h->pin_out, h->disp_l, P * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && h->device_dst) e = hipMemcpy(h->device_dst, h->disp_l, P * 4, hipMemcpyDeviceToDevice);
+        h->median_fallbacks++;
+        if (e != hipSuccess) { set_error("adc_wait: median fallback", e); return 2; }
     }
+    h->device_dst = nullptr;
+    h->force_median_fallback = 0;
     if (h->async_dst) {
         memcpy(h->async_dst, h->pin_out, (size_t)h->p.W * h->p.H * 4);
         h->async_dst = nullptr;
@@ -560,13 +570,22 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
         h->fuse_cost = 0;
         h->armmax_valid = 0;
         break;
-    case ADC_RUN_SCANLINE: e = adc_launch_scanline(h, arg); break;
+    case ADC_RUN_SCANLINE: // arg = passes (default 4); arg >= 100: the production form of the last pass, which also
+                           // writes the left-view disparity map (ADC_BUF_DISP_LEFT) -- ADC_RUN_WTA then only adds the right view
+        h->fuse_wta = arg >= 100 ? 1 : 0;
+        h->wta_left_done = 0;
+        e = adc_launch_scanline(h, arg >= 100 ? arg - 100 : arg);
+        h->fuse_wta = 0;
+        break;
     case ADC_RUN_WTA: e = adc_launch_wta(h); break;
     case ADC_RUN_LRCHECK: e = adc_launch_lrcheck(h); break;
     case ADC_RUN_REGION_VOTING: e = adc_run_region_voting(h); break;
     case ADC_RUN_INTERPOLATION: e = adc_launch_interpolation(h); break;
     case ADC_RUN_DISCONTINUITY: e = adc_launch_discontinuity(h); break;
-    case ADC_RUN_MEDIAN: e = adc_launch_median(h); break;
+    case ADC_RUN_MEDIAN: // arg 100: test hook -- arm the fallback path of the NEXT adc_wait (as if a band had timed out)
+        if (arg == 100) { h->force_median_fallback = 1; return 0; }
+        e = adc_launch_median(h);
+        break;
     default: return 1;
     }
     if (e != hipSuccess) { set_error("adc_debug_run launch", e); return 2; }
@@ -574,6 +593,15 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { set_error("adc_debug_run sync", e); return 2; }
     return 0;
+}
+
+int64_t adc_debug_counter(adc_handle* h, int which)
+{
+    if (!h) return -1;
+    switch (which) {
+    case 0: return h->median_fallbacks;
+    default: return -1;
+    }
 }
 
 int adc_debug_voting_stats(adc_handle* h, int64_t* rounds, int64_t* evaluations)

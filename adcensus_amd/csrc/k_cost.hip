@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256) void k_cost(const uint8_t* __restrict__ img_l,
         float* dst = vol + ((size_t)y * W + x) * Dp + lane * VPL;
         if constexpr (VPL == 1) dst[0] = out[0];
         else if constexpr (VPL == 2) *reinterpret_cast<float2*>(dst) = make_float2(out[0], out[1]);
-        else *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+        else {
+#pragma unroll
+            for (int q = 0; q < VPL; q += 4) *reinterpret_cast<float4*>(dst + q) = make_float4(out[q], out[q + 1], out[q + 2], out[q + 3]);
+        }
     }
 }
 
@@ -149,7 +152,9 @@ hipError_t adc_launch_cost(adc_handle* h, float* vol_out)
                        h->lut_census, vol_out, p.W, p.H, p.dmin, p.D)
     if (p.VPL == 1) LAUNCH(1);
     else if (p.VPL == 2) LAUNCH(2);
-    else LAUNCH(4);
+    else if (p.VPL == 4) LAUNCH(4);
+    else if (p.VPL == 8) LAUNCH(8);
+    else LAUNCH(16);
 #undef LAUNCH
     return hipGetLastError();
 }

@@ -227,9 +227,9 @@ __global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ wo
         if (counters[IRV_FLAG(round - 1)] == 0) return;
         n = counters[IRV_NDIRTY(round)];
     }
-    __shared__ int hist_all[4][ADC_MAX_DISP_RANGE];
+    extern __shared__ int hist_all[]; // [4][D]: one histogram per wave (dynamic: 4 * D * 4 bytes)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int* hist = hist_all[wave];
+    int* hist = hist_all + wave * D;
     const int tiles_x = (W + IRV_TILE - 1) / IRV_TILE;
     const int nwaves = gridDim.x * 4;
     for (int e = blockIdx.x * 4 + wave; e < n; e += nwaves) {
@@ -379,7 +379,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
                                            reinterpret_cast<const uchar4*>(h->irv_bbox), h->vote_dirty, h->vote_counters, p.W,
                                            p.H, round, h->vote_fin);
 #define IRV_VOTE(U_, J_)                                                                                              \
-    hipLaunchKernelGGL((k_irv_vote<U_, J_>), dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), 0, h->stream, \
+    hipLaunchKernelGGL((k_irv_vote<U_, J_>), dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), (size_t)4 * p.D * sizeof(int), h->stream, \
                        round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,                              \
                        reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,        \
                        p.opt.irv_ts, p.opt.irv_th, round, h->vote_fin, reinterpret_cast<int2*>(h->irv_state))
@@ -696,26 +696,36 @@ __global__ __launch_bounds__(256) void k_edge_detect(const float* __restrict__ d
 }
 
 // One thread per row: the fix-up is sequential along x (multistep_refiner.cpp:322-350).  The cost index
-// is lround(d) WITHOUT "- min_disparity" exactly like the reference (:329-331,:340).
+// is lround(d) WITHOUT "- min_disparity" exactly like the reference (:329-331,:340): with min_disparity != 0 that
+// index leaves the pixel's own cost row and lands in a neighbouring pixel's (flat [H][W][D] addressing), so the
+// reference's flat element index is mapped back to (pixel, d) of the padded layout.  Indices outside the volume
+// (undefined behaviour in the reference; cannot occur on edge pixels, which have 1 <= y <= H-2) are clamped.
+__device__ __forceinline__ float dda_cost(const float* __restrict__ vol, long long flat, long long total, int D, int Dp)
+{
+    flat = flat < 0 ? 0 : (flat >= total ? total - 1 : flat);
+    const long long pix = flat / D;
+    return vol[pix * Dp + (flat - pix * D)];
+}
 __global__ void k_discontinuity_rows(float* __restrict__ disp, const uint8_t* __restrict__ edge, const float* __restrict__ vol,
-                                     int W, int H, int Dp)
+                                     int W, int H, int D, int Dp)
 {
     const int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= H) return;
     float* row = disp + (size_t)y * W;
+    const long long total = (long long)W * H * D;
     for (int x = 1; x < W - 1; x++) {
         if (edge[(size_t)y * W + x] != 1) continue;
         const float d = row[x];
         if (d == ADC_INVALID_FLOAT) continue;
         const long di = lroundf(d);
-        const float* cp = vol + ((size_t)y * W + x) * Dp;
-        float c0 = cp[di];
+        const long long base = ((long long)y * W + x) * D; // cost_ptr of the reference (:330)
+        float c0 = dda_cost(vol, base + di, total, D, Dp);
         for (int k = 0; k < 2; k++) {
             const int x2 = k == 0 ? x - 1 : x + 1;
             const float d2 = row[x2];
             if (d2 == ADC_INVALID_FLOAT) continue;
             const long d2i = lroundf(d2);
-            const float c = k == 0 ? cp[-Dp + d2i] : cp[Dp + d2i];
+            const float c = dda_cost(vol, base + (k == 0 ? -(long long)D : (long long)D) + d2i, total, D, Dp);
             if (c < c0) { row[x] = d2; c0 = c; }
         }
     }
@@ -727,7 +737,7 @@ hipError_t adc_launch_discontinuity(adc_handle* h)
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_edge_detect, grid, block, 0, h->stream, h->disp_l, h->edge, p.W, p.H, 5.0f);
     hipLaunchKernelGGL(k_discontinuity_rows, dim3((p.H + 63) / 64), dim3(64), 0, h->stream, h->disp_l, h->edge, h->vol_a, p.W,
-                       p.H, p.Dp);
+                       p.H, p.D, p.Dp);
     return hipGetLastError();
 }
 
@@ -1002,7 +1012,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
 #undef MEDB_TAKE8
 }
 
-hipError_t adc_launch_median(adc_handle* h)
+static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float* out)
 {
     const AdcParams& p = h->p;
     static bool attr_set = false;
@@ -1013,6 +1023,19 @@ hipError_t adc_launch_median(adc_handle* h)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    const size_t lds = (size_t)p.H * 4 * sizeof(float);
+    if (p.H > 8192) return hipErrorInvalidValue; // LDS ring of H*16 B and <= 8 rows per thread
+    const int rpt = (p.H + 1023) / 1024;
+    if (rpt <= 1) hipLaunchKernelGGL(k_median_wavefront<1>, dim3(1), dim3(1024), lds, h->stream, in, out, p.W, p.H);
+    else if (rpt <= 2) hipLaunchKernelGGL(k_median_wavefront<2>, dim3(1), dim3(1024), lds, h->stream, in, out, p.W, p.H);
+    else if (rpt <= 4) hipLaunchKernelGGL(k_median_wavefront<4>, dim3(1), dim3(1024), lds, h->stream, in, out, p.W, p.H);
+    else hipLaunchKernelGGL(k_median_wavefront<8>, dim3(1), dim3(1024), lds, h->stream, in, out, p.W, p.H);
+    return hipGetLastError();
+}
+
+hipError_t adc_launch_median(adc_handle* h)
+{
+    const AdcParams& p = h->p;
     static const bool banded = [] { const char* e = getenv("ADC_MEDIAN_BANDED"); return e ? atoi(e) != 0 : true; }();
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
     if (banded && nbands > 1 && nbands <= 256 && p.W >= 2 && p.H >= 2 && h->med_hand) {
@@ -1028,15 +1051,21 @@ hipError_t adc_launch_median(adc_handle* h)
         h->disp_tmp = t;
         return hipGetLastError();
     }
-    const size_t lds = (size_t)p.H * 4 * sizeof(float);
-    if (p.H > 8192) return hipErrorInvalidValue; // LDS ring of H*16 B and <= 8 rows per thread
-    const int rpt = (p.H + 1023) / 1024;
-    if (rpt <= 1) hipLaunchKernelGGL(k_median_wavefront<1>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
-    else if (rpt <= 2) hipLaunchKernelGGL(k_median_wavefront<2>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
-    else if (rpt <= 4) hipLaunchKernelGGL(k_median_wavefront<4>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
-    else hipLaunchKernelGGL(k_median_wavefront<8>, dim3(1), dim3(1024), lds, h->stream, h->disp_l, h->disp_tmp, p.W, p.H);
+    hipError_t e = launch_median_wavefront(h, h->disp_l, h->disp_tmp);
+    if (e != hipSuccess) return e;
     float* t = h->disp_l;
     h->disp_l = h->disp_tmp;
     h->disp_tmp = t;
     return hipGetLastError();
+}
+
+// The banded filter reported a hand-off time-out (a band gave up waiting for its upstream band; cannot happen while all
+// bands are co-resident, but the spin is bounded on principle): redo the filter with the single-workgroup wavefront
+// kernel, which has no inter-workgroup dependency.  The unfiltered input is still intact in disp_tmp (the filter writes
+// to the other buffer).  Called by adc_wait after the stream has drained.
+hipError_t adc_median_fallback(adc_handle* h)
+{
+    hipError_t e = launch_median_wavefront(h, h->disp_tmp, h->disp_l);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(h->stream);
 }

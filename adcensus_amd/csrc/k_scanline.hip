@@ -83,14 +83,23 @@ __device__ __forceinline__ void vload(const float* p, float* r)
 {
     if constexpr (VPL == 1) r[0] = p[0];
     else if constexpr (VPL == 2) { const float2 v = *reinterpret_cast<const float2*>(p); r[0] = v.x; r[1] = v.y; }
-    else { const float4 v = *reinterpret_cast<const float4*>(p); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+    else {
+#pragma unroll
+        for (int q = 0; q < VPL; q += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p + q);
+            r[q] = v.x; r[q + 1] = v.y; r[q + 2] = v.z; r[q + 3] = v.w;
+        }
+    }
 }
 template <int VPL>
 __device__ __forceinline__ void vstore(float* p, const float* r)
 {
     if constexpr (VPL == 1) p[0] = r[0];
     else if constexpr (VPL == 2) *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]);
-    else *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    else {
+#pragma unroll
+        for (int q = 0; q < VPL; q += 4) *reinterpret_cast<float4*>(p + q) = make_float4(r[q], r[q + 1], r[q + 2], r[q + 3]);
+    }
 }
 
 // ------------------------------------------------------------------------------ penalty classes
@@ -172,9 +181,9 @@ hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream)
 
 template <int VPL>
 struct SoElem {
-    float c[VPL];  // data term
-    uint32_t rb;   // right-image step bytes (see so_class_offsets)
-    int c1;        // left-image step byte d1
+    float c[VPL];                // data term
+    uint32_t rb[(VPL + 3) / 4];  // right-image step bytes, little-endian dwords (see adc_so_class_offsets)
+    int c1;                      // left-image step byte d1
 };
 
 struct SoGeom {
@@ -195,7 +204,8 @@ __device__ __forceinline__ int so_rmap_offset(const SoGeom& g, int i, int cl_las
     const int m = g.dir > 0 ? i : g.plen - 1 - i;
     const int x = VERT ? g.path : m, y = VERT ? m : g.path;
     const int sy = VERT ? (g.dir > 0 ? y : y + 1) : y;
-    const int xr = x - cl_last;
+    int xr = x - cl_last; // (negative min_disparity: up to x + |dmin| -- columns >= W-1 are never used by the class rule)
+    xr = xr > g.W - 1 ? g.W - 1 : xr;
     return sy * g.W + (xr > 1 ? xr : 1) + ((!VERT && g.dir < 0) ? 1 : 0);
 }
 // same, from the coordinate m of the path element (x on a row path, y on a column path)
@@ -204,7 +214,8 @@ __device__ __forceinline__ int so_rmap_offset_m(const SoGeom& g, int m, int cl_l
 {
     const int x = VERT ? g.path : m, y = VERT ? m : g.path;
     const int sy = VERT ? (g.dir > 0 ? y : y + 1) : y;
-    const int xr = x - cl_last;
+    int xr = x - cl_last;
+    xr = xr > g.W - 1 ? g.W - 1 : xr;
     return sy * g.W + (xr > 1 ? xr : 1) + ((!VERT && g.dir < 0) ? 1 : 0);
 }
 template <int VPL>
@@ -213,6 +224,15 @@ __device__ __forceinline__ uint32_t so_rmap_load(const uint8_t* __restrict__ rma
     if constexpr (VPL == 1) return rmap[off];
     else if constexpr (VPL == 2) { uint16_t v; __builtin_memcpy(&v, rmap + off, 2); return v; }
     else { uint32_t v; __builtin_memcpy(&v, rmap + off, 4); return v; }
+}
+template <int VPL>
+__device__ __forceinline__ void so_rmap_load_words(const uint8_t* __restrict__ rmap, int off, uint32_t* w)
+{
+    if constexpr (VPL <= 4) w[0] = so_rmap_load<VPL>(rmap, off);
+    else {
+#pragma unroll
+        for (int q = 0; q < VPL / 4; q++) __builtin_memcpy(&w[q], rmap + off + 4 * q, 4);
+    }
 }
 
 // VERT=false: path = image row `path`, marching in x.  VERT=true: path = column, marching in y.
@@ -443,7 +463,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         }                                                                                                      \
         if constexpr (VPL == 1) (E).c[0] = tc_;                                                                \
         else { (E).c[0] = tc_.x; (E).c[VPL - 1] = tc_.y; }                                                     \
-        (E).rb = tr_;                                                                                          \
+        (E).rb[0] = tr_;                                                                                       \
         (E).c1 = (int)((cw >> (8 * ((U)&3))) & 0xffu);                                                         \
     } while (0)
 // one full step of the pipelined loop: take, re-issue the slot for the element PF ahead, DP step
@@ -511,26 +531,27 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         auto so_load = [&](int i) __attribute__((always_inline)) {
             SoElem<VPL> e;
             vload<VPL>(src + so_pixel<VERT>(g, i) * Dp + g.d0, e.c);
-            e.rb = so_rmap_load<VPL>(rmap, so_rmap_offset<VPL, VERT>(g, i, cl_last, 0));
+            so_rmap_load_words<VPL>(rmap, so_rmap_offset<VPL, VERT>(g, i, cl_last, 0), e.rb);
             e.c1 = (int)((c1p[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xffu);
             return e;
         };
-        SoElem<VPL> pre[SO_PF];
+        constexpr int SO_PFV = VPL <= 4 ? SO_PF : (VPL == 8 ? 8 : 4); // register budget: SO_PFV * (VPL + 2) per lane
+        SoElem<VPL> pre[SO_PFV];
 #pragma unroll
-        for (int u = 0; u < SO_PF; u++) pre[u] = so_load(adc_imin(1 + u, g.plen - 1));
+        for (int u = 0; u < SO_PFV; u++) pre[u] = so_load(adc_imin(1 + u, g.plen - 1));
         int i = 1;
-        for (; i + SO_PF <= g.plen; i += SO_PF) {
+        for (; i + SO_PFV <= g.plen; i += SO_PFV) {
 #pragma unroll
-            for (int u = 0; u < SO_PF; u++) {
+            for (int u = 0; u < SO_PFV; u++) {
                 const SoElem<VPL> cur = pre[u];
-                pre[u] = so_load(adc_imin(i + u + SO_PF, g.plen - 1));
+                pre[u] = so_load(adc_imin(i + u + SO_PFV, g.plen - 1));
                 __builtin_amdgcn_sched_barrier(0);
                 SO_STEP(i + u, cur);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
-        for (int u = 0; u < SO_PF; u++) {
+        for (int u = 0; u < SO_PFV; u++) {
             if (i + u < g.plen) SO_STEP(i + u, pre[u]);
         }
     }
@@ -604,5 +625,7 @@ hipError_t adc_launch_scanline(adc_handle* h, int passes)
     if (passes <= 0 || passes > 4) passes = 4;
     if (h->p.VPL == 1) return run_so<1>(h, passes);
     if (h->p.VPL == 2) return run_so<2>(h, passes);
-    return run_so<4>(h, passes);
+    if (h->p.VPL == 4) return run_so<4>(h, passes);
+    if (h->p.VPL == 8) return run_so<8>(h, passes);
+    return run_so<16>(h, passes);
 }

@@ -21,13 +21,14 @@ __device__ __forceinline__ void wave_argmin(float& c, int& d)
     }
 }
 
-#define WTA_PPW 8 // pixels per wave: their loads are all issued before the first reduction
+#define WTA_PPW_MAX 8 // pixels per wave: their loads are all issued before the first reduction
 
 template <int VPL, bool RIGHT>
 __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, float* __restrict__ disp, int W, int H, int dmin,
                                              int D)
 {
     constexpr int Dp = 64 * VPL;
+    constexpr int WTA_PPW = VPL <= 4 ? WTA_PPW_MAX : (VPL == 8 ? 4 : 2); // (register budget: WTA_PPW * VPL costs per lane)
     const int lane = threadIdx.x & 63;
     const long long P = (long long)W * H;
     const long long pix0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * WTA_PPW;
@@ -150,7 +151,8 @@ hipError_t adc_launch_wta(adc_handle* h)
 {
     const AdcParams& p = h->p;
     const long long P = (long long)p.W * p.H;
-    const unsigned blocks = (unsigned)((P + 4 * WTA_PPW - 1) / (4 * WTA_PPW));
+    const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : 2); // == k_wta's WTA_PPW
+    const unsigned blocks = (unsigned)((P + 4 * wta_ppw - 1) / (4 * wta_ppw));
     static const bool band = [] { const char* e = getenv("ADC_WTA_BAND"); return e ? atoi(e) != 0 : true; }();
     const bool left = !h->wta_left_done; // the last scanline pass of the pipeline already produced the left view
     h->wta_left_done = 0;
@@ -165,7 +167,9 @@ hipError_t adc_launch_wta(adc_handle* h)
     } while (0)
     if (p.VPL == 1) LAUNCH(1);
     else if (p.VPL == 2) LAUNCH(2);
-    else LAUNCH(4);
+    else if (p.VPL == 4) LAUNCH(4);
+    else if (p.VPL == 8) LAUNCH(8);
+    else LAUNCH(16);
 #undef LAUNCH
     return hipGetLastError();
 }

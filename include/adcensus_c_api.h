@@ -71,10 +71,11 @@ const char* adc_last_error(void);
 /*
  * Initialize.  Returns NULL when the reference's Initialize returns false
  * (width<=0 || height<=0, ADCensusStereo.cpp:31-33; max_disparity-min_disparity<=0, :38-40),
- * on a HIP failure, or when the disparity range exceeds ADC_MAX_DISP_RANGE.
+ * on a HIP failure (including out of memory), or when the disparity range exceeds ADC_MAX_DISP_RANGE
+ * (1024 = 16 disparities per lane; the reference accepts any positive range, larger ones return NULL here).
  * device < 0 means "current device".  All device scratch is allocated here, once.
  */
-#define ADC_MAX_DISP_RANGE 256
+#define ADC_MAX_DISP_RANGE 1024
 adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int device);
 void adc_destroy(adc_handle* h);
 
@@ -172,9 +173,14 @@ enum {
     ADC_RUN_COUNT
 };
 /* Runs ONE stage on the handle's current device buffers and synchronizes. `arg` is stage
- * specific (ADC_RUN_AGGREGATE: number of iterations, 0 -> 4; ADC_RUN_SCANLINE: number of
- * chained passes 1..4, 0 -> 4; else ignored). */
+ * specific (ADC_RUN_AGGREGATE: number of iterations, 0 -> 4, +100 fused cost, +200 host-chosen
+ * ring / pass pairs; ADC_RUN_SCANLINE: number of chained passes 1..4, 0 -> 4, +100 = the
+ * production form whose last pass also writes DISP_LEFT (the fused left-view winner-takes-all);
+ * ADC_RUN_MEDIAN: 100 = do not run, arm the fallback path of the next adc_wait; else ignored). */
 int adc_debug_run(adc_handle* h, int stage, int arg);
+/* Test-only event counters: which = 0 -> number of times adc_wait had to redo the median filter
+ * with the single-workgroup kernel (hand-off time-out of the banded kernel). */
+int64_t adc_debug_counter(adc_handle* h, int which);
 /* Statistics of the last region-voting run: total fixed-point rounds over the 10 passes and
  * total vote evaluations. */
 int adc_debug_voting_stats(adc_handle* h, int64_t* rounds, int64_t* evaluations);

@@ -17,11 +17,9 @@ def cone_pair():
 
 
 def data_pair(name):
-    """cloth3 / piano / wood2 from tests/golden/_data (git-ignored copies of the reference Data/ PNGs)."""
-    p = os.path.join(GOLDEN_DIR, "_data", name + "_pair.npz")
-    if not os.path.exists(p):
-        return None
-    z = np.load(p)
+    """cloth3 / piano / wood2: the other pairs of the reference's Data/ directory, committed as BGR arrays
+    (tests/golden/<name>_pair.npz, written by tools/make_golden.py; PNG decode is lossless)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + "_pair.npz"))
     return np.ascontiguousarray(z["left"]), np.ascontiguousarray(z["right"])
 
 
@@ -62,11 +60,44 @@ _CASES = {
     "noise_160x90_d128": (lambda: workloads.noise_pair(160, 90, seed=23), dict(max_disparity=128)),
     "noise_150x40_d256": (lambda: workloads.noise_pair(150, 40, seed=24), dict(max_disparity=256)),
     "s2_150x100_neg": (lambda: workloads.structured_pair(150, 100, 48, seed=22), dict(min_disparity=-8, max_disparity=40)),
+    # min_disparity > 0: the right-view WTA, the fused-cost record padding and the scanline
+    # interior test all have dmin-dependent branches.  (The reference reads out of bounds in the last min_disparity
+    # columns of the right-view map, ADCensusStereo.cpp:296-300: those columns are excluded, see canonical().)
+    "cone_pos": (cone_pair, dict(min_disparity=8, max_disparity=72)),
+    "q_40x30_pos_wltd": (lambda: workloads.quantized_noise_pair(40, 30, 64, seed=25), dict(min_disparity=5, max_disparity=69)),
+    "noise_160x90_d128_pos": (lambda: workloads.noise_pair(160, 90, seed=26), dict(min_disparity=3, max_disparity=131)),
+    "s2_150x100_pos": (lambda: workloads.structured_pair(150, 100, 48, seed=27), dict(min_disparity=4, max_disparity=52)),
+    # 128 < D < 192: four disparities per lane with a last 64-disparity chunk that is all padding
+    "s2_200x120_d160": (lambda: workloads.structured_pair(200, 120, 160, seed=28), dict(max_disparity=160)),
+    "noise_96x50_d160_neg": (lambda: workloads.noise_pair(96, 50, seed=29), dict(min_disparity=-70, max_disparity=90)),
+    # disparity ranges above 256 (chunked voting histogram, 8 disparities per lane)
+    "s2_360x60_d300": (lambda: workloads.structured_pair(360, 60, 300, seed=30), dict(max_disparity=300)),
+    "noise_80x40_d520": (lambda: workloads.noise_pair(80, 40, seed=31), dict(min_disparity=-10, max_disparity=510)),
+    # discontinuity adjustment with min_disparity != 0: the reference indexes the cost row with the ABSOLUTE
+    # disparity (multistep_refiner.cpp:331-339), i.e. it reads the neighbouring pixel's costs
+    "cone_crop_dda_neg": (lambda: _crop(cone_pair(), 100, 231, 120, 377), dict(min_disparity=-6, max_disparity=40, do_discontinuity_adjustment=1)),
+    "cone_crop_dda_pos": (lambda: _crop(cone_pair(), 100, 231, 120, 377), dict(min_disparity=3, max_disparity=43, do_discontinuity_adjustment=1)),
+    # the other Middlebury pairs of the reference's Data/ directory, ranges from Data/*/d_range.txt
+    "cloth3": (lambda: data_pair("cloth3"), dict(max_disparity=128)),
+    "piano": (lambda: data_pair("piano"), dict(max_disparity=64)),
+    "wood2": (lambda: data_pair("wood2"), dict(max_disparity=128)),
 }
 GOLDEN_CASES = list(_CASES.keys())
 # subset that the CPU-only tier recomputes with the port (kept small: the whole CPU suite must run in minutes)
 FAST_CASES = ["cone_crop_d40", "s2_96x64_d32", "q_257x131_d64", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8",
-              "q_40x1_d8", "q_3x3_d2", "noise_128x72_d64", "s2_150x100_neg", "s2_200x120_d200", "noise_160x90_d128"]
+              "q_40x1_d8", "q_3x3_d2", "noise_128x72_d64", "s2_150x100_neg", "s2_200x120_d200", "noise_160x90_d128",
+              "q_40x30_pos_wltd", "noise_160x90_d128_pos", "s2_150x100_pos", "s2_200x120_d160", "noise_96x50_d160_neg",
+              "s2_360x60_d300", "noise_80x40_d520", "cone_crop_dda_neg", "cone_crop_dda_pos"]
+
+
+def canonical(stage, arr, opt):
+    """The part of a stage dump that is defined behaviour of the reference: for min_disparity > 0 the right-view
+    WTA map's last min_disparity columns come from an out-of-bounds read (ADCensusStereo.cpp:296-300 with
+    best_disparity still 0) and are left out of hashes and comparisons.  (They are never consumed: the LR check
+    reads column lround(x - d) <= W - 1 - min_disparity.)"""
+    if stage == "disp_right_wta" and opt.min_disparity > 0:
+        return np.ascontiguousarray(arr[:, :max(0, arr.shape[1] - opt.min_disparity)])
+    return arr
 
 
 def make_case(name):

@@ -257,7 +257,9 @@ void emul_cost_window(const uint8_t* img_l, const uint8_t* img_r, const uint64_t
     float A[768] = {0}, C[64];
     for (int k = 0; k <= 765; k++) A[k] = (1.0f - expf(-((float)k / 3.0f) / (float)lambda_ad)) + 1.0f;
     for (int hm = 0; hm < 64; hm++) C[hm] = expf(-(float)hm / (float)lambda_census);
-    const int padl = (dmin + D - 1 > 0 ? dmin + D - 1 : 0) + 1;
+    // the product's padded range (capi.hip): 64 * VPL, VPL in {1,2,4,8,16} -- for 128 < D <= 192 the last chunk is all padding
+    const int Dp = D <= 64 ? 64 : (D <= 128 ? 128 : (D <= 256 ? 256 : (D <= 512 ? 512 : 1024)));
+    const int padl = (dmin + Dp - 1 > 0 ? dmin + Dp - 1 : 0) + 1; // sized from Dp: padding chunks march too
     const int pitch = padl + W + (dmin < 0 ? -dmin : 0) + 1;
     struct Rec { uint32_t b, c0, c1; };
     auto pack = [](const uint8_t* px) { return (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16); };
@@ -267,7 +269,6 @@ void emul_cost_window(const uint8_t* img_l, const uint8_t* img_r, const uint64_t
         return s_;
     };
     std::vector<Rec> rrow(pitch), lrow(W);
-    const int Dp = (D + 63) / 64 * 64;
     if (seg_len < 1) seg_len = W;
     for (int y = 0; y < H; y++) {
         for (int i = 0; i < pitch; i++) {
@@ -294,7 +295,7 @@ void emul_cost_window(const uint8_t* img_l, const uint8_t* img_r, const uint64_t
                 }
                 for (int x = lo; x < hi; x++) {
                     for (int lane = 63; lane > 0; lane--) win[lane] = win[lane - 1]; // wave_shr:1
-                    win[0] = rrow[padl - d_first + x];                                 // column x - d_first
+                    win[0] = rrow.at(padl - d_first + x);                              // column x - d_first (bounds-checked: the kernel does not clamp)
                     for (int lane = 0; lane < 64; lane++) {
                         const int d = chunk * 64 + lane;
                         if (d >= D) continue; // padding lanes write 0 into the padded volume
@@ -424,8 +425,8 @@ static void scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_
             for (int lane = 0; lane < 64; lane++) {
                 const int cl_last = lane * VPL + VPL - 1 + dmin, xr_last = x - cl_last;
                 const size_t off = (size_t)sy * W + (xr_last > 1 ? xr_last : 1) + shift;
-                uint32_t rb = 0;
-                for (int j = 0; j < VPL; j++) rb |= (uint32_t)rmap[off + j] << (8 * j);
+                uint32_t rb[(VPL + 3) / 4] = {0};
+                for (int j = 0; j < VPL; j++) rb[j >> 2] |= (uint32_t)rmap[off + j] << (8 * (j & 3));
                 int o8[VPL];
                 // the kernel takes the interior form whenever the wave-uniform test allows it
                 const int Dpad = (D + VPL - 1) / VPL * VPL;
@@ -455,7 +456,9 @@ void emul_scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_le
 {
     if (D <= 64) scanline_pass_lanes<1>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
     else if (D <= 128) scanline_pass_lanes<2>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
-    else scanline_pass_lanes<4>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
+    else if (D <= 256) scanline_pass_lanes<4>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
+    else if (D <= 512) scanline_pass_lanes<8>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
+    else scanline_pass_lanes<16>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2);
 }
 
 // ------------------------------------------------------------------ k_wta_right_band

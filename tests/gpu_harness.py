@@ -80,13 +80,21 @@ def stage_report(left, right, opt, o, device=0):
         st.debug_run(A.RUN_SCANLINE, 4)
         rec("cost_so", st.debug_read(A.BUF_VOLUME_A), o["cost_so"])
 
+        # production form of the scanline stage: the last pass also delivers the left-view winner-takes-all
+        # (ADCensusStereo::ComputeDisparity, ADCensusStereo.cpp:188-243) -- isolated: oracle cost_aggr in, both
+        # the optimised volume and the left disparity map compared
+        st.debug_write(A.BUF_VOLUME_A, o["cost_aggr"])
+        st.debug_write(A.BUF_DISP_LEFT, np.full((h, w), -7.0, np.float32))
+        st.debug_run(A.RUN_SCANLINE, 104)
+        rec("cost_so(fused wta)", st.debug_read(A.BUF_VOLUME_A), o["cost_so"])
+        rec("disp_left_wta(fused in scanline)", st.debug_read(A.BUF_DISP_LEFT), o["disp_left_wta"])
+
         st.debug_write(A.BUF_VOLUME_A, o["cost_so"])
         st.debug_run(A.RUN_WTA)
         rec("disp_left_wta", st.debug_read(A.BUF_DISP_LEFT), o["disp_left_wta"])
-        got_r, want_r = st.debug_read(A.BUF_DISP_RIGHT), o["disp_right_wta"]
-        if opt.min_disparity > 0:  # reference reads out of bounds there (last dmin columns): not comparable
-            got_r, want_r = got_r[:, :max(0, w - opt.min_disparity)], want_r[:, :max(0, w - opt.min_disparity)]
-        rec("disp_right_wta", got_r, want_r)
+        # (min_disparity > 0: the reference reads out of bounds in the last dmin columns -> cases.canonical)
+        rec("disp_right_wta", cases.canonical("disp_right_wta", st.debug_read(A.BUF_DISP_RIGHT), opt),
+            cases.canonical("disp_right_wta", o["disp_right_wta"], opt))
 
         if opt.do_lr_check:
             st.debug_write(A.BUF_DISP_LEFT, o["disp_left_wta"])

@@ -69,3 +69,21 @@ def test_product_does_not_reference_oracle():
                     if re.search(r"(from|import)\s+oracle|oracle/|pyoracle|libadcensus_(ref|port)", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_types_header_is_source_compatible(tmp_path):
+    """include/adcensus_types.h provides every name the reference's adcensus_types.h puts into the global namespace
+    (adcensus_types.h:12-17,21-42,45-86): a translation unit that uses all of them compiles against include/ alone."""
+    import subprocess
+    src = tmp_path / "names.cpp"
+    src.write_text(
+        '#include "ADCensusStereo.h"\n'
+        "static_assert(sizeof(sint8) == 1 && sizeof(uint16) == 2 && sizeof(sint64) == 8 && sizeof(float64) == 8, \"\");\n"
+        "int main() {\n"
+        "  ADColor c(1, 2, 3); CensusSize s = Census9x7; float32* p = new float32[3]; SAFE_DELETE(p);\n"
+        "  vector<pair<sint32, sint32>> v; ADCensusOption o; ADCensusStereo st;\n"
+        "  const bool ok = c.b == 1 && c.g == 2 && c.r == 3 && s == 1 && Census5x5 == 0 && !p && v.empty() && o.cross_L1 == 34 &&\n"
+        "                  Large_Float == 99999.0f && Small_Float == -99999.0f && Invalid_Float > Large_Float;\n"
+        "  (void)st; return ok ? 0 : 1;\n"
+        "}\n")
+    subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])

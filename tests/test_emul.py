@@ -20,9 +20,10 @@ def same(a, b):
 
 
 EMUL_CASES = ["cone_crop_d40", "s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8", "q_40x1_d8",
-              "q_3x3_d2", "s2_150x100_neg"]
+              "q_3x3_d2", "s2_150x100_neg", "q_40x30_pos_wltd", "s2_150x100_pos"]
 # + disparity ranges that put 2 and 4 disparities into a lane (scanline class derivation, winner-takes-all)
-LANE_CASES = EMUL_CASES + ["s2_320x180_d128", "s2_200x120_d200"]
+LANE_CASES = EMUL_CASES + ["s2_320x180_d128", "s2_200x120_d200", "noise_160x90_d128_pos", "s2_200x120_d160",
+                           "noise_96x50_d160_neg", "s2_360x60_d300", "noise_80x40_d520"]
 
 
 @pytest.fixture(scope="module")
@@ -76,7 +77,7 @@ def test_marching_ring_pass_pairs(emul, dumps, name, pf, hseg, vseg):
 
 
 @pytest.mark.parametrize("name", ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2", "s2_150x100_neg",
-                                  "s2_200x120_d200"])
+                                  "s2_200x120_d200", "q_40x30_pos_wltd", "s2_150x100_pos", "s2_200x120_d160", "noise_96x50_d160_neg"])
 @pytest.mark.parametrize("seg", [0, 7, 50])
 def test_fused_cost_lane_window(emul, dumps, name, seg):
     """The matching cost as the fused first aggregation pass computes it (shifting lane window over padded right-image

@@ -65,6 +65,41 @@ def test_async_and_device_entry_points(hip, oracle):
         s.Release()
 
 
+def test_median_handoff_timeout_falls_back(hip, oracle):
+    """A hand-off time-out of the banded median must not fail the Match: adc_wait redoes the filter with the
+    single-workgroup kernel.  The time-out itself cannot be provoked, so the test arms the same path through the
+    debug hook and checks result + counter, for the host-pointer and the device-pointer entry points."""
+    A = hip
+    from oracle import pyoracle
+    from adcensus_amd import workloads
+    w, h, d = 200, 150, 32  # 3 bands of 64 rows -> the banded kernel is the one in use
+    left, right = workloads.structured_pair(w, h, d, seed=5)
+    opt = pyoracle.Option(max_disparity=d)
+    want = oracle.run(left, right, opt, stages=["disp_final"])["disp_final"]
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(w, h, cases.to_product_option(opt))
+    got = np.zeros((h, w), np.float32)
+    assert st.Match(left, right, got) and st.debug_counter(0) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    st.debug_run(A.RUN_MEDIAN, 100)
+    got[:] = -1
+    assert st.Match(left, right, got) and st.debug_counter(0) == 1
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    lib = A.lib()
+    n = w * h
+    dl, dr, dd = lib.adc_device_malloc(n * 3), lib.adc_device_malloc(n * 3), lib.adc_device_malloc(n * 4)
+    assert lib.adc_memcpy_h2d(dl, left.ctypes.data, n * 3) == 0 and lib.adc_memcpy_h2d(dr, right.ctypes.data, n * 3) == 0
+    st.debug_run(A.RUN_MEDIAN, 100)
+    assert st.match_device(dl, dr, dd) and st.wait() and st.debug_counter(0) == 2
+    got[:] = -1
+    assert lib.adc_memcpy_d2h(got.ctypes.data, dd, n * 4) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert st.Match(left, right, got) and st.debug_counter(0) == 2  # the hook is one-shot
+    for p in (dl, dr, dd):
+        lib.adc_device_free(p)
+    st.Release()
+
+
 def test_aggregation_fast_path_equals_direct(hip, oracle, monkeypatch):
     """A/B: the marching-ring kernel and the one-thread-per-element direct kernel agree bit-for-bit."""
     A = hip

@@ -25,7 +25,7 @@ def _sha(a):
 def _check(oracle, name):
     left, right, opt = cases.make_case(name)
     dumps = oracle.run(left, right, opt)
-    bad = [k for k, v in dumps.items() if _sha(v) != GOLDEN[name][k]]
+    bad = [k for k, v in dumps.items() if _sha(cases.canonical(k, v, opt)) != GOLDEN[name][k]]
     assert not bad, "%s oracle differs from the reference golden on %s: %s" % (oracle.kind, name, bad)
 
 

@@ -11,7 +11,7 @@ Writes
   tests/golden/golden.json       SHA-256 of every stage dump of the reference for a list of named,
                                  seeded cases (Cone + small synthetic cases + option variants)
   tests/golden/cone_final.npy.gz not written: the final map is pinned by its SHA-256 only
-and copies the other Data/ pairs into tests/golden/_data/ (git-ignored, travels with gpurun).
+  tests/golden/{cloth3,piano,wood2}_pair.npz  the other pairs of the reference's Data/ dir (committed too)
 """
 import hashlib
 import json
@@ -40,8 +40,7 @@ def main():
         np.savez_compressed(os.path.join(gold, "cone_pair.npz"),
                             left=bgr(os.path.join(REF_DATA, "Cone", "im2.png")),
                             right=bgr(os.path.join(REF_DATA, "Cone", "im6.png")))
-        data = os.path.join(gold, "_data")
-        os.makedirs(data, exist_ok=True)
+        data = gold  # committed (about 4.7 MB): the GPU parity tests of these pairs must run on a fresh clone
         for name, l, r in (("cloth3", "Cloth3/view1.png", "Cloth3/view5.png"), ("piano", "Piano/im0.png", "Piano/im1.png"),
                            ("wood2", "Wood2/view1.png", "Wood2/view5.png")):
             np.savez_compressed(os.path.join(data, name + "_pair.npz"), left=bgr(os.path.join(REF_DATA, l)),
@@ -51,7 +50,7 @@ def main():
     for name in cases.GOLDEN_CASES:
         left, right, opt = cases.make_case(name)
         dumps = ref.run(left, right, opt)
-        out["cases"][name] = {k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in dumps.items()}
+        out["cases"][name] = {k: hashlib.sha256(cases.canonical(k, v, opt).tobytes()).hexdigest() for k, v in dumps.items()}
         print(name, left.shape, "final", out["cases"][name]["disp_final"][:16], flush=True)
     with open(os.path.join(gold, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
