@@ -48,6 +48,8 @@ struct adc_handle {
     uint16_t *sup_h, *sup_v;
     int* armmax;             // [0] max horizontal arm, [1] max vertical arm of the current left image
     uint32_t *rec_h, *rec_v; // packed {arm_lo, arm_hi, divisor} per pixel, line-major (rec_v transposed)
+    uint32_t *rec2_h, *rec2_v; // uint2 {arm_lo | span<<8 | divisor<<16, RN(1/divisor)}: records of the register-ring kernels
+    float* agg_sink;           // 256 KiB scratch: store target of the halo steps of a pass pair (k_aggregate_rr.h)
     uint8_t *cdiff_lh, *cdiff_lv, *cdiff_rh, *cdiff_rv;
     uint8_t* so_cls; // path-ordered left-image colour-step words (d1) of the 4 scanline pass types (k_scanline.hip)
     // volumes

@@ -79,6 +79,9 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->armmax, 4 * sizeof(int)));
     HIP_OK(hipMalloc(&h->rec_h, P * 4));
     HIP_OK(hipMalloc(&h->rec_v, P * 4));
+    HIP_OK(hipMalloc(&h->rec2_h, P * 8));
+    HIP_OK(hipMalloc(&h->rec2_v, P * 8));
+    HIP_OK(hipMalloc(&h->agg_sink, 1024 * 64 * sizeof(float)));
     // + slack: the scanline kernels fetch up to VPL (<= 16) bytes starting at a column <= W-1 (+1 on R->L passes)
     HIP_OK(hipMalloc(&h->cdiff_lh, P + 64));
     HIP_OK(hipMalloc(&h->cdiff_lv, P + 64));
@@ -233,7 +236,7 @@ void adc_destroy(adc_handle* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
-                    h->armmax, h->rec_h, h->rec_v, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
+                    h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
                     h->chg_a, h->edge};
     for (void* b : bufs) if (b) hipFree(b);

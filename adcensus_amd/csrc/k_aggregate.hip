@@ -17,6 +17,7 @@
 //   * algorithmic bytes per pass: read V + write V (+4 B/pixel arms, +2 B/pixel counts), V = 4*W*H*Dp.
 #include "adc_internal.h"
 #include "adc_device_fn.h"
+#include "k_aggregate_rr.h"
 
 // ------------------------------------------------------------------------------- direct (fallback)
 // One thread per volume element reading its arm span straight from global memory.  Used when the
@@ -214,7 +215,7 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
                                                const int* __restrict__ armmax, int small_variant, int small_L,
                                                const AggCostIn& ci)
 {
-    static_assert(!REGRING || (!SMALL && !PAIR && VPL == 1), "register ring: full-ring pass (plain or with the fused cost)");
+    static_assert(!REGRING || (!SMALL && !PAIR && VPL == 1), "register ring here: the fused-cost first pass (plain passes and pairs: k_aggregate_rr.h)");
     static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
     static_assert(!PAIR || (DIVIDE && !COSTIN), "a fused pair = dividing pass + the following non-dividing pass");
     static_assert(VPL == 1 || (VPL == 2 && SMALL && !COSTIN), "two disparities per lane: small ring, no fused cost");
@@ -615,14 +616,22 @@ __global__ __launch_bounds__(64) void k_agg_march(const float* __restrict__ src,
                                                                   small_variant, small_L, ci);
 }
 
-// full ring in registers (2L+1 <= AGG_RING_REGS): the compiler keeps to v0..v55, the ring owns v56..v127
+// full ring in registers (2L+1 <= AGG_RING_REGS): the compiler keeps to v0..v55, ring 1 owns v56..v127, ring 2 (pairs)
+// v128..v199.  Body: k_aggregate_rr.h.
 template <bool VERT, bool DIVIDE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AGG_RING_V0))) void k_agg_regring(
-    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ rec, int W, int H, int Dp, int L,
-    int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L, AggCostIn ci)
+    const float* __restrict__ src, float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp, int L,
+    int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L, float* __restrict__ sink)
 {
-    agg_march_body<VERT, DIVIDE, false, false, false, 1, true>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax,
-                                                                small_variant, small_L, ci);
+    agg_rr_body<VERT, DIVIDE, false>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax, small_variant, small_L, sink);
+}
+// pass pair on two register rings: dividing pass + the next iteration's first pass
+template <bool VERT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AGG_RING_V0))) void k_agg_regring_pair(
+    const float* __restrict__ src, float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp, int L,
+    int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L, float* __restrict__ sink)
+{
+    agg_rr_body<VERT, true, true>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax, small_variant, small_L, sink);
 }
 
 // the same for the first pass of the pipeline (fused matching cost; its two tables stay in LDS)
@@ -693,10 +702,11 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
         // full ring of a plain pass: in registers when it fits (ADC_AGG_REGRING=0: LDS ring)
         static const bool regring_env = env_int("ADC_AGG_REGRING", 1) != 0;
-        const bool regring = variant == 0 && !PAIR && regring_env && Lv >= 1 && 2 * Lv + 1 <= AGG_RING_REGS;
+        const bool regring = variant == 0 && regring_env && Lv >= 1 && 2 * Lv + 1 <= AGG_RING_REGS;
         const size_t ring_bytes = regring ? 0 : (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
-        const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + (PAIR ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
-        const int waves_per_cu = regring ? 16 : adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
+        const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + ((PAIR && !regring) ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
+        // register rings: 128 VGPRs -> 4 waves per SIMD; a pair (two rings, 200 VGPRs) -> 2
+        const int waves_per_cu = regring ? (PAIR ? 8 : 16) : adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
         int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
         if (nseg < 1) nseg = pick_nseg(nlines, N, PAIR ? 2 * Lv : Lv, 256 * waves_per_cu);
         int seg_len = (N + nseg - 1) / nseg;
@@ -716,9 +726,14 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
             if constexpr (COSTIN)
                 hipLaunchKernelGGL(k_agg_regring_cost, dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
                                    VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
-            else if constexpr (!PAIR)
+            else if constexpr (PAIR)
+                hipLaunchKernelGGL((k_agg_regring_pair<VERT>), dim3((unsigned)per_xcd * 8), dim3(64), 0, h->heavy, src, dst,
+                                   reinterpret_cast<const uint2*>(VERT ? h->rec2_v : h->rec2_h), p.W, p.H, p.Dp, Lv, seg_len, nseg,
+                                   per_xcd, h->armmax, sv, sl, h->agg_sink);
+            else
                 hipLaunchKernelGGL((k_agg_regring<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), 0, h->heavy, src, dst,
-                                   VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
+                                   reinterpret_cast<const uint2*>(VERT ? h->rec2_v : h->rec2_h), p.W, p.H, p.Dp, Lv, seg_len, nseg,
+                                   per_xcd, h->armmax, sv, sl, h->agg_sink);
         } else if (variant && vpl == 2) {
             if constexpr (!COSTIN)
                 hipLaunchKernelGGL((k_agg_march<VERT, DIVIDE, true, false, PAIR, 2>), dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
@@ -738,7 +753,10 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
 {
     static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
     static const bool pair_env = env_int("ADC_AGG_PAIR", 1) != 0;
-    static const bool pair_full = env_int("ADC_AGG_PAIR_FULL", 0) != 0; // also with the full ring (2 x 17 KiB of LDS per wave)
+    // pairs with the full ring: 1 (default) = when both rings fit into registers (k_agg_regring_pair), 2 = also as two
+    // 17 KiB LDS rings per wave (measured 3x slower than two single passes), 0 = never
+    static const int pair_full = env_int("ADC_AGG_PAIR_FULL", 1);
+    static const bool regring_on = env_int("ADC_AGG_REGRING", 1) != 0;
     static bool attr_set = false;
     if (!attr_set) {
         // allow > 64 KiB dynamic LDS for the ring (large cross_L1)
@@ -753,6 +771,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     }
     hipError_t e = hipSuccess;
     const int Lfull = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
+    const bool regring_fits = regring_on && Lfull >= 1 && 2 * Lfull + 1 <= AGG_RING_REGS;
     const bool lds_fits = (size_t)(2 * Lfull + 1) * 64 * sizeof(float) + (768 + 64) * sizeof(float) <= 150 * 1024;
     const bool marching = !direct && (size_t)(2 * Lfull + 1) * 64 * sizeof(float) <= 150 * 1024;
     h->agg_first_fused = 0;
@@ -793,7 +812,8 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
         if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
         // second pass of the iteration (dividing): vertical after a horizontal first pass and vice versa
         const int wsec = hf ? which_v : which_h;
-        const bool pair = pair_env && marching && k + 1 < iterations && (wsec == 1 || (pair_full && wsec == 2));
+        const bool pair = pair_env && marching && k + 1 < iterations &&
+                          (wsec == 1 || (wsec == 2 && (pair_full >= 2 || (pair_full == 1 && regring_fits))));
         if (hf) {
             if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, direct, wsec);
             else e = launch_pass<true, true>(h, cur, oth, direct, which_v); // / sup_h

@@ -108,17 +108,29 @@ __global__ __launch_bounds__(256) void k_color_diffs(const uint8_t* __restrict__
 //   rec_h[y][x]  = {left, right, sup_v}   (H passes march along x; the dividing H pass is the 2nd pass of a
 //                                          vertical-first iteration -> vec_sup_count_[1])
 //   rec_v[x][y]  = {top, bottom, sup_h}   (V passes march along y: stored TRANSPOSED so a line is contiguous)
+// rec2_* (register-ring kernels, k_aggregate_rr.h): 8 bytes {lob | span << 8 | divisor << 16, RN(1 / divisor)} with
+// lob = arm_lo + L + 1 (the BIASED arm: first ring slot of the span = write slot - lob, L = the arm limit = ring
+// half-depth), span = arm_lo + arm_hi + 1 (both <= 255 for L <= 84; the register rings need L <= 35) and the
+// correctly rounded reciprocal (IEEE division here: no fast-math) that Markstein's division sequence starts from.
 __global__ __launch_bounds__(256) void k_make_records(const uchar4* __restrict__ arms, const uint16_t* __restrict__ sup_h,
                                                       const uint16_t* __restrict__ sup_v, uint32_t* __restrict__ rec_h,
-                                                      uint32_t* __restrict__ rec_v, int W, int H)
+                                                      uint32_t* __restrict__ rec_v, uint2* __restrict__ rec2_h,
+                                                      uint2* __restrict__ rec2_v, int W, int H, int L)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const size_t p = (size_t)y * W + x;
     const uchar4 a = arms[p];
-    rec_h[p] = (uint32_t)a.x | ((uint32_t)a.y << 8) | ((uint32_t)sup_v[p] << 16);
-    rec_v[(size_t)x * H + y] = (uint32_t)a.z | ((uint32_t)a.w << 8) | ((uint32_t)sup_h[p] << 16);
+    const uint32_t ch = sup_h[p], cv = sup_v[p];
+    rec_h[p] = (uint32_t)a.x | ((uint32_t)a.y << 8) | (cv << 16);
+    rec_v[(size_t)x * H + y] = (uint32_t)a.z | ((uint32_t)a.w << 8) | (ch << 16);
+    if (rec2_h) {
+        const uint32_t nh = (uint32_t)a.x + a.y + 1u, nv = (uint32_t)a.z + a.w + 1u;
+        const uint32_t bias = (uint32_t)L + 1u;
+        rec2_h[p] = make_uint2((((uint32_t)a.x + bias) & 255u) | ((nh & 255u) << 8) | (cv << 16), __float_as_uint(1.0f / (float)cv));
+        rec2_v[(size_t)x * H + y] = make_uint2((((uint32_t)a.z + bias) & 255u) | ((nv & 255u) << 8) | (ch << 16), __float_as_uint(1.0f / (float)ch));
+    }
 }
 
 hipError_t adc_launch_records(adc_handle* h)
@@ -126,7 +138,8 @@ hipError_t adc_launch_records(adc_handle* h)
     const AdcParams& p = h->p;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_make_records, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
-                       h->rec_h, h->rec_v, p.W, p.H);
+                       h->rec_h, h->rec_v, reinterpret_cast<uint2*>(h->rec2_h), reinterpret_cast<uint2*>(h->rec2_v), p.W, p.H,
+                       adc_imax(0, adc_imin(p.opt.cross_L1, 255)));
     return hipGetLastError();
 }
 

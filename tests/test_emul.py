@@ -76,6 +76,49 @@ def test_marching_ring_pass_pairs(emul, dumps, name, pf, hseg, vseg):
     assert same(a, o["cost_aggr"])
 
 
+RR_CASES = ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2", "cone_crop_d40", "q_257x131_d64"]
+
+
+@pytest.mark.parametrize("name", RR_CASES)
+@pytest.mark.parametrize("hseg,vseg", [(1, 1), (3, 2), (2, 5)])
+def test_register_ring_body_single_passes(emul, dumps, name, hseg, vseg):
+    """k_aggregate_rr.h compiled for the CPU (RR_EMUL): 8 single register-ring passes == the reference's cost_aggr
+    (biased-arm records, one slot counter per ring, 35-add blocks with M0-relative addressing, Markstein division)."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D = opt.max_disparity - opt.min_disparity
+    L = max(0, min(opt.cross_L1, 255))
+    a, b = o["cost_init"].copy(), np.full_like(o["cost_init"], np.nan)
+    hfirst = True
+    for _ in range(4):
+        order = [(0, 0, o["sup_count_h"]), (1, 1, o["sup_count_h"])] if hfirst else [(1, 0, o["sup_count_v"]), (0, 1, o["sup_count_v"])]
+        for vert, div, sup in order:
+            assert emul.emul_rr_pass(P(a), P(b), P(o["arms"]), P(sup), w, h, D, vert, div, 0, L, vseg if vert else hseg) == 0
+            a, b = b, a
+        hfirst = not hfirst
+    assert same(a, o["cost_aggr"])
+
+
+@pytest.mark.parametrize("name", RR_CASES)
+@pytest.mark.parametrize("hseg,vseg", [(1, 1), (3, 2), (2, 5)])
+def test_register_ring_body_pass_pairs(emul, dumps, name, hseg, vseg):
+    """Production launch sequence on long-arm images: H0 | V0+V1 | H1+H2 | V2+V3 | H3 with the pairs on two register
+    rings (k_agg_regring_pair): first-pass outputs stay in ring 2, halo steps store to the sink."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D = opt.max_disparity - opt.min_disparity
+    L = max(0, min(opt.cross_L1, 255))
+    a, b = o["cost_init"].copy(), np.full_like(o["cost_init"], np.nan)
+    assert emul.emul_rr_pass(P(a), P(b), P(o["arms"]), P(o["sup_count_h"]), w, h, D, 0, 0, 0, L, hseg) == 0  # H0
+    a, b = b, a
+    for vert, sup in ((1, o["sup_count_h"]), (0, o["sup_count_v"]), (1, o["sup_count_h"])):  # the three pairs
+        assert emul.emul_rr_pass(P(a), P(b), P(o["arms"]), P(sup), w, h, D, vert, 1, 1, L, vseg if vert else hseg) == 0
+        a, b = b, a
+    assert emul.emul_rr_pass(P(a), P(b), P(o["arms"]), P(o["sup_count_v"]), w, h, D, 0, 1, 0, L, hseg) == 0  # H3 (dividing)
+    a, b = b, a
+    assert same(a, o["cost_aggr"])
+
+
 @pytest.mark.parametrize("name", ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2", "s2_150x100_neg",
                                   "s2_200x120_d200", "q_40x30_pos_wltd", "s2_150x100_pos", "s2_200x120_d160", "noise_96x50_d160_neg"])
 @pytest.mark.parametrize("seg", [0, 7, 50])
