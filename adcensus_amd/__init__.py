@@ -87,6 +87,8 @@ def lib():
     L.adc_get_stage_ms.restype = C.c_int
     L.adc_get_aggregate_pass_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.adc_get_aggregate_pass_ms.restype = C.c_int
+    L.adc_get_aggregate_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.adc_get_aggregate_info.restype = C.c_int
     L.adc_get_stream.argtypes = [vp]
     L.adc_get_stream.restype = vp
     L.adc_device_synchronize.restype = C.c_int
@@ -220,6 +222,12 @@ class ADCensusStereo:
         ms, n = C.c_float(0), C.c_int(0)
         lib().adc_get_aggregate_pass_ms(self._h, C.byref(ms), C.byref(n))
         return float(ms.value), int(n.value)
+
+    def aggregate_info(self):
+        """(average ms of a regular aggregation launch, launches, algorithmic passes they covered, first pass fused?)"""
+        ms, n, p, f = C.c_float(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().adc_get_aggregate_info(self._h, C.byref(ms), C.byref(n), C.byref(p), C.byref(f))
+        return float(ms.value), int(n.value), int(p.value), bool(f.value)
 
     # -- test-only debug surface ---------------------------------------------------------------
     def _buf_spec(self, which):

@@ -101,6 +101,7 @@ struct adc_handle {
     float stage_ms[ADC_STAGE_COUNT];
     float agg_pass_ms;
     int agg_launches;
+    int agg_passes;    // algorithmic passes those launches covered (a pair launch covers two)
     bool timings_pending;
     // region voting statistics of the last run
     int64_t vote_rounds, vote_evals;

@@ -464,6 +464,16 @@ int adc_get_aggregate_pass_ms(adc_handle* h, float* avg_ms, int* launches)
     if (launches) *launches = h->agg_launches - (h->agg_first_fused ? 1 : 0);
     return 0;
 }
+int adc_get_aggregate_info(adc_handle* h, float* avg_launch_ms, int* launches, int* passes, int* first_fused)
+{
+    if (!h) return 1;
+    const int ff = h->agg_first_fused ? 1 : 0;
+    if (avg_launch_ms) *avg_launch_ms = h->agg_pass_ms;
+    if (launches) *launches = h->agg_launches - ff;
+    if (passes) *passes = h->agg_passes - ff;
+    if (first_fused) *first_fused = ff;
+    return 0;
+}
 void* adc_get_stream(adc_handle* h) { return h ? (void*)h->stream : nullptr; }
 int adc_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : 1; }
 void* adc_device_malloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }

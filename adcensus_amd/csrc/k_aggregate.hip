@@ -753,9 +753,13 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
 {
     static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
     static const bool pair_env = env_int("ADC_AGG_PAIR", 1) != 0;
-    // pairs with the full ring: 1 (default) = when both rings fit into registers (k_agg_regring_pair), 2 = also as two
-    // 17 KiB LDS rings per wave (measured 3x slower than two single passes), 0 = never
-    static const int pair_full = env_int("ADC_AGG_PAIR_FULL", 1);
+    // pairs with the full ring: 0 (default) = never, 1 = when both rings fit into registers (k_agg_regring_pair), 2 = also
+    // as two 17 KiB LDS rings per wave.  Measured on MI355X (structured 1080p pair, rocprofv3): a register-ring pair
+    // launch takes 0.95-1.02 ms against 2 x 0.42 ms for two single passes -- 200 VGPRs leave 2 waves per SIMD, and this
+    // kernel family runs at ~8.7 cycles per instruction and wave whatever the occupancy, so halving the waves doubles
+    // the time per step while the saved HBM round trip (0.2 ms at the copy rate) does not pay for it; two LDS rings were
+    // 3x slower.  The single pass itself now runs at the device copy rate.
+    static const int pair_full = env_int("ADC_AGG_PAIR_FULL", 0);
     static const bool regring_on = env_int("ADC_AGG_REGRING", 1) != 0;
     static bool attr_set = false;
     if (!attr_set) {
@@ -790,6 +794,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     float* oth = h->vol_b;
     bool horizontal_first = true; // cross_aggregator.cpp:100
     int launch = 0;
+    int passes = 0; // algorithmic passes (cross_aggregator.cpp: 2 per iteration) covered by the launches so far
     bool second_done = false; // the first pass of this iteration was already computed by the previous pair launch
     for (int k = 0; k < iterations && e == hipSuccess; k++) {
         const bool hf = horizontal_first;
@@ -806,6 +811,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
             }
             { float* t = cur; cur = oth; oth = t; }
             launch++;
+            passes++;
         }
         second_done = false;
         if (e != hipSuccess) break;
@@ -823,11 +829,13 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
         }
         { float* t = cur; cur = oth; oth = t; }
         launch++;
+        passes += pair ? 2 : 1;
         second_done = pair;
         horizontal_first = !horizontal_first;
     }
     if (h->profiling) hipEventRecord(h->ev_agg[launch < 8 ? launch : 8], h->heavy);
     h->agg_launches = launch < 8 ? launch : 8;
+    h->agg_passes = passes;
     // the result must be in vol_a (cost_aggr_): swap the two volume pointers if it ended up in the other one
     if (cur != h->vol_a) { h->vol_b = h->vol_a; h->vol_a = cur; }
     return e;

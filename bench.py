@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- stereo pairs/s of the MI355X-native AD-Census Match path (BASELINE.json metric).
 
-A "step" = one full `Match` (cost volume -> 4x cross aggregation -> 4 scanline passes -> L/R WTA ->
-multi-step refinement) of one 1920x1080, D=128 stereo pair whose images are already resident in
-HBM (adc_match_device); the disparity map stays in HBM.  N>1: one process per GPU
-(torch.distributed / RCCL), pairs are independent work items (weak scaling, no data collective;
-RCCL is used only for the barrier and the max-over-ranks reduction of the elapsed time).
+A "step" = one full `Match` (cost volume -> 4x cross aggregation -> 4 scanline passes -> L/R WTA -> multi-step
+refinement) of one 1920x1080, D=128 stereo pair whose images are already resident in HBM (adc_match_device); the
+disparity map stays in HBM.  The timed region is a FARM over a batch of DISTINCT pairs (BASELINE.json configs[4],
+SURVEY.md 8d config 5): batch = steps x ranks pairs, pair i = the seeded synthetic pair 12345 + i, rank r takes the
+pairs i = r (mod ranks) (adcensus_amd/farm.py), `--inflight` pipelines per GPU.  There is no data-path collective:
+RCCL is used for the barriers, the MAX over ranks of the elapsed time, the SUM of the done counter and an all-gather of
+one SHA-256 per pair.  After the timed region every rank recomputes the pairs of its neighbour rank (untimed), so each
+output of the batch is compared with the same pair computed on another GPU (N = 1: computed a second time), and with
+the committed table of 1-GPU outputs (tests/golden/farm_digests.json) when the size matches.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the aggregation pass kernel (k_agg_march; k_agg_regring on long-arm images): algorithmic bytes per launch
-                  (2*V + 4*P arms [+ 2*P counts on dividing passes], V = 4*W*H*D) / its average
-                  launch duration measured with HIP events on the handle's own stream inside the
-                  timed region, vs 8 TB/s HBM3E (regular passes only: the first pass, which computes the
-                  matching cost itself and only writes, is not part of the average); device_copy_GBps =
-                  a device-to-device copy of one volume measured after the timed region (practical ceiling).
-  cpu_baseline -- the reference CPU path (oracle/_ref, kind "reference"; the plain-C port if absent)
-                  timed on this host, 1 thread, on a bounded row-strip sample of the same pair.
+  roofline       the aggregation kernel (K4).  achieved = ALGORITHMIC bytes per regular launch (one pass =
+                 2V + 4P arm records [+ 2P support counts on dividing passes], V = 4*W*H*D; a pass-pair launch does two
+                 passes of work) / average launch duration from HIP events on the handle's own stream inside the timed
+                 region.  hbm_achieved = the bytes that launch really moves (a pair launch reads V and writes V once) /
+                 the same duration; traffic = those bytes as measured by rocprofv3 PMC passes (profiles/, None when the
+                 committed measurement does not match this build); device_copy_GBps = a device-to-device copy of one
+                 volume measured after the timed region (the practical ceiling next to the 8 TB/s spec peak).
+  structured     (N = 1) the same measurement on the SURVEY 8d "structured" pair (natural-image-like arms / voting load).
+  host_inclusive (N = 1) the drop-in entry point adc_match(left, right, disp) with pageable host buffers: pinned staging
+                 copies + H2D + kernels + D2H + copy-out (ADCensusStereo.cpp:69-132 incl. the memcpy at :125).
+  throughput_mode (N = 1) the same batch with 3 pipelines in flight per GPU.
+  cpu_baseline   the reference CPU path (oracle/_ref, kind "reference"; the plain-C port if absent) timed on this host,
+                 1 thread, on a bounded row-strip sample of the same pair.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,6 +41,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
+
+K4_REV = "r2-rr1"  # bumped whenever the aggregation kernels change: a committed PMC measurement of another revision is stale
 
 
 def parse():
@@ -42,171 +56,313 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--disp", type=int, default=128)
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ADC_BENCH_INFLIGHT", "1")),
-                    help="ADCensusStereo objects (streams) in flight per GPU")
+                    help="ADCensusStereo objects (streams) in flight per GPU in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the structured / host-inclusive / throughput legs")
     ap.add_argument("--cpu-rows", type=int, default=540, help="rows of the CPU-baseline sample strip")
+    ap.add_argument("--write-digests", default="", help="write {pair id: sha256} of the batch outputs to this file (N = 1)")
     return ap.parse_args()
+
+
+def reexec_under_torchrun(a):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+class Matcher:
+    """`inflight` ADCensusStereo pipelines on one GPU + the device-resident inputs / outputs of a list of pairs."""
+
+    def __init__(self, A, device, W, H, D, inflight):
+        self.A, self.lib = A, A.lib()
+        self.W, self.H, self.D, self.P = W, H, D, W * H
+        self.opt = A.ADCensusOption(min_disparity=0, max_disparity=D)
+        self.handles = []
+        for _ in range(max(1, inflight)):
+            st = A.ADCensusStereo(device=device)
+            if not st.Initialize(W, H, self.opt):
+                raise SystemExit("Initialize failed: " + A.last_error())
+            self.handles.append(st)
+        self.buf = {}  # pair id -> (d_left, d_right, d_disp)
+
+    def upload(self, pid, left, right):
+        lib, P = self.lib, self.P
+        dl, dr, dd = lib.adc_device_malloc(P * 3), lib.adc_device_malloc(P * 3), lib.adc_device_malloc(P * 4)
+        assert dl and dr and dd, "device allocation failed"
+        assert lib.adc_memcpy_h2d(dl, left.ctypes.data, P * 3) == 0 and lib.adc_memcpy_h2d(dr, right.ctypes.data, P * 3) == 0
+        self.buf[pid] = (dl, dr, dd)
+
+    def submit(self, slot, pid):
+        dl, dr, dd = self.buf[pid]
+        if not self.handles[slot].match_device(dl, dr, dd):
+            raise SystemExit("Match failed: " + self.A.last_error())
+
+    def wait(self, slot):
+        if not self.handles[slot].wait():
+            raise SystemExit("Match failed: " + self.A.last_error())
+
+    def output(self, pid):
+        out = np.empty((self.H, self.W), np.float32)
+        assert self.lib.adc_memcpy_d2h(out.ctypes.data, self.buf[pid][2], self.P * 4) == 0
+        return out
+
+    def clear_output(self, pid):
+        z = np.full((self.H, self.W), -1.0, np.float32)
+        assert self.lib.adc_memcpy_h2d(self.buf[pid][2], z.ctypes.data, self.P * 4) == 0
+
+    def free(self, pid):
+        for p in self.buf.pop(pid):
+            self.lib.adc_device_free(p)
+
+    def release(self):
+        for pid in list(self.buf):
+            self.free(pid)
+        for st in self.handles:
+            st.Release()
+
+
+def make_pair(workload, W, H, D, pid):
+    from adcensus_amd import workloads
+    if workload == "noise":
+        return workloads.noise_pair(W, H, 12345 + pid)  # SURVEY.md 8d: seeds 12345 + i
+    return workloads.structured_pair(W, H, D, seed=777 + pid)
+
+
+def k4_roofline(prof, W, H, D, lib, workload):
+    """prof: list of aggregate_info() tuples of the profiled handle, one per timed Match."""
+    P = float(W) * H
+    V = 4.0 * P * D
+    prof = [p for p in prof if p[1] > 0 and p[0] > 0]
+    if not prof:
+        return None
+    ms = float(np.mean([p[0] for p in prof]))
+    launches, passes, fused = prof[-1][1], prof[-1][2], prof[-1][3]
+    # algorithmic bytes of the regular launches: every pass 2V + 4P; the dividing ones (4 of 8, all regular) + 2P
+    alg_total = passes * (2.0 * V + 4.0 * P) + 4 * 2.0 * P
+    hbm_total = launches * (2.0 * V + 4.0 * P) + 4 * 2.0 * P  # a pair launch still reads V and writes V once
+    alg_per_launch, hbm_per_launch = alg_total / launches, hbm_total / launches
+    achieved = alg_per_launch / (ms * 1e-3) / 1e9
+    hbm = hbm_per_launch / (ms * 1e-3) / 1e9
+    copy_gbps = None
+    try:
+        nb = int(V)
+        ca, cb = lib.adc_device_malloc(nb), lib.adc_device_malloc(nb)
+        if ca and cb:
+            t = lib.adc_device_copy_ms(cb, ca, nb, 5)
+            if t > 0:
+                copy_gbps = round(2.0 * nb / (t * 1e-3) / 1e9, 1)
+        for q in (ca, cb):
+            if q:
+                lib.adc_device_free(q)
+    except Exception:
+        copy_gbps = None
+    pairs = passes > launches
+    kern = ("k_agg_march<.., PAIR> (LDS rings, short-arm image: a launch = dividing pass + next first pass)" if pairs and workload == "noise"
+            else ("k_agg_regring_pair" if pairs else "k_agg_regring (register ring, one pass per launch)"))
+    return {"kernel": kern, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(workload, (W, H, D)),
+            "algorithmic_bytes_per_launch": alg_per_launch, "passes_per_launch": round(passes / float(launches), 3),
+            "regular_launches": launches, "first_pass_fused_with_cost": bool(fused),
+            "hbm_bytes_per_launch": hbm_per_launch, "hbm_achieved": round(hbm, 2), "hbm_frac": round(hbm / 8000.0, 4),
+            "avg_launch_ms": round(ms, 5), "device_copy_GBps": copy_gbps,
+            "hbm_frac_of_device_copy": round(hbm / copy_gbps, 4) if copy_gbps else None}
+
+
+def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair_ids, dist=None, tensor_device="cpu"):
+    """Uploads the pairs, runs warm-up + the timed farm region; returns (matcher, elapsed, total, stage_ms, roofline-prof)."""
+    from adcensus_amd import farm
+    m = Matcher(A, device, W, H, D, inflight)
+    for pid in pair_ids:
+        l, r = make_pair(workload, W, H, D, pid)
+        m.upload(pid, l, r)
+    m.handles[0].set_profiling(True)
+    prof, stages = [], []
+
+    def run(n):
+        ids = [pair_ids[i % len(pair_ids)] for i in range(n)]
+
+        def wait(slot):
+            m.wait(slot)
+            if slot == 0:
+                prof.append(m.handles[0].aggregate_info())
+                stages.append(m.handles[0].stage_ms())
+        farm.run_pairs(ids, m.submit, wait, inflight)
+
+    elapsed, total = farm.timed_region(run, steps, warmup, dist=dist, device_sync=m.lib.adc_device_synchronize,
+                                       tensor_device=tensor_device)
+    keep = max(1, (steps + inflight - 1) // inflight)
+    return m, elapsed, total, stages[-keep:], prof[-keep:]
+
+
+def mean_stages(stages):
+    return {k: round(float(np.mean([s[k] for s in stages])), 4) for k in stages[0]} if stages else {}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(reexec_under_torchrun(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    torch = None
+    tensor_device = "cpu"
     if world > 1:
         # torch first: its bundled HIP runtime (same SONAME) is then shared by the C-ABI library
-        import torch as _torch
+        import torch
         import torch.distributed as _dist
-        torch, dist = _torch, _dist
+        dist = _dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ADC_BENCH_BACKEND", "nccl")  # "gloo": test hook (several ranks on one GPU)
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            tensor_device = "cuda"
         else:
             local_rank = int(os.environ.get("ADC_BENCH_DEVICE", local_rank))
             dist.init_process_group(backend=backend)
     import adcensus_amd as A
-    from adcensus_amd import workloads
+    from adcensus_amd import farm
     lib = A.lib()
     if A.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible")
     W, H, D = a.width, a.height, a.disp
-    P = W * H
-    opt = A.ADCensusOption(min_disparity=0, max_disparity=D)
-
-    # synthetic pair(s): distinct seed per rank and per in-flight slot
     F = max(1, a.inflight)
-    handles, bufs, pairs = [], [], []
-    for i in range(F):
-        seed = 12345 + rank * 64 + i
-        left, right = (workloads.noise_pair(W, H, seed) if a.workload == "noise"
-                       else workloads.structured_pair(W, H, D, seed=777 + rank * 64 + i))
-        pairs.append((left, right))
-        st = A.ADCensusStereo(device=local_rank)
-        if not st.Initialize(W, H, opt):
-            raise SystemExit("Initialize failed: " + A.last_error())
-        dl, dr, dd = lib.adc_device_malloc(P * 3), lib.adc_device_malloc(P * 3), lib.adc_device_malloc(P * 4)
-        assert dl and dr and dd
-        assert lib.adc_memcpy_h2d(dl, left.ctypes.data, P * 3) == 0 and lib.adc_memcpy_h2d(dr, right.ctypes.data, P * 3) == 0
-        handles.append(st)
-        bufs.append((dl, dr, dd))
-    handles[0].set_profiling(True)
 
-    def run_steps(nsteps, collect=None):
-        """nsteps Match calls spread over the F objects, one host thread per object."""
-        counts = [nsteps // F + (1 if i < nsteps % F else 0) for i in range(F)]
-        errs = []
-
-        def worker(i):
-            st, (dl, dr, dd) = handles[i], bufs[i]
-            for _ in range(counts[i]):
-                if not (st.match_device(dl, dr, dd) and st.wait()):
-                    errs.append(A.last_error())
-                    return
-                if collect is not None and i == 0:
-                    collect.append((st.stage_ms(), st.aggregate_pass_ms()))
-        ths = [threading.Thread(target=worker, args=(i,)) for i in range(F) if counts[i]]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        if errs:
-            raise SystemExit("Match failed: %s" % errs[0])
-
-    from adcensus_amd import farm
-    prof = []
-    elapsed, total_steps = farm.timed_region(lambda n: run_steps(n, prof), a.steps, a.warmup, dist=dist,
-                                             device_sync=lib.adc_device_synchronize,
-                                             tensor_device="cuda" if (dist is not None and dist.get_backend() == "nccl") else "cpu")
-    prof = prof[-a.steps:] if len(prof) > a.steps else prof  # drop the warm-up samples of object 0
+    # ---- the batch: steps x ranks distinct pairs, partitioned round-robin over the ranks (weak scaling)
+    batch = a.steps * world
+    mine = farm.partition(batch, world, rank)
+    m, elapsed, total, stages, prof = measure_workload(A, local_rank, W, H, D, a.workload, a.steps, a.warmup, F, mine,
+                                                       dist=dist, tensor_device=tensor_device)
+    # ---- verification (untimed): digests of this rank's outputs, recomputation of the neighbour rank's pairs
+    primary = {pid: farm.digest(m.output(pid).tobytes()) for pid in mine}
+    recheck = {}
+    for pid in farm.neighbour_pairs(batch, world, rank):
+        own = pid in m.buf
+        if not own:
+            l, r = make_pair(a.workload, W, H, D, pid)
+            m.upload(pid, l, r)
+        else:
+            m.clear_output(pid)
+        m.submit(0, pid)
+        m.wait(0)
+        recheck[pid] = farm.digest(m.output(pid).tobytes())
+        if not own:
+            m.free(pid)
+    done = farm.done_counter(len(primary), dist, tensor_device)
+    all_primary, all_recheck = farm.gather_digests(primary, dist), farm.gather_digests(recheck, dist)
 
     if rank == 0:
-        total_pairs = total_steps  # SUM over ranks of the steps each rank timed
-        value = total_pairs / elapsed
-        # roofline of the dominant kernel (aggregation pass): algorithmic bytes per launch / avg launch time
-        V = 4.0 * P * D
-        # SURVEY.md 8d: a regular pass moves 2V + 4P (+2P counts when it divides); 8 passes = 16V + 32P + 8P.  With the
-        # cost fused into the first pass (default) that pass is write-only and is left out of the average: the 7
-        # regular passes (4 of them dividing) move 14V + 28P + 8P.
-        # Short-arm images (the noise pair): the dividing pass of an iteration and the first pass of the next one share
-        # a launch, so after the fused first pass there are 4 launches (3 pairs + the last pass), each read V + write V
-        # + arm records and counts = 2V + 6P.
-        npass = max([p[1][1] for p in prof] or [8])
-        if npass == 7:
-            per_launch_bytes = (14.0 * V + 36.0 * P) / 7.0
-        elif npass in (4, 5):
-            per_launch_bytes = 2.0 * V + 6.0 * P
-        else:
-            per_launch_bytes = (16.0 * V + 40.0 * P) / 8.0
-        agg = [p[1][0] for p in prof if p[1][1] > 0 and p[1][0] > 0]
-        agg_ms = float(np.mean(agg)) if agg else float("nan")
-        achieved = per_launch_bytes / (agg_ms * 1e-3) / 1e9 if agg else float("nan")
-        stage = {}
-        if prof:
-            for k in prof[0][0]:
-                stage[k] = round(float(np.mean([p[0][k] for p in prof])), 4)
-        # practical ceiling next to the 8 TB/s peak: a plain device-to-device copy of one volume (read V + write V),
-        # measured after the timed region on two scratch buffers
-        copy_gbps = None
-        try:
-            nb = int(V)
-            ca, cb = lib.adc_device_malloc(nb), lib.adc_device_malloc(nb)
-            if ca and cb:
-                ms = lib.adc_device_copy_ms(cb, ca, nb, 5)
-                if ms > 0:
-                    copy_gbps = round(2.0 * nb / (ms * 1e-3) / 1e9, 1)
-            for q in (ca, cb):
-                if q:
-                    lib.adc_device_free(q)
-        except Exception:
-            copy_gbps = None
+        ref_table = None
+        ref_path = os.path.join(ROOT, "tests", "golden", "farm_digests.json")
+        if os.path.exists(ref_path):
+            with open(ref_path) as f:
+                t = json.load(f)
+            if t.get("workload") == a.workload and t.get("size") == [W, H, D]:
+                ref_table = t["digests"]
+        check = farm.cross_check(all_primary, all_recheck, ref_table)
+        check["done_counter"] = done
+        check["ok"] = (done == batch and check["pairs"] == batch and not check["duplicates"] and not check["mismatches"]
+                       and not check["reference_mismatches"])
+        if a.write_digests and world == 1:
+            with open(a.write_digests, "w") as f:
+                json.dump({"workload": a.workload, "size": [W, H, D], "generator": "python bench.py --steps %d --write-digests ... (1 GPU)" % a.steps,
+                           "digests": {str(k): v for k, v in sorted(primary.items())}}, f, indent=1, sort_keys=True)
+        value = total / elapsed
+        stage = mean_stages(stages)
+        sizes = {(1920, 1080, 128): " (BASELINE.json configs[3])" if a.workload == "noise" else " (size of BASELINE.json configs[3], SURVEY 8d structured pair)",
+                 (1242, 375, 128): " (size of BASELINE.json configs[2])", (450, 375, 64): " (size of BASELINE.json configs[1])"}
         out = {
-            "metric": "stereo pairs/s at 1920x1080 D=128 (ADCensusStereo::Match)" if (W, H, D) == (1920, 1080, 128)
-                      else "stereo pairs/s at %dx%d D=%d (ADCensusStereo::Match)" % (W, H, D),
+            "metric": "stereo pairs/s at %dx%d D=%d (ADCensusStereo::Match, images and disparity map resident in HBM)" % (W, H, D),
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d D=%d%s" % (a.workload, W, H, D, {(1920, 1080, 128): " (BASELINE.json configs[3])" if a.workload == "noise" else " (size of BASELINE.json configs[3], SURVEY 8d structured pair)",
-                                                                            (1242, 375, 128): " (size of BASELINE.json configs[2])",
-                                                                            (450, 375, 64): " (size of BASELINE.json configs[1])"}.get((W, H, D), "")),
-                       "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs)" % world},
+            "config": {"workload": "%s %dx%d D=%d%s" % (a.workload, W, H, D, sizes.get((W, H, D), "")),
+                       "batch": "%d distinct pairs (seeds 12345+i), %d per GPU" % (batch, a.steps),
+                       "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs, round-robin partition)" % world},
+            "farm_check": check,
             "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
             "stage_ms": stage,
-            "roofline": {"kernel": "%s (one aggregation launch: %s)" % (("k_agg_march", "pass pair, 2 passes of work") if npass in (4, 5)
-                                                                                    else ("k_agg_regring / k_agg_march", "one pass")), "bound": "hbm",
-                         "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(a.workload, (W, H, D)),
-                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(agg_ms, 5),
-                         "device_copy_GBps": copy_gbps,
-                         "frac_of_device_copy": round(achieved / copy_gbps, 4) if copy_gbps else None},
+            "roofline": k4_roofline(prof, W, H, D, lib, a.workload),
         }
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pairs[0], D, a.cpu_rows, H)
-        print(json.dumps(out), flush=True)
+    m.release()
 
-    for st, (dl, dr, dd) in zip(handles, bufs):
-        st.Release()
-        for p in (dl, dr, dd):
-            lib.adc_device_free(p)
+    if rank == 0 and world == 1 and not a.no_extra_legs:
+        other = "structured" if a.workload == "noise" else "noise"
+        # ---- second workload (one pair: generating structured pairs costs seconds each), one pipeline
+        n2 = max(5, min(10, a.steps))
+        m2, e2, t2, st2, pf2 = measure_workload(A, local_rank, W, H, D, other, n2, 2, 1, [0])
+        s2 = mean_stages(st2)
+        out[other] = {"value": round(t2 / e2, 4), "unit": "pairs/s", "ms_per_step": round(1000.0 * e2 / n2, 4), "steps": n2,
+                      "workload": "%s %dx%d D=%d (one pair repeated)" % (other, W, H, D), "stage_ms": s2,
+                      "roofline": k4_roofline(pf2, W, H, D, lib, other)}
+        m2.release()
+        # ---- the drop-in entry point with pageable host buffers
+        out["host_inclusive"] = host_inclusive_leg(A, local_rank, W, H, D, a.workload, max(5, min(10, a.steps)))
+        # ---- throughput mode: 3 pipelines in flight
+        n3 = max(6, min(24, a.steps))
+        ids3 = list(range(min(n3, 8)))
+        m3, e3, t3, _, _ = measure_workload(A, local_rank, W, H, D, a.workload, n3, 3, 3, ids3)
+        out["throughput_mode"] = {"value": round(t3 / e3, 4), "unit": "pairs/s", "in_flight_per_gpu": 3, "steps": n3,
+                                  "note": "same workload, three pipelines (streams) in flight; per-kernel durations are then inflated by co-running kernels, which is why the headline region uses one"}
+        m3.release()
+    if rank == 0:
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(make_pair(a.workload, W, H, D, 0), D, a.cpu_rows, H)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
+def host_inclusive_leg(A, device, W, H, D, workload, n):
+    left, right = make_pair(workload, W, H, D, 0)
+    st = A.ADCensusStereo(device=device)
+    if not st.Initialize(W, H, A.ADCensusOption(min_disparity=0, max_disparity=D)):
+        raise SystemExit("Initialize failed: " + A.last_error())
+    disp = np.empty((H, W), np.float32)  # pageable, like a caller's malloc'ed buffer
+    for _ in range(2):
+        assert st.Match(left, right, disp)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        assert st.Match(left, right, disp)
+    dt = time.perf_counter() - t0
+    st.Release()
+    return {"value": round(n / dt, 4), "unit": "pairs/s", "ms_per_pair": round(1000.0 * dt / n, 4), "steps": n,
+            "entry_point": "adc_match(left, right, disp) == ADCensusStereo::Match with pageable host buffers: 2 host copies into pinned "
+                           "staging (12.4 MB), H2D, kernels, D2H (8.3 MB), copy-out; synchronous"}
+
+
 def pmc_traffic(workload, whd):
-    """HBM bytes per aggregation launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 +
-    WRITE_SIZE, separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md); None when not collected for
-    this workload / size."""
+    """HBM bytes per aggregation launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
+    separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md).  None when not collected for this workload / size
+    or when it was collected on another revision of the aggregation kernels (K4_REV)."""
     if whd != (1920, 1080, 128):
         return None
-    p = os.path.join(ROOT, "profiles", "r1_k4_pmc_traffic_%s.json" % workload)
+    p = os.path.join(ROOT, "profiles", "r2_k4_pmc_traffic_%s.json" % workload)
     try:
         with open(p) as f:
-            return float(json.load(f)["traffic_bytes_per_launch_avg"])
+            o = json.load(f)
+        if o.get("k4_rev") != K4_REV:
+            return None
+        return float(o["traffic_bytes_per_launch_avg"])
     except Exception:
         return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(pair, D, rows, H):
@@ -235,8 +391,9 @@ def cpu_baseline(pair, D, rows, H):
         os.close(saved)
     full_secs = secs * (H / float(rows))
     return {"value": round(1.0 / full_secs, 6), "unit": "pairs/s", "cores": 1, "kind": "reference" if orc.kind == "reference" else "port",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count() or 0, "build": getattr(orc, "build_info", "unknown"),
             "sample": "top %d of %d rows of the same pair (full width, D=%d): %.2f s measured, scaled by rows to %.1f s/pair; "
-                      "host has %d cores, the reference is single-threaded" % (rows, H, D, secs, full_secs, os.cpu_count() or 0)}
+                      "the reference is single-threaded" % (rows, H, D, secs, full_secs)}
 
 
 if __name__ == "__main__":

@@ -116,6 +116,10 @@ int adc_get_stage_ms(adc_handle* h, float* ms, int n);
 /* Per-kernel-launch average of the aggregation pass kernel over the last match (ms), and the
  * number of launches it averaged (8 for 4 iterations). */
 int adc_get_aggregate_pass_ms(adc_handle* h, float* avg_ms, int* launches);
+/* The same average with what it covers: number of REGULAR aggregation launches of the last match (the first pass is
+ * left out when it computed the matching cost itself: first_fused = 1, write-only), and the number of algorithmic
+ * passes (cross_aggregator.cpp:100-118, two per iteration) those launches covered -- a pass-pair launch covers two. */
+int adc_get_aggregate_info(adc_handle* h, float* avg_launch_ms, int* launches, int* passes, int* first_fused);
 
 /* Print the reference's six timing lines from Match (ADCensusStereo.cpp:88-129); default off. */
 void adc_set_verbose(adc_handle* h, int on);

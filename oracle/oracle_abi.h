@@ -45,6 +45,7 @@ typedef struct adc_oracle_dump {
 
 /* "reference" or "port". */
 const char* adc_oracle_kind(void);
+const char* adc_oracle_build_info(void);
 
 /* Whole pipeline stage by stage with dumps.  0 = ok, nonzero = Initialize failed. */
 int adc_oracle_run(int32_t width, int32_t height, const adc_option* opt,

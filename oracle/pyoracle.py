@@ -81,6 +81,11 @@ class Oracle:
         self.lib.adc_oracle_median3_inplace.restype = None
         self.lib.adc_oracle_median3_inplace.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         self.kind = self.lib.adc_oracle_kind().decode()
+        try:
+            self.lib.adc_oracle_build_info.restype = C.c_char_p
+            self.build_info = self.lib.adc_oracle_build_info().decode()
+        except AttributeError:  # a checker built before the symbol existed
+            self.build_info = "unknown"
 
     @staticmethod
     def _check_images(left, right):

@@ -73,6 +73,11 @@ void dump(T* dst, const T* src, size_t n)
 extern "C" {
 
 const char* adc_oracle_kind(void) { return "reference"; }
+/* compiler + flags this checker was built with (reported next to the CPU baseline by bench.py) */
+#ifndef ADC_ORACLE_FLAGS
+#define ADC_ORACLE_FLAGS "?"
+#endif
+const char* adc_oracle_build_info(void) { return "compiler " __VERSION__ ", flags " ADC_ORACLE_FLAGS; }
 
 int adc_oracle_run(int32_t width, int32_t height, const adc_option* opt,
                    const uint8_t* bgr_left, const uint8_t* bgr_right, adc_oracle_dump* out)

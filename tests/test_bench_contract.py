@@ -1,5 +1,7 @@
-"""bench.py's one-line JSON contract, checked on the committed sample outputs (profiles/r1_bench_*.json were written
-by `python bench.py` on an MI355X) and on the helpers that do not need a GPU."""
+"""bench.py's one-line JSON contract, checked on the committed sample outputs (profiles/r*_bench_*.json were written by
+`python bench.py` on an MI355X) and on the helpers that do not need a GPU."""
+import glob
+import importlib.util
 import json
 import os
 
@@ -8,9 +10,24 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
             "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict}
+SAMPLES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*.json")))
 
 
-@pytest.mark.parametrize("name", ["r1_bench_default.json", "r1_bench_structured.json"])
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _check_roofline(r):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", SAMPLES)
 def test_committed_bench_lines_follow_the_contract(name):
     path = os.path.join(ROOT, "profiles", name)
     lines = [l for l in open(path).read().splitlines() if l.strip()]
@@ -21,23 +38,57 @@ def test_committed_bench_lines_follow_the_contract(name):
     assert "vs_baseline" in o and o["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
     assert o["unit"] == "pairs/s" and o["higher_is_better"] is True and o["scaling"] == "weak" and o["dtype"] == "f32"
     assert "workload" in o["config"] and "model" not in o["config"]
-    r = o["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert abs(o["value"] - 1000.0 / o["ms_per_step"] * o["n_gpus"]) / o["value"] < 0.02  # one object in flight, N = 1
+    _check_roofline(o["roofline"])
+    if o["config"].get("in_flight_per_gpu", 1) == 1:
+        assert abs(o["value"] - 1000.0 / o["ms_per_step"] * o["n_gpus"]) / o["value"] < 0.02
     if "cpu_baseline" in o:
         c = o["cpu_baseline"]
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("reference", "port") and c["cores"] == 1
+    if name.startswith("r2_"):  # round-2 lines: the farm check and the extra legs
+        assert o["farm_check"]["ok"] is True and o["farm_check"]["done_counter"] == o["steps"] * o["n_gpus"]
+        r = o["roofline"]
+        assert r["hbm_frac"] <= r["frac"] + 1e-9 and r["passes_per_launch"] >= 1.0
+        for leg in ("structured", "noise"):
+            if leg in o:
+                _check_roofline(o[leg]["roofline"])
+        if o["n_gpus"] == 1 and "host_inclusive" in o:
+            assert o["host_inclusive"]["value"] < o["value"] * 1.05  # the host path cannot beat the resident one
+            assert set(("cpu_model", "build", "host_cores")) <= set(o["cpu_baseline"])
 
 
-def test_pmc_traffic_helper_reads_the_committed_profiles():
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    for wl in ("noise", "structured"):
-        t = bench.pmc_traffic(wl, (1920, 1080, 128))
-        assert t is not None and 2.1e9 < t < 2.4e9, (wl, t)  # ~2.13 GB algorithmic + segment halos
+def test_round2_sample_is_committed():
+    assert any(n.startswith("r2_bench_") for n in SAMPLES), "commit a round-2 bench.py output under profiles/"
+
+
+def test_pmc_traffic_helper():
+    bench = _bench()
     assert bench.pmc_traffic("noise", (640, 480, 64)) is None
+    for wl in ("noise", "structured"):
+        p = os.path.join(ROOT, "profiles", "r2_k4_pmc_traffic_%s.json" % wl)
+        t = bench.pmc_traffic(wl, (1920, 1080, 128))
+        if os.path.exists(p) and json.load(open(p)).get("k4_rev") == bench.K4_REV:
+            assert t is not None and 2.1e9 < t < 2.4e9, (wl, t)  # ~2.13 GB algorithmic + segment halos
+        else:
+            assert t is None  # a measurement of another kernel revision must not be reported
+
+
+def test_roofline_arithmetic():
+    """k4_roofline on synthetic aggregate_info tuples: a pair launch counts two passes of algorithmic bytes but one
+    volume in + one volume out of HBM traffic."""
+    bench = _bench()
+
+    class NoLib:
+        def adc_device_malloc(self, n):
+            return 0
+
+        def adc_device_free(self, p):
+            pass
+    W, H, D = 1920, 1080, 128
+    P, V = float(W * H), 4.0 * W * H * D
+    r = bench.k4_roofline([(0.5, 7, 7, True)], W, H, D, NoLib(), "structured")  # 7 single launches after the fused first pass
+    assert abs(r["algorithmic_bytes_per_launch"] - (7 * (2 * V + 4 * P) + 8 * P) / 7) < 1 and r["passes_per_launch"] == 1.0
+    assert abs(r["achieved"] - r["hbm_achieved"]) < 1e-6
+    r = bench.k4_roofline([(0.5, 4, 7, True)], W, H, D, NoLib(), "noise")  # 3 pairs + the last pass
+    assert abs(r["algorithmic_bytes_per_launch"] - (7 * (2 * V + 4 * P) + 8 * P) / 4) < 1
+    assert abs(r["hbm_bytes_per_launch"] - (4 * (2 * V + 4 * P) + 8 * P) / 4) < 1
+    assert r["frac"] > r["hbm_frac"] and abs(r["passes_per_launch"] - 1.75) < 1e-9
