@@ -65,6 +65,8 @@ struct adc_handle {
     uint8_t* elig;       // region voting: eligible mask of the current pass
     uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
     int32_t* vote_list;  // compact list of eligible pixels
+    int32_t* interp_list;     // target list of the interpolation (its own buffers: the voting chain may be CONTINUED after
+    int32_t* interp_counters; // the interpolation has run once, and must find its list and control block untouched)
     int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
     int32_t* ray_tab;     // [max_search][16] packed ray offsets (dy<<16 | dx&0xffff), NULL when a step is too close to a .5 tie
     int ray_tab_rows;
@@ -73,7 +75,11 @@ struct adc_handle {
     uint32_t* cost_lrec;
     int rrec_pitch, rrec_padl;
     int armmax_host[2];   // maximum horizontal / vertical arm of the current pair, read back by the pipeline
-    int armmax_valid;
+    int armmax_valid;     // 0 unknown (debug surface: two launches per pass, the kernels decide), 1 exact (read back),
+                          // 2 assumed from the previous Match of this handle (the small-ring kernels verify on the device and
+                          // raise armmax[3]; adc_wait then redoes the Match), 3 unknown in the pipeline: full ring (always valid)
+    int arm_known;        // armmax_host holds the maxima of the previous Match
+    int arm_redos;        // how often the assumption was wrong
     int fuse_cost;        // set by the pipeline: the first aggregation pass computes the matching cost itself
     int agg_first_fused;  // the last aggregation run did so (pass timings: the regular passes are 1..)
     int fuse_wta;         // set by the pipeline: the last scanline pass also writes the left-view disparity map
@@ -84,10 +90,17 @@ struct adc_handle {
     int median_fallbacks;      // how often adc_wait had to redo the median
     int32_t* pin_flags;   // pinned host word: error flag of the banded median's hand-off (read back after every Match)
     uint32_t* bgrx_l;     // left image packed B | G<<8 | R<<16 per pixel (interpolation gathers)
-    int32_t* irv_state;  // int2 per pixel: {disparity bits, eligibility / finality stamp} of the current voting pass
-    int32_t* vote_fin;   // finality stamps of the current voting pass (round+1 when the value became final)
-    int32_t* vote_counters; // [0]=list length, [1]=changed flag, [2]=evaluations(lo), ...
-    uint8_t* chg_a;      // change-tile map of the voting rounds (int32 stamp per 8x8 tile)
+    uint16_t* st16;      // region voting: 16-bit state map [H][st16_pitch] {bin:11 | final | eligible} (k_voting.hip)
+    int st16_pitch;      // row pitch of st16 in elements (multiple of 8: rows start 16-byte aligned)
+    float* disp_vote;    // the map the voting chain works on (copy of the LR-checked map, copied back when the chain ends)
+    int irv_budget;      // kernel pairs (A,B) the next Match enqueues for the voting chain (adapted from the last Match)
+    int irv_chain;       // kernels of the chain enqueued so far (continuation starts here)
+    int irv_pending;     // a chain was enqueued and its final state has not been looked at yet
+    int irv_overflows;   // how often adc_wait had to continue the chain (budget too small)
+    float *tail_disp_l, *tail_disp_tmp; // buffer roles at the start of the stages behind the voting (for a redo)
+    int32_t* vote_counters; // voting chain control block (state slots + accumulator ring), median progress words at [160..]
+    uint8_t* chg_a;      // change-tile map of the voting rounds: one byte stamp per 8x8 tile, row pitch chg_pitch
+    int chg_pitch;
     uint8_t* edge;       // discontinuity adjustment edge mask
     // pinned staging for adc_match / adc_match_async
     uint8_t* pin_in;  // 2 * 3*W*H
@@ -122,7 +135,8 @@ size_t adc_so_cls_bytes(int W, int H);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_lrcheck(adc_handle* h);
-hipError_t adc_run_region_voting(adc_handle* h); // contains host-side convergence checks
+hipError_t adc_run_region_voting(adc_handle* h); // enqueue only (device-driven chain with a launch budget)
+hipError_t adc_voting_finish(adc_handle* h, int* continued); // after a sync: continue the chain if the budget was too small
 hipError_t adc_launch_interpolation(adc_handle* h);
 hipError_t adc_launch_discontinuity(adc_handle* h);
 hipError_t adc_launch_median(adc_handle* h);

@@ -99,20 +99,28 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->label, P));
     HIP_OK(hipMalloc(&h->elig, P));
     HIP_OK(hipMalloc(&h->irv_bbox, P * 4));
-    HIP_OK(hipMalloc(&h->vote_list, P * 4));
-    HIP_OK(hipMalloc(&h->vote_dirty, P * 4));
-    HIP_OK(hipMalloc(&h->vote_fin, P * 4));
-    HIP_OK(hipMalloc(&h->irv_state, P * 8));
+    HIP_OK(hipMalloc(&h->vote_list, P * 8));  // int2 {pixel, arms} per entry
+    HIP_OK(hipMalloc(&h->vote_dirty, P * 8));
+    HIP_OK(hipMalloc(&h->interp_list, P * 4));
+    HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));
+    h->st16_pitch = (p.W + 7) & ~7;
+    HIP_OK(hipMalloc(&h->st16, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t)));
+    HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin
+    HIP_OK(hipMalloc(&h->disp_vote, P * 4));
     HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
-    const size_t tiles = (size_t)((p.W + 7) / 8) * ((p.H + 7) / 8);
-    HIP_OK(hipMalloc(&h->chg_a, tiles * 4));
+    h->irv_budget = 48;
+    // change-tile map of the voting rounds: one BYTE per 8x8 tile, rows padded to a multiple of 4 (+16: a 16-byte load
+    // may start at the last dword of a row)
+    h->chg_pitch = (((p.W + 7) / 8 + 3) & ~3) + 16;
+    const size_t tiles = (size_t)h->chg_pitch * ((p.H + 7) / 8) + 64;
+    HIP_OK(hipMalloc(&h->chg_a, tiles));
     HIP_OK(hipMalloc(&h->edge, P));
     HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
-    HIP_OK(hipHostMalloc(&h->pin_flags, 64, hipHostMallocDefault));
-    memset(h->pin_flags, 0, 64);
+    HIP_OK(hipHostMalloc(&h->pin_flags, 64 * sizeof(int32_t), hipHostMallocDefault));
+    memset(h->pin_flags, 0, 64 * sizeof(int32_t)); // [0] median error, [4..7] armmax + violation flag, [16..23] voting state
     HIP_OK(hipMemset(h->label, 0, P));
-    HIP_OK(hipMemset(h->chg_a, 0, tiles * 4));
+    HIP_OK(hipMemset(h->chg_a, 0, tiles));
     HIP_OK(hipMemset(h->vol_a, 0, VB));
     HIP_OK(hipMemset(h->vol_b, 0, VB));
     return hipSuccess;
@@ -237,7 +245,7 @@ void adc_destroy(adc_handle* h)
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->vote_fin, h->irv_state, h->vote_counters,
+                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->interp_list, h->interp_counters, h->st16, h->disp_vote, h->vote_counters,
                     h->chg_a, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
@@ -252,6 +260,15 @@ void adc_destroy(adc_handle* h)
 }
 
 // ------------------------------------------------------------------------------ the pipeline
+// the stages behind the region voting (redone by adc_wait when the voting chain had to be continued)
+static hipError_t run_refine_tail(adc_handle* h)
+{
+    const adc_option& o = h->p.opt;
+    if (o.do_filling && o.do_lr_check) HIP_OK(adc_launch_interpolation(h));
+    if (o.do_discontinuity_adjustment) HIP_OK(adc_launch_discontinuity(h));
+    HIP_OK(adc_launch_median(h));
+    return hipSuccess;
+}
 static hipError_t run_refine(adc_handle* h)
 {
     // MultiStepRefiner::Refine (multistep_refiner.cpp:60-87); do_filling drives both the voting and the
@@ -260,13 +277,11 @@ static hipError_t run_refine(adc_handle* h)
     const size_t P = (size_t)h->p.W * h->p.H;
     if (o.do_lr_check) HIP_OK(adc_launch_lrcheck(h));
     else HIP_OK(hipMemsetAsync(h->label, 0, P, h->stream));
-    if (o.do_filling && o.do_lr_check) {
-        HIP_OK(adc_run_region_voting(h));
-        HIP_OK(adc_launch_interpolation(h));
-    }
-    if (o.do_discontinuity_adjustment) HIP_OK(adc_launch_discontinuity(h));
-    HIP_OK(adc_launch_median(h));
-    return hipSuccess;
+    h->irv_pending = 0;
+    if (o.do_filling && o.do_lr_check) HIP_OK(adc_run_region_voting(h));
+    h->tail_disp_l = h->disp_l;
+    h->tail_disp_tmp = h->disp_tmp;
+    return run_refine_tail(h);
 }
 
 // The streaming phase (cost .. WTA, ~26 passes over the volume) of different objects on one device is
@@ -303,18 +318,21 @@ static hipError_t run_heavy(adc_handle* h)
     MARK(1, h->heavy);
     HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
     MARK(2, h->heavy);
-    {   // The maximum arm lengths decide the ring depth of the aggregation kernels and whether same-direction pass
-        // pairs can share a launch (k_aggregate.hip).  Reading two ints back costs one early host synchronisation
-        // (~0.15 ms into the pair; the queue refills while the first aggregation pass runs) and saves three volume
-        // round trips on short-arm images.  ADC_AGG_HOST_ARMS=0: no read-back, the kernels decide per launch.
-        static const bool host_arms = [] { const char* e = getenv("ADC_AGG_HOST_ARMS"); return e ? atoi(e) != 0 : true; }();
-        h->armmax_valid = 0;
+    {   // The maximum arm lengths decide the ring depth of the aggregation kernels and whether same-direction pass pairs
+        // can share a launch (k_aggregate.hip).  The host does NOT wait for them: it assumes the maxima of the previous
+        // Match of this handle (exact ring depth for that image), the small-ring kernels verify the assumption on the
+        // device (armmax[3] is raised and the pass skipped when an arm is longer) and adc_wait redoes the Match with the
+        // full ring -- which is valid for every image and is what the first Match of a handle uses.
+        // ADC_AGG_HOST_ARMS=1: read the two maxima back instead (one early host synchronisation, the round-1 behaviour).
+        static const bool host_arms = [] { const char* e = getenv("ADC_AGG_HOST_ARMS"); return e ? atoi(e) != 0 : false; }();
         if (host_arms && h->pin_flags) {
             HIP_OK(hipMemcpyAsync(h->pin_flags + 4, h->armmax, 2 * sizeof(int), hipMemcpyDeviceToHost, h->heavy));
             HIP_OK(hipStreamSynchronize(h->heavy));
             h->armmax_host[0] = h->pin_flags[4];
             h->armmax_host[1] = h->pin_flags[5];
             h->armmax_valid = 1;
+        } else {
+            h->armmax_valid = h->arm_known ? 2 : 3;
         }
     }
     HIP_OK(adc_launch_records(h));
@@ -336,6 +354,8 @@ static hipError_t run_heavy(adc_handle* h)
     MARK(4, h->heavy);
     HIP_OK(adc_launch_wta(h));                   // ComputeDisparity + ComputeDisparityRight, :108-109
     MARK(5, h->heavy);
+    // maxima + violation flag of this pair, looked at by adc_wait (they seed the next Match's assumption)
+    if (h->pin_flags) HIP_OK(hipMemcpyAsync(h->pin_flags + 4, h->armmax, 4 * sizeof(int), hipMemcpyDeviceToHost, h->heavy));
     HIP_OK(hipEventRecord(h->ev_heavy_done, h->heavy));
     if (h->heavy != h->stream) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_heavy_done, 0));
 #undef MARK
@@ -382,6 +402,15 @@ static void collect_timings(adc_handle* h)
     }
 }
 
+// the final map -> where the caller wants it (pinned staging for host callers, the caller's device buffer otherwise)
+static hipError_t enqueue_output(adc_handle* h)
+{
+    const size_t P = (size_t)h->p.W * h->p.H;
+    if (h->async_dst) return hipMemcpyAsync(h->pin_out, h->disp_l, P * 4, hipMemcpyDeviceToHost, h->stream);
+    if (h->device_dst) return hipMemcpyAsync(h->device_dst, h->disp_l, P * 4, hipMemcpyDeviceToDevice, h->stream);
+    return hipSuccess;
+}
+
 int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, void* d_disp)
 {
     if (!h || !d_left || !d_right || !d_disp) return 1; // ADCensusStereo.cpp:71-76
@@ -390,8 +419,9 @@ int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, voi
     if (hipMemcpyAsync(h->img_l, d_left, P * 3, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
     if (hipMemcpyAsync(h->img_r, d_right, P * 3, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
     if (run_pipeline(h) != hipSuccess) return 2;
-    if (hipMemcpyAsync(d_disp, h->disp_l, P * 4, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
     h->device_dst = d_disp;
+    h->async_dst = nullptr;
+    if (enqueue_output(h) != hipSuccess) return 2;
     return 0;
 }
 
@@ -405,8 +435,9 @@ int adc_match_async(adc_handle* h, const uint8_t* left, const uint8_t* right, fl
     if (hipMemcpyAsync(h->img_l, h->pin_in, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
     if (hipMemcpyAsync(h->img_r, h->pin_in + P * 3, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
     if (run_pipeline(h) != hipSuccess) return 2;
-    if (hipMemcpyAsync(h->pin_out, h->disp_l, P * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 2;
     h->async_dst = disp;
+    h->device_dst = nullptr;
+    if (enqueue_output(h) != hipSuccess) return 2;
     return 0;
 }
 
@@ -415,23 +446,55 @@ int adc_wait(adc_handle* h)
     if (!h) return 1;
     hipSetDevice(h->device);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("adc_wait", hipGetLastError()); return 2; }
+    // (1) the aggregation assumed the arm maxima of the previous Match; a longer arm raised the flag and the pass was
+    //     skipped: redo the whole Match with the full ring (valid for every image).  The inputs are still in HBM.
+    if (h->pin_flags) {
+        if (h->pin_flags[7] != 0) {
+            h->arm_redos++;
+            h->arm_known = 0;
+            hipError_t e = run_pipeline(h);
+            if (e == hipSuccess) e = enqueue_output(h);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { set_error("adc_wait: redo with the full aggregation ring", e); return 2; }
+        }
+        h->armmax_host[0] = h->pin_flags[4];
+        h->armmax_host[1] = h->pin_flags[5];
+        h->arm_known = 1;
+    }
+    // (2) the voting chain ran out of its launch budget before it converged: continue it, redo the stages behind it
+    int continued = 0;
+    hipError_t e = hipSuccess;
+    if (h->irv_pending) {
+        // the continuation delivers into the buffer that was disp_l when the chain was enqueued (the stages behind the
+        // voting have swapped the roles since)
+        float *now_l = h->disp_l, *now_tmp = h->disp_tmp;
+        h->disp_l = h->tail_disp_l;
+        h->disp_tmp = h->tail_disp_tmp;
+        e = adc_voting_finish(h, &continued);
+        if (!continued) { h->disp_l = now_l; h->disp_tmp = now_tmp; }
+    }
+    if (e == hipSuccess && continued) {
+        e = run_refine_tail(h);
+        if (e == hipSuccess) e = enqueue_output(h);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    if (e != hipSuccess) { set_error("adc_wait: region voting continuation", e); return 2; }
+    // (3) a median band gave up waiting for its upstream band: the map is incomplete -- redo the filter with the
+    //     single-workgroup kernel (no inter-workgroup dependency) and deliver that result
     if (h->pin_flags && (h->pin_flags[0] != 0 || h->force_median_fallback)) {
-        // a median band gave up waiting for its upstream band: the map is incomplete -- redo the filter with the
-        // single-workgroup kernel (no inter-workgroup dependency) and deliver that result
         h->pin_flags[0] = 0;
-        const size_t P = (size_t)h->p.W * h->p.H;
-        hipError_t e = adc_median_fallback(h);
-        if (e == hipSuccess && h->async_dst) e = hipMemcpy(h->pin_out, h->disp_l, P * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && h->device_dst) e = hipMemcpy(h->device_dst, h->disp_l, P * 4, hipMemcpyDeviceToDevice);
+        e = adc_median_fallback(h);
+        if (e == hipSuccess) e = enqueue_output(h);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         h->median_fallbacks++;
         if (e != hipSuccess) { set_error("adc_wait: median fallback", e); return 2; }
     }
-    h->device_dst = nullptr;
     h->force_median_fallback = 0;
     if (h->async_dst) {
         memcpy(h->async_dst, h->pin_out, (size_t)h->p.W * h->p.H * 4);
         h->async_dst = nullptr;
     }
+    h->device_dst = nullptr;
     collect_timings(h);
     return 0;
 }
@@ -592,7 +655,12 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
         break;
     case ADC_RUN_WTA: e = adc_launch_wta(h); break;
     case ADC_RUN_LRCHECK: e = adc_launch_lrcheck(h); break;
-    case ADC_RUN_REGION_VOTING: e = adc_run_region_voting(h); break;
+    case ADC_RUN_REGION_VOTING: // arg > 0: launch budget (kernel pairs) of this run, e.g. 4 to force the continuation path
+        if (arg > 0) h->irv_budget = arg;
+        e = adc_run_region_voting(h);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) { int cont = 0; e = adc_voting_finish(h, &cont); }
+        break;
     case ADC_RUN_INTERPOLATION: e = adc_launch_interpolation(h); break;
     case ADC_RUN_DISCONTINUITY: e = adc_launch_discontinuity(h); break;
     case ADC_RUN_MEDIAN: // arg 100: test hook -- arm the fallback path of the NEXT adc_wait (as if a band had timed out)
@@ -613,6 +681,9 @@ int64_t adc_debug_counter(adc_handle* h, int which)
     if (!h) return -1;
     switch (which) {
     case 0: return h->median_fallbacks;
+    case 1: return h->irv_overflows;
+    case 2: return h->arm_redos;
+    case 3: return h->irv_budget;
     default: return -1;
     }
 }

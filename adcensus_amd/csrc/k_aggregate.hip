@@ -226,9 +226,17 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
     // 32 waves/CU and the full-ring variant exits at once, otherwise the other way round (armmax[0] = max horizontal
     // arm, armmax[1] = max vertical arm, from k_build_arms).  small_variant < 0: the host has read armmax and
     // launches only the variant that applies.
+    // small_variant == 2: the host ASSUMED (from the previous Match of the handle) that no arm of this direction exceeds
+    // small_L = the ring depth of this launch; when the assumption is wrong the pass is skipped and armmax[3] raised --
+    // adc_wait then redoes the Match with the full ring.
     if (small_variant >= 0) {
         const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
-        if ((small_variant != 0) != fits_small) return;
+        if (small_variant == 2) {
+            if (!fits_small) {
+                if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int*>(armmax)[3] = 1;
+                return;
+            }
+        } else if ((small_variant != 0) != fits_small) return;
     }
     extern __shared__ __attribute__((aligned(16))) float ring_all[];
     const int R = 2 * L + 1;
@@ -715,7 +723,8 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const long long waves = nlines * nseg;
         const int per_xcd = (int)((waves + 7) / 8);
         const bool both = which == 0 && small_L > 0 && small_L < L;
-        const int sv = both ? variant : -1, sl = both ? small_L : 0x7fffffff;
+        const bool verify = variant == 1 && which == 1 && h->armmax_valid == 2; // ring depth assumed from the previous Match
+        const int sv = both ? variant : (verify ? 2 : -1), sl = both ? small_L : (verify ? Lv : 0x7fffffff);
         AggCostIn ci;
         ci.rrec = reinterpret_cast<const uint4*>(h->cost_rrec);
         ci.lrec = reinterpret_cast<const uint4*>(h->cost_lrec);
@@ -783,7 +792,9 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     const int small_L = adc_agg_small_L(h);
     const bool small_ok = small_L > 0 && small_L < Lfull;
     int which_h = 0, which_v = 0; // 0 = let the kernels decide (two launches per pass)
-    if (h->armmax_valid && marching) {
+    if (h->armmax_valid == 3 && marching) { // nothing known about this image: the full ring is valid for every image
+        which_h = which_v = 2;
+    } else if (h->armmax_valid && marching) {
         which_h = (small_ok && h->armmax_host[0] <= small_L) ? 1 : 2;
         which_v = (small_ok && h->armmax_host[1] <= small_L) ? 1 : 2;
     }

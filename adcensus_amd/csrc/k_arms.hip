@@ -147,7 +147,7 @@ hipError_t adc_launch_arms(adc_handle* h)
 {
     const AdcParams& p = h->p;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
-    hipMemsetAsync(h->armmax, 0, 2 * sizeof(int), h->heavy);
+    hipMemsetAsync(h->armmax, 0, 4 * sizeof(int), h->heavy); // [0],[1] maxima, [3] "assumed ring depth too small" flag (k_aggregate.hip)
     hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->img_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
                        p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2, h->armmax);
     hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,

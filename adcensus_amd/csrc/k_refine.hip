@@ -87,27 +87,8 @@ hipError_t adc_launch_lrcheck(adc_handle* h)
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------ K8 region voting
-#define IRV_TILE 8
-
-// Dependency box of a pixel's vote: the cross region of p spans rows y-top..y+bottom, but only pixels that PRECEDE p in
-// raster order can influence it, i.e. rows y-top..y; its horizontal extent is the widest H arm of those rows.
-// bbox[p] = {top, max left arm, max right arm} (computed once per Match; arms do not change).
-__global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arms, uchar4* __restrict__ bbox, int W, int H)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const uchar4 a = arms[(size_t)y * W + x];
-    int ml = 0, mr = 0;
-    for (int t = -(int)a.z; t <= 0; t++) {
-        const uchar4 q = arms[(size_t)(y + t) * W + x];
-        ml = adc_imax(ml, (int)q.x);
-        mr = adc_imax(mr, (int)q.y);
-    }
-    bbox[(size_t)y * W + x] = make_uchar4(a.z, (unsigned char)ml, (unsigned char)mr, 0);
-}
-
+// ------------------------------------------------------------------------------ K8 region voting: k_voting.hip
+// (the list compaction below is what is left here: the interpolation uses it to build its target lists)
 // Pass set-up: elig = pixels of this list that are still invalid (the ordering mask of the pass);
 // the work list only keeps those that CAN be filled: the vote needs count > irv_ts and count <= region
 // size == horizontal-first support count, so pixels with sup_h <= irv_ts stay invalid whatever happens.
@@ -164,253 +145,6 @@ __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ l
         if (listed[k]) list[mine + __popcll(m[k] & ((1ull << lane) - 1ull))] = p;
         off += wcnt[k][0] + wcnt[k][1] + wcnt[k][2] + wcnt[k][3];
     }
-}
-
-// counters layout (int32): [0] list length  [2] evaluations  [8 + (r&63)] "round r changed something"
-//                           [72 + (r&63)] number of dirty entries of round r
-// chg[tile] = r + 1 when a pixel of the tile changed in round r (cleared once per pass).
-#define IRV_FLAG(r) (8 + ((r)&63))
-#define IRV_NDIRTY(r) (72 + ((r)&63))
-
-// Round r > 0, step 1: one thread per list entry decides whether the entry must be re-evaluated: some pixel
-// of its dependency box (k_irv_bbox) changed in round r-1 (8x8 change tiles).  Dirty entries are compacted.
-__global__ __launch_bounds__(256) void k_irv_check(const int32_t* __restrict__ list, int n, const int32_t* __restrict__ chg,
-                                                   const uchar4* __restrict__ bbox, int32_t* __restrict__ dlist,
-                                                   int32_t* __restrict__ counters, int W, int H, int round,
-                                                   const int32_t* __restrict__ fin)
-{
-    if (counters[IRV_FLAG(round - 1)] == 0) return; // previous round changed nothing: converged
-    __shared__ int wcnt[4];
-    __shared__ int base;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tiles_x = (W + IRV_TILE - 1) / IRV_TILE;
-    bool dirty = false;
-    int p = -1;
-    if (i < n && fin[list[i]] == 0) { // final values are never re-evaluated
-        p = list[i];
-        const int y = p / W, x = p - y * W;
-        const uchar4 bb = bbox[p];
-        const int tx0 = adc_imax(0, x - (int)bb.y) / IRV_TILE, tx1 = adc_imin(W - 1, x + (int)bb.z) / IRV_TILE;
-        const int ty0 = adc_imax(0, y - (int)bb.x) / IRV_TILE, ty1 = y / IRV_TILE;
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) dirty |= chg[ty * tiles_x + tx] == round; // changed in round-1
-    }
-    const unsigned long long m = __ballot(dirty);
-    if (lane == 0) wcnt[wave] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        base = tot ? atomicAdd(&counters[IRV_NDIRTY(round)], tot) : 0;
-    }
-    __syncthreads();
-    if (dirty) {
-        int off = base;
-        for (int w = 0; w < wave; w++) off += wcnt[w];
-        off += __popcll(m & ((1ull << lane) - 1ull));
-        dlist[off] = p;
-    }
-}
-
-// Step 2: one wave per entry to evaluate: all 64 lanes sweep the cross region (4 region rows x 16 columns
-// per trip) into an LDS histogram, wave arg-max with lowest-bin tie-break, in-place (chaotic) update.
-// IRV_U = region rows per 16-lane group and trip, IRV_J = 16-column chunks per row and trip (wider rows loop): the
-// number of gathers in flight per lane (IRV_U*IRV_J) trades trips per vote against registers, i.e. waves per SIMD.
-template <int IRV_U, int IRV_J>
-__global__ __launch_bounds__(256) void k_irv_vote(const int32_t* __restrict__ work, int n_full, float* disp,
-                                                  const uint8_t* __restrict__ elig, const uchar4* __restrict__ arms,
-                                                  int32_t* __restrict__ chg, int32_t* __restrict__ counters, int W, int H, int dmin,
-                                                  int D, int irv_ts, float irv_th, int round, int32_t* fin, int2* state)
-{
-    int n = n_full; // round 0 evaluates the whole list
-    if (round > 0) {
-        if (counters[IRV_FLAG(round - 1)] == 0) return;
-        n = counters[IRV_NDIRTY(round)];
-    }
-    extern __shared__ int hist_all[]; // [4][D]: one histogram per wave (dynamic: 4 * D * 4 bytes)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int* hist = hist_all + wave * D;
-    const int tiles_x = (W + IRV_TILE - 1) / IRV_TILE;
-    const int nwaves = gridDim.x * 4;
-    for (int e = blockIdx.x * 4 + wave; e < n; e += nwaves) {
-        const int p = work[e];
-        const int y = p / W, x = p - y * W;
-        for (int b = lane; b < D; b += 64) hist[b] = 0;
-        bool deps_open = false;
-        const uchar4 arm = arms[p];
-        const int top = (int)arm.z, nrows = top + (int)arm.w + 1; // region rows y-top .. y+bottom (<= 2*255+1)
-        // the H arms of all region rows are fetched in ONE round trip (lane r holds row r), then handed to the
-        // 16-lane row groups with a shuffle; 4 rows x 16 columns of the region are read per trip
-        for (int rbase = 0; rbase < nrows; rbase += 64) {
-            const int myr = rbase + lane;
-            uint32_t a2 = 0;
-            if (myr < nrows) a2 = reinterpret_cast<const uint32_t*>(arms)[(y - top + myr) * W + x];
-            const int sub = lane >> 4, sl = lane & 15;
-            const int rend = adc_imin(nrows - rbase, 64);
-            // 16 region rows per trip: every 16-lane group takes 4 rows (r0+sub, +4, +8, +12) x 5 column chunks,
-            // i.e. 20 gathers per lane in flight at once -- the vote is latency-bound (one wave, few dependent
-            // round trips), so the trip count is what matters: <= 5 trips for the largest region of the default
-            // arm length instead of 18
-            for (int r0 = 0; r0 < rend; r0 += 4 * IRV_U) {
-                int yt[IRV_U], l2[IRV_U], r2[IRV_U];
-#pragma unroll
-                for (int u = 0; u < IRV_U; u++) {
-                    const int r = r0 + 4 * u + sub;
-                    const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
-                    yt[u] = y - top + rbase + r;
-                    l2[u] = (int)(arm2 & 255u);
-                    r2[u] = r < rend ? (int)((arm2 >> 8) & 255u) : -0x10000; // no column of a row past the end is <= r2
-                }
-                for (int cb = 0;; cb += 16 * IRV_J) { // one iteration unless a row is wider than 16*IRV_J
-                    int2 st[IRV_U][IRV_J];
-#pragma unroll
-                    for (int u = 0; u < IRV_U; u++)
-#pragma unroll
-                        for (int j = 0; j < IRV_J; j++) {
-                            const int s2 = -l2[u] + sl + cb + 16 * j;
-                            const int q = s2 <= r2[u] ? yt[u] * W + x + s2 : p; // clamped: loads stay unconditional
-                            st[u][j] = state[q];
-                        }
-                    bool more = false;
-#pragma unroll
-                    for (int u = 0; u < IRV_U; u++) {
-#pragma unroll
-                        for (int j = 0; j < IRV_J; j++) {
-                            const int s2 = -l2[u] + sl + cb + 16 * j;
-                            const int q = yt[u] * W + x + s2;
-                            const bool in = s2 <= r2[u];
-                            float v = __int_as_float(st[u][j].x);
-                            const int meta = st[u][j].y;
-                            const bool el = meta >= 0;
-                            // eligible pixels of this pass: visible only if they precede p in raster order
-                            // (already processed by the sequential scan), otherwise still invalid
-                            if (!in || (el && q >= p)) v = ADC_INVALID_FLOAT;
-                            // an eligible predecessor whose value was not yet final before this round: my vote may still change
-                            if (in && el && q < p && !(meta != 0 && meta <= round + 1)) deps_open = true;
-                            if (v != ADC_INVALID_FLOAT) {
-                                const int b = (int)lroundf(v) - dmin; // multistep_refiner.cpp:193-196
-                                if (b >= 0 && b < D) atomicAdd(&hist[b], 1);
-                            }
-                        }
-                        more |= (-l2[u] + cb + 16 * IRV_J) <= r2[u];
-                    }
-                    if (!__any(more)) break;
-                }
-            }
-        }
-        // first maximum (lowest bin on ties) and total count (multistep_refiner.cpp:199-209)
-        int bh = 0, bb = 0x7fffffff, cnt = 0;
-        for (int b = lane; b < D; b += 64) {
-            const int hv = hist[b];
-            cnt += hv;
-            if (hv > bh) { bh = hv; bb = b; }
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const int oh = __shfl_xor(bh, m, 64), ob = __shfl_xor(bb, m, 64);
-            cnt += __shfl_xor(cnt, m, 64);
-            const bool take = (oh > bh) || (oh == bh && ob < bb);
-            bh = take ? oh : bh;
-            bb = take ? ob : bb;
-        }
-        const float nv = adc_vote_decide(bb, bh, cnt, dmin, irv_ts, irv_th);
-        const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
-        if (lane == 0) {
-            if (all_final) { fin[p] = round + 2; state[p].y = round + 2; } // visible as "final" to rounds > this one only
-            const float cur = disp[p];
-            if (__float_as_uint(cur) != __float_as_uint(nv)) {
-                disp[p] = nv;
-                state[p].x = __float_as_int(nv);
-                chg[(y / IRV_TILE) * tiles_x + x / IRV_TILE] = round + 1;
-                counters[IRV_FLAG(round)] = 1;
-            }
-        }
-    }
-}
-
-hipError_t adc_run_region_voting(adc_handle* h)
-{
-    const AdcParams& p = h->p;
-    const int P = p.W * p.H;
-    const int tiles = ((p.W + IRV_TILE - 1) / IRV_TILE) * ((p.H + IRV_TILE - 1) / IRV_TILE);
-    const int Lmax = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
-    const int min_region = Lmax <= 127 ? p.opt.irv_ts : -1; // u16 support counts cannot wrap for L <= 127
-    static const int shape = [] { const char* e = getenv("ADC_IRV_SHAPE"); return e ? atoi(e) : 22; }();
-    const int BATCH0 = 8; // rounds launched per host check at the start of a pass (a converged pass turns the rest into no-ops)
-    h->vote_rounds = 0;
-    h->vote_evals = 0;
-    hipError_t e = hipSuccess;
-    int32_t host_cnt[136];
-    {
-        dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
-        hipLaunchKernelGGL(k_irv_bbox, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms),
-                           reinterpret_cast<uchar4*>(h->irv_bbox), p.W, p.H);
-    }
-    int32_t* chg = reinterpret_cast<int32_t*>(h->chg_a);
-    for (int it = 0; it < 5; it++) {         // multistep_refiner.cpp:167
-        bool filled_any = false; // an iteration that fills nothing leaves the map unchanged: the remaining ones are no-ops
-        for (int k = 0; k < 2; k++) {        // mismatches, then occlusions (:170-171)
-            if ((e = hipMemsetAsync(h->vote_counters, 0, 136 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_irv_begin, dim3((P + 256 * IRV_BEGIN_PPT - 1) / (256 * IRV_BEGIN_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
-                               h->vote_list, h->vote_counters, k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION, P, min_region, h->vote_fin,
-                               reinterpret_cast<int2*>(h->irv_state));
-            if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
-            const int n = host_cnt[0];
-            if (n == 0) continue;
-            if ((e = hipMemsetAsync(chg, 0, (size_t)tiles * sizeof(int32_t), h->stream)) != hipSuccess) return e;
-            const unsigned vote_blocks_full = (unsigned)adc_imin((n + 3) / 4, 256 * 8);
-            const unsigned check_blocks = (unsigned)((n + 255) / 256);
-            bool done = false;
-            int hint = n; // dirty entries expected per round of the next batch (sizes the vote grid; any size is correct)
-            for (int r0 = 0, BATCH = BATCH0; !done; r0 += BATCH) {
-                // two batches of 8 rounds, then 16 per host check: the long tail consists of short rounds, where the host
-                // round trip (~50 us) costs more than a few no-op launches after convergence
-                BATCH = r0 < 16 ? BATCH0 : 2 * BATCH0;
-                if (r0 > 0) { // recycle the flag / count rings for this batch (the previous round's flag must stay)
-                    // r0 is a multiple of the batch size, which divides 64: the batch's ring entries are contiguous
-                    hipMemsetAsync(h->vote_counters + IRV_FLAG(r0), 0, BATCH * sizeof(int32_t), h->stream);
-                    hipMemsetAsync(h->vote_counters + IRV_NDIRTY(r0), 0, BATCH * sizeof(int32_t), h->stream);
-                }
-                const unsigned vote_blocks = (unsigned)adc_imax(64, adc_imin((hint + hint / 4 + 3) / 4, 256 * 8));
-                for (int round = r0; round < r0 + BATCH; round++) {
-                    if (round > 0)
-                        hipLaunchKernelGGL(k_irv_check, dim3(check_blocks), dim3(256), 0, h->stream, h->vote_list, n, chg,
-                                           reinterpret_cast<const uchar4*>(h->irv_bbox), h->vote_dirty, h->vote_counters, p.W,
-                                           p.H, round, h->vote_fin);
-#define IRV_VOTE(U_, J_)                                                                                              \
-    hipLaunchKernelGGL((k_irv_vote<U_, J_>), dim3(round == 0 ? vote_blocks_full : vote_blocks), dim3(256), (size_t)4 * p.D * sizeof(int), h->stream, \
-                       round == 0 ? h->vote_list : h->vote_dirty, n, h->disp_l, h->elig,                              \
-                       reinterpret_cast<const uchar4*>(h->arms), chg, h->vote_counters, p.W, p.H, p.dmin, p.D,        \
-                       p.opt.irv_ts, p.opt.irv_th, round, h->vote_fin, reinterpret_cast<int2*>(h->irv_state))
-                    if (shape == 45) IRV_VOTE(4, 5);
-                    else if (shape == 23) IRV_VOTE(2, 3);
-                    else IRV_VOTE(2, 2); // default: 62 VGPRs -> 8 waves per SIMD.  Measured on the structured 1080p pair
-                                         // (refinement stage): 4x5 12.1 ms, 4x3 9.9, 2x3 9.0, 2x2 8.4, 1x2 8.7 -- the votes are
-                                         // latency-bound, so waves in flight beat gathers in flight per wave
-#undef IRV_VOTE
-                }
-                if ((e = hipMemcpyAsync(host_cnt, h->vote_counters, 136 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
-                if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
-                if (r0 == 0 && host_cnt[IRV_FLAG(0)] != 0) filled_any = true;
-                if (getenv("ADC_IRV_TRACE")) {
-                    fprintf(stderr, "[irv] it=%d list=%d n=%d r0=%d dirty:", it, k, n, r0);
-                    for (int round = r0; round < r0 + BATCH; round++)
-                        fprintf(stderr, " %d%s", round == 0 ? n : host_cnt[IRV_NDIRTY(round)], host_cnt[IRV_FLAG(round)] ? "*" : "");
-                    fprintf(stderr, "\n");
-                }
-                hint = adc_imax(1, host_cnt[IRV_NDIRTY(r0 + BATCH - 1)]);
-                for (int round = r0; round < r0 + BATCH; round++) {
-                    h->vote_rounds++;
-                    h->vote_evals += round == 0 ? n : host_cnt[IRV_NDIRTY(round)]; // votes evaluated (statistics)
-                    if (host_cnt[IRV_FLAG(round)] == 0) { done = true; break; } // full round without change: fixed point
-                }
-                if (r0 > n + 16) return hipErrorUnknown; // cannot happen: the triangular system converges in <= n rounds
-            }
-        }
-        if (!filled_any) break;
-    }
-    return hipGetLastError();
 }
 
 // --------------------------------------------------------------------------- K9 proper interpolation
@@ -645,15 +379,15 @@ hipError_t adc_launch_interpolation(adc_handle* h)
         const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
         if (rays) {
             hipError_t e;
-            if ((e = hipMemsetAsync(h->vote_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_irv_begin, dim3((P + 256 * IRV_BEGIN_PPT - 1) / (256 * IRV_BEGIN_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
-                               h->vote_list, h->vote_counters, which, P, -1, (int32_t*)nullptr, (int2*)nullptr);
+                               h->interp_list, h->interp_counters, which, P, -1, (int32_t*)nullptr, (int2*)nullptr);
             if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
             if (h->ray_tab && max_search == h->ray_tab_rows) {
                 if (k == 0) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
                 static const int ns = [] { const char* e = getenv("ADC_INTERP_NS"); return e ? atoi(e) : 4; }(); // ray steps per trip
 #define INTERP_TAB(NS_)                                                                                                \
-    hipLaunchKernelGGL(k_interpolate_tab<NS_>, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters,    \
+    hipLaunchKernelGGL(k_interpolate_tab<NS_>, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters,    \
                        h->disp_l, h->disp_tmp, h->bgrx_l, h->ray_tab, p.W, p.H, which, max_search)
                 if (ns == 8) INTERP_TAB(8);
                 else if (ns == 16) INTERP_TAB(16);
@@ -662,7 +396,7 @@ hipError_t adc_launch_interpolation(adc_handle* h)
 #undef INTERP_TAB
             }
             else
-                hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->vote_list, h->vote_counters, h->disp_l,
+                hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_l,
                                    h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
         } else {
             hipLaunchKernelGGL(k_interpolate, grid, block, 0, h->stream, h->disp_l, h->disp_tmp, h->label, h->img_l, h->ray_sincos,

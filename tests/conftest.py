@@ -48,8 +48,10 @@ def emul():
     import ctypes
     out_dir = os.path.join(ROOT, "tests", "emul", "_build")
     so = os.path.join(out_dir, "libadcensus_emul.so")
-    srcs = [os.path.join(ROOT, "tests", "emul", "emul.cpp"), os.path.join(ROOT, "tests", "emul", "emul_rr.cpp")]
-    hdrs = [os.path.join(ROOT, "adcensus_amd", "csrc", "adc_device_fn.h"), os.path.join(ROOT, "adcensus_amd", "csrc", "k_aggregate_rr.h")]
+    srcs = [os.path.join(ROOT, "tests", "emul", "emul.cpp"), os.path.join(ROOT, "tests", "emul", "emul_rr.cpp"),
+            os.path.join(ROOT, "tests", "emul", "emul_irv.cpp")]
+    hdrs = [os.path.join(ROOT, "adcensus_amd", "csrc", "adc_device_fn.h"), os.path.join(ROOT, "adcensus_amd", "csrc", "k_aggregate_rr.h"),
+            os.path.join(ROOT, "adcensus_amd", "csrc", "irv_plan.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs + hdrs):
         os.makedirs(out_dir, exist_ok=True)
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-Wno-unknown-pragmas", "-fPIC", "-shared", *srcs, "-o", so])

@@ -214,6 +214,16 @@ def test_refiner_parallel_forms(emul, dumps, name):
         emul.emul_region_voting(P(d), P(o["outlier_label"]), P(o["arms"]), w, h, dmin, D, opt.irv_ts, C.c_float(opt.irv_th),
                                 max(0, min(opt.cross_L1, 255)), seed, C.byref(ev))
         assert same(d, o["disp_after_irv"])
+    # the device-driven chain (k_voting.hip): state machine of irv_plan.h on the 16-bit state map, shuffled vote order
+    emul.emul_irv_chain.restype = C.c_long
+    for seed in (3, 77):
+        d = o["disp_after_lr"].copy()
+        stats = (C.c_long * 3)()
+        L = max(0, min(opt.cross_L1, 255))
+        rounds = emul.emul_irv_chain(P(d), P(o["outlier_label"]), P(o["arms"]), P(o["sup_count_h"]), w, h, dmin, D, opt.irv_ts,
+                                     C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, 0, stats)
+        assert rounds >= 0, rounds
+        assert same(d, o["disp_after_irv"])
     a, b = o["disp_after_irv"].copy(), np.empty((h, w), np.float32)
     ms = max(abs(opt.max_disparity), abs(opt.min_disparity))
     emul.emul_interpolate(P(a), P(b), P(o["outlier_label"]), P(left), w, h, 1, ms)

@@ -100,6 +100,43 @@ def test_median_handoff_timeout_falls_back(hip, oracle):
     st.Release()
 
 
+def test_async_pipeline_assumptions_and_budgets(hip, oracle):
+    """Match never waits for the device in mid-pipeline: the aggregation ASSUMES the arm maxima of the previous Match of the
+    handle and the voting chain has a launch BUDGET adapted from the previous Match.  Both are verified / completed by
+    adc_wait -- wrong assumptions cost time, never correctness.  Sequence on ONE handle: structured pair (long arms, many
+    voting rounds), noise pair (short arms, no rounds), structured again (assumed short arms: wrong -> redo; budget too
+    small -> continuation), every result bit-exact."""
+    A = hip
+    from oracle import pyoracle
+    from adcensus_amd import workloads
+    w, h, d = 256, 160, 64
+    opt = pyoracle.Option(max_disparity=d)
+    s_pair = workloads.structured_pair(w, h, d, seed=41)
+    n_pair = workloads.noise_pair(w, h, seed=42)
+    want_s = oracle.run(s_pair[0], s_pair[1], opt, stages=["disp_final"])["disp_final"]
+    want_n = oracle.run(n_pair[0], n_pair[1], opt, stages=["disp_final"])["disp_final"]
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(w, h, cases.to_product_option(opt))
+
+    def same(a, b):
+        return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert same(st.match(*s_pair), want_s)           # first Match: full ring, default budget
+    redo0, over0 = st.debug_counter(2), st.debug_counter(1)
+    assert same(st.match(*s_pair), want_s)           # same image again: assumptions hold
+    assert st.debug_counter(2) == redo0 and st.debug_counter(1) == over0
+    assert same(st.match(*n_pair), want_n)           # short arms after long arms: the full ring stays valid, no redo
+    assert st.debug_counter(2) == redo0
+    small_budget = st.debug_counter(3)
+    assert same(st.match(*n_pair), want_n)           # now the small ring is assumed (and right)
+    assert st.debug_counter(2) == redo0
+    assert same(st.match(*s_pair), want_s)           # long arms while the small ring is assumed: detected on the device, redone
+    assert st.debug_counter(2) == redo0 + 1
+    assert st.debug_counter(1) >= over0 + 1          # and the noise-sized voting budget was too small: continued
+    assert st.debug_counter(3) > small_budget
+    assert same(st.match(*s_pair), want_s)
+    st.Release()
+
+
 def test_aggregation_fast_path_equals_direct(hip, oracle, monkeypatch):
     """A/B: the marching-ring kernel and the one-thread-per-element direct kernel agree bit-for-bit."""
     A = hip
