@@ -1,12 +1,12 @@
 // adcensus_cli.cpp -- counterpart of the reference's demo (main.cpp:34-145) without OpenCV:
-//   adcensus_cli left.ppm right.ppm [dmin] [dmax] [out_prefix]
-// reads two binary PPM (P6, 8-bit RGB) images, runs ADCensusStereo::Initialize / Match exactly like
-// main.cpp:80-118 and writes
-//   <out>-d.pgm   min-max normalised 8-bit disparity (SaveDisparityMap, main.cpp:180-206)
-//   <out>-c.ppm   JET colour map of it (cv::applyColorMap(..., COLORMAP_JET), main.cpp:207)
-//   <out>.pfm     raw float32 disparity
-//   <out>.txt     x y disparity point list (SaveDisparityCloud without the Q-matrix, main.cpp:212-230)
-// PNG <-> PPM conversion: tools/png2ppm.py (PIL).
+//   adcensus_cli left.{png,ppm} right.{png,ppm} [min_disparity] [max_disparity] [out_prefix]
+// loads the pair (8-bit PNG: gray / RGB / palette / RGBA, non-interlaced; or binary PPM), runs
+// ADCensusStereo::Initialize / Match exactly like main.cpp:80-118 and writes what SaveDisparityMap /
+// SaveDisparityCloud write (main.cpp:120-128,180-230):
+//   <out>-d.png      min-max normalised 8-bit disparity: uchar((|d| - min) / (max - min) * 255), invalid -> 0
+//   <out>-c.png      cv::applyColorMap(<out>-d, COLORMAP_JET)
+//   <out>-cloud.txt  "x y |d| r g b" per valid pixel ("%f %f %f %d %d %d", colours of the LEFT image)
+// plus <out>.pfm (raw float32 disparity, for bit-exact comparisons).  PNG coding uses zlib (the image has no OpenCV).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -15,85 +15,265 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>
+
 #include "ADCensusStereo.h"
 
-static bool read_ppm(const char* path, std::vector<uint8>& bgr, int& w, int& h)
+// ------------------------------------------------------------------------------------------------ image files
+static bool read_file(const char* path, std::vector<uint8>& buf)
 {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
-    char magic[3] = {0};
-    int maxv = 0;
-    auto skip = [&]() { int c; while ((c = fgetc(f)) != EOF) { if (c == '#') { while ((c = fgetc(f)) != EOF && c != '\n') {} } else if (!isspace(c)) { ungetc(c, f); break; } } };
-    if (fscanf(f, "%2s", magic) != 1 || strcmp(magic, "P6") != 0) { fclose(f); return false; }
-    skip(); if (fscanf(f, "%d", &w) != 1) { fclose(f); return false; }
-    skip(); if (fscanf(f, "%d", &h) != 1) { fclose(f); return false; }
-    skip(); if (fscanf(f, "%d", &maxv) != 1 || maxv != 255) { fclose(f); return false; }
-    fgetc(f);
-    std::vector<uint8> rgb((size_t)w * h * 3);
-    const bool ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n > 0 && fread(buf.data(), 1, buf.size(), f) == buf.size();
     fclose(f);
-    bgr.resize(rgb.size());
-    for (size_t i = 0; i < (size_t)w * h; i++) { bgr[3 * i] = rgb[3 * i + 2]; bgr[3 * i + 1] = rgb[3 * i + 1]; bgr[3 * i + 2] = rgb[3 * i]; } // main.cpp:69-74
     return ok;
 }
+static uint32 be32(const uint8* p) { return ((uint32)p[0] << 24) | ((uint32)p[1] << 16) | ((uint32)p[2] << 8) | p[3]; }
 
-static void jet(uint8 v, uint8 rgb[3])
+// 8-bit, non-interlaced PNG -> tightly packed B,G,R (the layout main.cpp:65-76 builds from cv::Vec3b)
+static bool decode_png(const std::vector<uint8>& file, std::vector<uint8>& bgr, int& w, int& h)
 {
-    const float t = v / 255.0f;
-    auto ch = [](float x) { x = x < 0 ? 0 : (x > 1 ? 1 : x); return (uint8)lroundf(x * 255.0f); };
-    rgb[0] = ch(1.5f - fabsf(4.0f * t - 3.0f));
-    rgb[1] = ch(1.5f - fabsf(4.0f * t - 2.0f));
-    rgb[2] = ch(1.5f - fabsf(4.0f * t - 1.0f));
+    static const uint8 sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 33 || memcmp(file.data(), sig, 8) != 0) return false;
+    size_t pos = 8;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8> idat, plte;
+    while (pos + 12 <= file.size()) {
+        const uint32 len = be32(&file[pos]);
+        const char* type = reinterpret_cast<const char*>(&file[pos + 4]);
+        if (pos + 12 + len > file.size()) return false;
+        const uint8* data = &file[pos + 8];
+        if (!memcmp(type, "IHDR", 4)) {
+            w = (int)be32(data); h = (int)be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(data, data + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + len;
+    }
+    if (w <= 0 || h <= 0 || depth != 8 || interlace != 0) return false;
+    const int ch = ctype == 0 ? 1 : (ctype == 2 ? 3 : (ctype == 3 ? 1 : (ctype == 4 ? 2 : (ctype == 6 ? 4 : 0))));
+    if (!ch) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<uint8> raw((stride + 1) * h);
+    uLongf rawlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
+    std::vector<uint8> img(stride * h), zero(stride, 0);
+    for (int y = 0; y < h; y++) { // undo the scanline filters (PNG specification, section 9)
+        const uint8 ft = raw[(stride + 1) * y];
+        const uint8* in = &raw[(stride + 1) * y + 1];
+        uint8* out = &img[stride * y];
+        const uint8* up = y ? &img[stride * (y - 1)] : zero.data();
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= (size_t)ch ? out[i - ch] : 0, b = up[i], c = i >= (size_t)ch ? up[i - ch] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            else if (ft != 0) return false;
+            out[i] = (uint8)(in[i] + pred);
+        }
+    }
+    bgr.resize((size_t)w * h * 3);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        uint8 r, g, b;
+        const uint8* p = &img[i * ch];
+        if (ctype == 0 || ctype == 4) r = g = b = p[0];
+        else if (ctype == 3) { if ((size_t)p[0] * 3 + 2 >= plte.size()) return false; r = plte[p[0] * 3]; g = plte[p[0] * 3 + 1]; b = plte[p[0] * 3 + 2]; }
+        else { r = p[0]; g = p[1]; b = p[2]; }
+        bgr[3 * i] = b; bgr[3 * i + 1] = g; bgr[3 * i + 2] = r;
+    }
+    return true;
 }
+static bool decode_ppm(const std::vector<uint8>& file, std::vector<uint8>& bgr, int& w, int& h)
+{
+    size_t pos = 0;
+    auto token = [&](std::string& t) {
+        t.clear();
+        while (pos < file.size()) {
+            if (file[pos] == '#') { while (pos < file.size() && file[pos] != '\n') pos++; }
+            else if (isspace(file[pos])) pos++;
+            else break;
+        }
+        while (pos < file.size() && !isspace(file[pos])) t.push_back((char)file[pos++]);
+        return !t.empty();
+    };
+    std::string t;
+    if (!token(t) || t != "P6") return false;
+    if (!token(t)) return false;
+    w = atoi(t.c_str());
+    if (!token(t)) return false;
+    h = atoi(t.c_str());
+    if (!token(t) || atoi(t.c_str()) != 255) return false;
+    pos++; // the single whitespace byte behind maxval
+    if (w <= 0 || h <= 0 || pos + (size_t)w * h * 3 > file.size()) return false;
+    bgr.resize((size_t)w * h * 3);
+    for (size_t i = 0; i < (size_t)w * h; i++) { bgr[3 * i] = file[pos + 3 * i + 2]; bgr[3 * i + 1] = file[pos + 3 * i + 1]; bgr[3 * i + 2] = file[pos + 3 * i]; }
+    return true;
+}
+static bool load_image(const char* path, std::vector<uint8>& bgr, int& w, int& h)
+{
+    std::vector<uint8> file;
+    if (!read_file(path, file)) return false;
+    return decode_png(file, bgr, w, h) || decode_ppm(file, bgr, w, h);
+}
+
+// 8-bit PNG, channels = 1 (gray) or 3 (R,G,B): filter 0 on every line, one zlib stream, one IDAT
+static bool write_png(const std::string& path, const uint8* px, int w, int h, int channels)
+{
+    const size_t stride = (size_t)w * channels;
+    std::vector<uint8> raw((stride + 1) * h);
+    for (int y = 0; y < h; y++) { raw[(stride + 1) * y] = 0; memcpy(&raw[(stride + 1) * y + 1], px + stride * y, stride); }
+    uLongf clen = compressBound((uLong)raw.size());
+    std::vector<uint8> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    auto chunk = [&](const char* type, const uint8* data, uint32 len) {
+        uint8 hdr[8] = {(uint8)(len >> 24), (uint8)(len >> 16), (uint8)(len >> 8), (uint8)len, (uint8)type[0], (uint8)type[1], (uint8)type[2], (uint8)type[3]};
+        fwrite(hdr, 1, 8, f);
+        if (len) fwrite(data, 1, len, f);
+        uLong crc = crc32(0L, hdr + 4, 4);
+        if (len) crc = crc32(crc, data, len);
+        const uint8 c4[4] = {(uint8)(crc >> 24), (uint8)(crc >> 16), (uint8)(crc >> 8), (uint8)crc};
+        fwrite(c4, 1, 4, f);
+    };
+    static const uint8 sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    const uint8 ihdr[13] = {(uint8)(w >> 24), (uint8)(w >> 16), (uint8)(w >> 8), (uint8)w, (uint8)(h >> 24), (uint8)(h >> 16), (uint8)(h >> 8), (uint8)h,
+                            8, (uint8)(channels == 1 ? 0 : 2), 0, 0, 0};
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), (uint32)clen);
+    chunk("IEND", nullptr, 0);
+    fclose(f);
+    return true;
+}
+
+// cv::COLORMAP_JET of OpenCV 3.1 as {R,G,B} per grey level.  The reference writes <name>-d.png and its colour-mapped
+// copy <name>-c.png (main.cpp:203-209); this table is that mapping, read off the reference's own result images
+// (doc/exp/res/{cone,cloth,piano}-{d,c}.png: 239 of the 256 levels occur, each with ONE colour); the 17 levels that do
+// not occur (2-9, 13-19, 22, 24) lie on the first linear segment (0, 0, 128 + 4*level).
+static const uint8 kJet[256][3] = {
+    {0,0,128}, {0,0,132}, {0,0,136}, {0,0,140}, {0,0,144}, {0,0,148}, {0,0,152}, {0,0,156},
+    {0,0,160}, {0,0,164}, {0,0,168}, {0,0,172}, {0,0,176}, {0,0,180}, {0,0,184}, {0,0,188},
+    {0,0,192}, {0,0,196}, {0,0,200}, {0,0,204}, {0,0,208}, {0,0,212}, {0,0,216}, {0,0,220},
+    {0,0,224}, {0,0,228}, {0,0,232}, {0,0,236}, {0,0,240}, {0,0,244}, {0,0,248}, {0,0,252},
+    {0,0,255}, {0,4,255}, {0,8,255}, {0,12,255}, {0,16,255}, {0,20,255}, {0,24,255}, {0,28,255},
+    {0,32,255}, {0,36,255}, {0,40,255}, {0,44,255}, {0,48,255}, {0,52,255}, {0,56,255}, {0,60,255},
+    {0,64,255}, {0,68,255}, {0,72,255}, {0,76,255}, {0,80,255}, {0,84,255}, {0,88,255}, {0,92,255},
+    {0,96,255}, {0,100,255}, {0,104,255}, {0,108,255}, {0,112,255}, {0,116,255}, {0,120,255}, {0,124,255},
+    {0,128,255}, {0,132,255}, {0,136,255}, {0,140,255}, {0,144,255}, {0,148,255}, {0,152,255}, {0,156,255},
+    {0,160,255}, {0,164,255}, {0,168,255}, {0,172,255}, {0,176,255}, {0,180,255}, {0,184,255}, {0,188,255},
+    {0,192,255}, {0,196,255}, {0,200,255}, {0,204,255}, {0,208,255}, {0,212,255}, {0,216,255}, {0,220,255},
+    {0,224,255}, {0,228,255}, {0,232,255}, {0,236,255}, {0,240,255}, {0,244,255}, {0,248,255}, {0,252,255},
+    {2,255,254}, {6,255,250}, {10,255,246}, {14,255,242}, {18,255,238}, {22,255,234}, {26,255,230}, {30,255,226},
+    {34,255,222}, {38,255,218}, {42,255,214}, {46,255,210}, {50,255,206}, {54,255,202}, {58,255,198}, {62,255,194},
+    {66,255,190}, {70,255,186}, {74,255,182}, {78,255,178}, {82,255,174}, {86,255,170}, {90,255,166}, {94,255,162},
+    {98,255,158}, {102,255,154}, {106,255,150}, {110,255,146}, {114,255,142}, {118,255,138}, {122,255,134}, {126,255,130},
+    {130,255,126}, {134,255,122}, {138,255,118}, {142,255,114}, {146,255,110}, {150,255,106}, {154,255,102}, {158,255,98},
+    {162,255,94}, {166,255,90}, {170,255,86}, {174,255,82}, {178,255,78}, {182,255,74}, {186,255,70}, {190,255,66},
+    {194,255,62}, {198,255,58}, {202,255,54}, {206,255,50}, {210,255,46}, {214,255,42}, {218,255,38}, {222,255,34},
+    {226,255,30}, {230,255,26}, {234,255,22}, {238,255,18}, {242,255,14}, {246,255,10}, {250,255,6}, {254,255,1},
+    {255,252,0}, {255,248,0}, {255,244,0}, {255,240,0}, {255,236,0}, {255,232,0}, {255,228,0}, {255,224,0},
+    {255,220,0}, {255,216,0}, {255,212,0}, {255,208,0}, {255,204,0}, {255,200,0}, {255,196,0}, {255,192,0},
+    {255,188,0}, {255,184,0}, {255,180,0}, {255,176,0}, {255,172,0}, {255,168,0}, {255,164,0}, {255,160,0},
+    {255,156,0}, {255,152,0}, {255,148,0}, {255,144,0}, {255,140,0}, {255,136,0}, {255,132,0}, {255,128,0},
+    {255,124,0}, {255,120,0}, {255,116,0}, {255,112,0}, {255,108,0}, {255,104,0}, {255,100,0}, {255,96,0},
+    {255,92,0}, {255,88,0}, {255,84,0}, {255,80,0}, {255,76,0}, {255,72,0}, {255,68,0}, {255,64,0},
+    {255,60,0}, {255,56,0}, {255,52,0}, {255,48,0}, {255,44,0}, {255,40,0}, {255,36,0}, {255,32,0},
+    {255,28,0}, {255,24,0}, {255,20,0}, {255,16,0}, {255,12,0}, {255,8,0}, {255,4,0}, {255,0,0},
+    {252,0,0}, {248,0,0}, {244,0,0}, {240,0,0}, {236,0,0}, {232,0,0}, {228,0,0}, {224,0,0},
+    {220,0,0}, {216,0,0}, {212,0,0}, {208,0,0}, {204,0,0}, {200,0,0}, {196,0,0}, {192,0,0},
+    {188,0,0}, {184,0,0}, {180,0,0}, {176,0,0}, {172,0,0}, {168,0,0}, {164,0,0}, {160,0,0},
+    {156,0,0}, {152,0,0}, {148,0,0}, {144,0,0}, {140,0,0}, {136,0,0}, {132,0,0}, {128,0,0}};
 
 int main(int argc, char** argv)
 {
+    // file-format helpers that need no GPU (used by the CPU test tier):
+    //   --convert in.{png,ppm} out.png       decode + re-encode (R,G,B)
+    //   --colormap in-d.png out-c.png        the JET mapping SaveDisparityMap applies to the grey disparity image
+    if (argc == 4 && (!strcmp(argv[1], "--convert") || !strcmp(argv[1], "--colormap"))) {
+        std::vector<uint8> bgr;
+        int cw = 0, chh = 0;
+        if (!load_image(argv[2], bgr, cw, chh)) { printf("cannot read %s\n", argv[2]); return -1; }
+        std::vector<uint8> rgb(bgr.size());
+        for (size_t i = 0; i < (size_t)cw * chh; i++) {
+            if (!strcmp(argv[1], "--convert")) { rgb[3 * i] = bgr[3 * i + 2]; rgb[3 * i + 1] = bgr[3 * i + 1]; rgb[3 * i + 2] = bgr[3 * i]; }
+            else { const uint8 g = bgr[3 * i + 1]; rgb[3 * i] = kJet[g][0]; rgb[3 * i + 1] = kJet[g][1]; rgb[3 * i + 2] = kJet[g][2]; }
+        }
+        return write_png(argv[3], rgb.data(), cw, chh, 3) ? 0 : -1;
+    }
     if (argc < 3) {
-        printf("usage: %s left.ppm right.ppm [min_disparity] [max_disparity] [out_prefix]\n", argv[0]);
+        printf("usage: %s left.png right.png [min_disparity] [max_disparity] [out_prefix]\n", argv[0]);
         return -1;
     }
+    printf("Image Loading...");
     std::vector<uint8> left, right;
     int w = 0, h = 0, w2 = 0, h2 = 0;
-    if (!read_ppm(argv[1], left, w, h) || !read_ppm(argv[2], right, w2, h2) || w != w2 || h != h2) {
-        printf("cannot read the image pair (binary PPM, equal sizes)\n");
+    if (!load_image(argv[1], left, w, h) || !load_image(argv[2], right, w2, h2)) {
+        printf("cannot read the image pair (8-bit PNG or binary PPM)\n"); // main.cpp:50-53
         return -1;
     }
+    if (w != w2 || h != h2) {
+        printf("the two images differ in size\n"); // main.cpp:54-57
+        return -1;
+    }
+    printf("Done!\n");
     ADCensusOption ad_option;                               // main.cpp:80-92
     ad_option.min_disparity = argc < 4 ? 0 : atoi(argv[3]);
     ad_option.max_disparity = argc < 5 ? 64 : atoi(argv[4]);
     ad_option.lrcheck_thres = 1.0f;
     ad_option.do_lr_check = true;
     ad_option.do_filling = true;
-    const std::string out = argc < 6 ? std::string(argv[1]) : std::string(argv[5]);
+    std::string out = argc < 6 ? std::string(argv[1]) : std::string(argv[5]);
+    if (argc < 6 && out.size() > 4 && out[out.size() - 4] == '.') out.resize(out.size() - 4);
     printf("w = %d, h = %d, d = [%d,%d]\n\n", w, h, ad_option.min_disparity, ad_option.max_disparity);
 
     ADCensusStereo ad_census;
     ad_census.SetVerbose(true);
+    printf("AD-Census Initializing...\n");
     auto t0 = std::chrono::steady_clock::now();
     if (!ad_census.Initialize(w, h, ad_option)) { printf("AD-Census initialisation failed: %s\n", ad_census.LastError()); return -2; }
     auto t1 = std::chrono::steady_clock::now();
     printf("AD-Census Initializing Done! Timing :	%lf s\n\n", std::chrono::duration<double>(t1 - t0).count());
+    printf("AD-Census Matching...\n");
     std::vector<float32> disparity((size_t)w * h, 0.0f);
     t0 = std::chrono::steady_clock::now();
     if (!ad_census.Match(left.data(), right.data(), disparity.data())) { printf("AD-Census matching failed: %s\n", ad_census.LastError()); return -2; }
     t1 = std::chrono::steady_clock::now();
     printf("\nAD-Census Matching...Done! Timing :	%lf s\n", std::chrono::duration<double>(t1 - t0).count());
 
-    // SaveDisparityMap (main.cpp:180-206): min-max over valid |d|, uchar((|d|-min)/(max-min)*255)
-    float mn = (float)w, mx = -(float)w;
-    for (float d : disparity) if (d != Invalid_Float) { const float a = fabsf(d); mn = a < mn ? a : mn; mx = a > mx ? a : mx; }
+    // SaveDisparityMap (main.cpp:180-206): min-max over the valid |d|, uchar((|d| - min) / (max - min) * 255), invalid -> 0
+    float32 mn = float32(w), mx = -float32(w);
+    for (float32 d : disparity) { const float32 a = fabsf(d); if (a != Invalid_Float) { mn = a < mn ? a : mn; mx = a > mx ? a : mx; } }
     std::vector<uint8> gray((size_t)w * h, 0), col((size_t)w * h * 3, 0);
     for (size_t i = 0; i < gray.size(); i++) {
-        if (disparity[i] != Invalid_Float && mx > mn) gray[i] = (uint8)((fabsf(disparity[i]) - mn) / (mx - mn) * 255);
-        jet(gray[i], &col[3 * i]);
+        const float32 a = fabsf(disparity[i]);
+        gray[i] = a == Invalid_Float ? 0 : static_cast<uint8>((a - mn) / (mx - mn) * 255);
+        col[3 * i] = kJet[gray[i]][0]; col[3 * i + 1] = kJet[gray[i]][1]; col[3 * i + 2] = kJet[gray[i]][2];
     }
-    FILE* f = fopen((out + "-d.pgm").c_str(), "wb");
-    if (f) { fprintf(f, "P5\n%d %d\n255\n", w, h); fwrite(gray.data(), 1, gray.size(), f); fclose(f); }
-    f = fopen((out + "-c.ppm").c_str(), "wb");
-    if (f) { fprintf(f, "P6\n%d %d\n255\n", w, h); fwrite(col.data(), 1, col.size(), f); fclose(f); }
+    if (!write_png(out + "-d.png", gray.data(), w, h, 1) || !write_png(out + "-c.png", col.data(), w, h, 3)) printf("cannot write %s-d.png / -c.png\n", out.c_str());
+    // SaveDisparityCloud (main.cpp:212-230): x y |d| r g b, colours of the left image (stored B,G,R)
+    FILE* f = fopen((out + "-cloud.txt").c_str(), "w");
+    if (f) {
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                const float32 a = fabsf(disparity[(size_t)i * w + j]);
+                if (a == Invalid_Float) continue;
+                const uint8* p = &left[((size_t)i * w + j) * 3];
+                fprintf(f, "%f %f %f %d %d %d\n", float32(j), float32(i), a, p[2], p[1], p[0]);
+            }
+        fclose(f);
+    }
     f = fopen((out + ".pfm").c_str(), "wb");
     if (f) { fprintf(f, "Pf\n%d %d\n-1.0\n", w, h); for (int y = h - 1; y >= 0; y--) fwrite(&disparity[(size_t)y * w], 4, w, f); fclose(f); }
-    f = fopen((out + ".txt").c_str(), "w");
-    if (f) { for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) { const float d = disparity[(size_t)y * w + x]; if (d != Invalid_Float) fprintf(f, "%d %d %f\n", x, y, d); } fclose(f); }
     return 0;
 }

@@ -87,3 +87,35 @@ def test_types_header_is_source_compatible(tmp_path):
         "  (void)st; return ok ? 0 : 1;\n"
         "}\n")
     subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def _cli():
+    cli = os.path.join(ROOT, "adcensus_amd", "bin", "adcensus_cli")
+    if not os.path.exists(cli):
+        pytest.fail("adcensus_cli not built (python -c 'import __graft_entry__ as g; g.build()')")
+    return cli
+
+
+def test_cli_png_codec_and_jet_colormap(tmp_path):
+    """The CLI's own PNG reader / writer (main.cpp:47-48,203-209 use OpenCV) round-trips the reference's image types, and its
+    COLORMAP_JET table reproduces the reference's colour-mapped result image from its grey one, pixel for pixel."""
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    from tests import cases
+    cli = _cli()
+    left, _ = cases.cone_pair()
+    rgb = np.ascontiguousarray(left[:, :, ::-1])
+    for name, im in (("rgb.png", Image.fromarray(rgb)), ("gray.png", Image.fromarray(rgb[:, :, 1])),
+                     ("pal.png", Image.fromarray(rgb).quantize(64)), ("rgba.png", Image.fromarray(np.dstack([rgb, rgb[:, :, :1]])))):
+        src, dst = str(tmp_path / name), str(tmp_path / ("out_" + name))
+        im.save(src)
+        subprocess.check_call([cli, "--convert", src, dst])
+        want = np.array(Image.open(src).convert("RGB"))
+        got = np.array(Image.open(dst))
+        assert got.shape == want.shape and np.array_equal(got, want), name
+    d = os.path.join(ROOT, "tests", "golden", "ref_cone-d.png")  # the reference's own result images (doc/exp/res)
+    c = os.path.join(ROOT, "tests", "golden", "ref_cone-c.png")
+    out = str(tmp_path / "c.png")
+    subprocess.check_call([cli, "--colormap", d, out])
+    assert np.array_equal(np.array(Image.open(out)), np.array(Image.open(c).convert("RGB")))
