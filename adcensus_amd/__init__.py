@@ -110,6 +110,16 @@ def lib():
     L.adc_debug_set_images.restype = C.c_int
     L.adc_debug_run.argtypes = [vp, C.c_int, C.c_int]
     L.adc_debug_run.restype = C.c_int
+    L.adc_farm_create.argtypes = [i32, i32, C.POINTER(ADCensusOption), C.c_int, C.c_int]
+    L.adc_farm_create.restype = vp
+    L.adc_farm_destroy.argtypes = [vp]
+    L.adc_farm_destroy.restype = None
+    L.adc_farm_submit.argtypes = [vp, u8p, u8p, vp, C.POINTER(C.c_uint64)]
+    L.adc_farm_submit.restype = C.c_int
+    L.adc_farm_wait.argtypes = [vp, C.c_uint64]
+    L.adc_farm_wait.restype = C.c_int
+    L.adc_farm_drain.argtypes = [vp]
+    L.adc_farm_drain.restype = C.c_int64
     L.adc_debug_counter.argtypes = [vp, C.c_int]
     L.adc_debug_counter.restype = C.c_int64
     L.adc_debug_voting_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -129,6 +139,52 @@ def last_error():
 def _img(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     return a
+
+
+class PairFarm:
+    """Persistent farm of `pipelines` matchers of one geometry on one device (adc_farm_* of the C ABI): submit() enqueues
+    a whole Match asynchronously from host buffers, results land in the caller's arrays in submission order."""
+
+    def __init__(self, width, height, option, device=-1, pipelines=3):
+        self.width, self.height = int(width), int(height)
+        self._f = lib().adc_farm_create(self.width, self.height, C.byref(option), int(device), int(pipelines))
+        if not self._f:
+            raise RuntimeError("adc_farm_create failed: " + last_error())
+        self._keep = {}
+
+    def submit(self, img_left, img_right, disp_left):
+        l, r = _img(img_left), _img(img_right)
+        assert l.size == self.width * self.height * 3 and r.size == l.size
+        assert disp_left.dtype == np.float32 and disp_left.flags["C_CONTIGUOUS"] and disp_left.size == self.width * self.height
+        t = C.c_uint64(0)
+        rc = lib().adc_farm_submit(self._f, l.ctypes.data, r.ctypes.data, disp_left.ctypes.data, C.byref(t))
+        if rc != 0:
+            raise RuntimeError("adc_farm_submit failed (%d): %s" % (rc, last_error()))
+        self._keep[int(t.value)] = disp_left  # the output array must stay alive until the pair is delivered
+        return int(t.value)
+
+    def wait(self, ticket):
+        if lib().adc_farm_wait(self._f, int(ticket)) != 0:
+            raise RuntimeError("adc_farm_wait failed: " + last_error())
+        self._keep.pop(int(ticket), None)
+
+    def drain(self):
+        n = int(lib().adc_farm_drain(self._f))
+        if n < 0:
+            raise RuntimeError("adc_farm_drain failed: " + last_error())
+        self._keep.clear()
+        return n
+
+    def close(self):
+        if self._f:
+            lib().adc_farm_destroy(self._f)
+            self._f = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ADCensusStereo:

@@ -506,6 +506,79 @@ int adc_match(adc_handle* h, const uint8_t* left, const uint8_t* right, float* d
     return adc_wait(h);
 }
 
+// ------------------------------------------------------------------------------ pair farm
+struct adc_farm {
+    std::vector<adc_handle*> pipes;
+    std::vector<uint64_t> in_flight; // ticket of the pair in flight on each pipeline (0 = idle)
+    uint64_t next_ticket = 1;
+    int64_t delivered = 0;
+};
+
+adc_farm* adc_farm_create(int32_t width, int32_t height, const adc_option* opt, int device, int pipelines)
+{
+    if (pipelines < 1 || pipelines > 64) { g_last_error = "adc_farm_create: pipelines must be 1..64"; return nullptr; }
+    adc_farm* f = new (std::nothrow) adc_farm();
+    if (!f) return nullptr;
+    for (int i = 0; i < pipelines; i++) {
+        adc_handle* h = adc_create(width, height, opt, device);
+        if (!h) { adc_farm_destroy(f); return nullptr; }
+        f->pipes.push_back(h);
+        f->in_flight.push_back(0);
+    }
+    return f;
+}
+void adc_farm_destroy(adc_farm* f)
+{
+    if (!f) return;
+    for (size_t i = 0; i < f->pipes.size(); i++) {
+        if (f->in_flight[i]) adc_wait(f->pipes[i]);
+        adc_destroy(f->pipes[i]);
+    }
+    delete f;
+}
+static int farm_collect(adc_farm* f, size_t slot)
+{
+    if (!f->in_flight[slot]) return 0;
+    const int rc = adc_wait(f->pipes[slot]);
+    f->in_flight[slot] = 0;
+    if (rc == 0) f->delivered++;
+    return rc;
+}
+int adc_farm_submit(adc_farm* f, const uint8_t* left, const uint8_t* right, float* disp, uint64_t* ticket)
+{
+    if (!f || !left || !right || !disp) return 1;
+    const uint64_t t = f->next_ticket;
+    const size_t slot = (size_t)((t - 1) % f->pipes.size());
+    int rc = farm_collect(f, slot); // the pipeline's previous pair (if any) must be delivered before its staging is reused
+    if (rc != 0) return rc;
+    rc = adc_match_async(f->pipes[slot], left, right, disp);
+    if (rc != 0) return rc;
+    f->in_flight[slot] = t;
+    f->next_ticket++;
+    if (ticket) *ticket = t;
+    return 0;
+}
+int adc_farm_wait(adc_farm* f, uint64_t ticket)
+{
+    if (!f || ticket == 0 || ticket >= f->next_ticket) return 1;
+    const size_t slot = (size_t)((ticket - 1) % f->pipes.size());
+    if (f->in_flight[slot] && f->in_flight[slot] <= ticket) return farm_collect(f, slot);
+    return 0; // already delivered (a later pair of the pipeline is in flight, or the pipeline is idle)
+}
+int64_t adc_farm_drain(adc_farm* f)
+{
+    if (!f) return -1;
+    // oldest first
+    for (size_t k = 0; k < f->pipes.size(); k++) {
+        size_t best = f->pipes.size();
+        for (size_t i = 0; i < f->pipes.size(); i++)
+            if (f->in_flight[i] && (best == f->pipes.size() || f->in_flight[i] < f->in_flight[best])) best = i;
+        if (best == f->pipes.size()) break;
+        if (farm_collect(f, best) != 0) return -1;
+    }
+    return f->delivered;
+}
+
 // ------------------------------------------------------------------------------ misc plumbing
 const char* adc_stage_name(int s)
 {

@@ -304,6 +304,7 @@ def main():
         m2.release()
         # ---- the drop-in entry point with pageable host buffers
         out["host_inclusive"] = host_inclusive_leg(A, local_rank, W, H, D, a.workload, max(5, min(10, a.steps)))
+        out["host_farm"] = host_farm_leg(A, local_rank, W, H, D, a.workload, max(9, min(24, a.steps)))
         # ---- throughput mode: 3 pipelines in flight
         n3 = max(6, min(24, a.steps))
         ids3 = list(range(min(n3, 8)))
@@ -335,6 +336,24 @@ def host_inclusive_leg(A, device, W, H, D, workload, n):
     return {"value": round(n / dt, 4), "unit": "pairs/s", "ms_per_pair": round(1000.0 * dt / n, 4), "steps": n,
             "entry_point": "adc_match(left, right, disp) == ADCensusStereo::Match with pageable host buffers: 2 host copies into pinned "
                            "staging (12.4 MB), H2D, kernels, D2H (8.3 MB), copy-out; synchronous"}
+
+
+def host_farm_leg(A, device, W, H, D, workload, n):
+    """The persistent farm of the C ABI (adc_farm_*): pageable host buffers in, pageable host buffers out, 3 pipelines."""
+    pairs = [make_pair(workload, W, H, D, i) for i in range(min(n, 6))]
+    farm = A.PairFarm(W, H, A.ADCensusOption(min_disparity=0, max_disparity=D), device=device, pipelines=3)
+    outs = [np.empty((H, W), np.float32) for _ in range(3)]
+    for i in range(3):
+        farm.submit(pairs[i % len(pairs)][0], pairs[i % len(pairs)][1], outs[i % 3])
+    farm.drain()
+    t0 = time.perf_counter()
+    for i in range(n):
+        farm.submit(pairs[i % len(pairs)][0], pairs[i % len(pairs)][1], outs[i % 3])
+    farm.drain()
+    dt = time.perf_counter() - t0
+    farm.close()
+    return {"value": round(n / dt, 4), "unit": "pairs/s", "pipelines": 3, "steps": n,
+            "entry_point": "adc_farm_submit / adc_farm_drain: pageable host images in, pageable host maps out, pinned staging ring inside"}
 
 
 def pmc_traffic(workload, whd):

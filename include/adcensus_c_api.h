@@ -99,6 +99,24 @@ int adc_match_device(adc_handle* h, const void* d_bgr_left, const void* d_bgr_ri
 int adc_match_async(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left);
 int adc_wait(adc_handle* h);
 
+/* -------------------------------------------------------------------------------------------
+ * Pair farm: a persistent set of `pipelines` matcher objects of one geometry on one device, each
+ * with its own stream and pinned staging buffers (the ring), fed round-robin.  adc_farm_submit copies the pair into the
+ * next pipeline's pinned slot and enqueues the whole Match asynchronously -- it blocks only when that pipeline is still
+ * busy with an earlier pair, and then exactly until that pair is done and delivered.  Results arrive in the caller's
+ * `disp_left` buffers in submission order; adc_farm_wait(ticket) / adc_farm_drain complete them.  Match semantics are
+ * those of adc_match (same values, same error codes); the caller's image buffers may be reused as soon as submit returns.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct adc_farm adc_farm;
+adc_farm* adc_farm_create(int32_t width, int32_t height, const adc_option* opt, int device, int pipelines);
+void adc_farm_destroy(adc_farm* f);
+/* Returns 0 and the ticket (1, 2, 3, ...) of the pair; 1 on bad arguments, 2 on a HIP failure. */
+int adc_farm_submit(adc_farm* f, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left, uint64_t* ticket);
+/* Blocks until the pair with this ticket (and every earlier pair of its pipeline) has been delivered. */
+int adc_farm_wait(adc_farm* f, uint64_t ticket);
+/* Completes everything submitted so far; returns the number of pairs delivered since creation, negative on failure. */
+int64_t adc_farm_drain(adc_farm* f);
+
 /* Stage timers (ms, HIP events on the handle's stream) of the most recent completed match.
  * Enable with adc_set_profiling(h,1).  Order: see adc_stage_name(). */
 enum {
