@@ -41,7 +41,8 @@ struct adc_handle {
     bool own_stream;
 
     // images + per-pixel maps
-    uint8_t *img_l, *img_r;
+    uint8_t *img_l, *img_r;         // the pair being matched: the handle's own buffers, or the caller's (adc_match_device)
+    uint8_t *img_l_own, *img_r_own;
     uint8_t *gray_l, *gray_r;
     uint64_t *census_l, *census_r;
     uint8_t* arms;
@@ -89,6 +90,7 @@ struct adc_handle {
     int force_median_fallback; // test hook (ADC_DEBUG_FORCE_MEDIAN_FALLBACK via adc_debug_run): adc_wait takes the fallback path
     int median_fallbacks;      // how often adc_wait had to redo the median
     int32_t* pin_flags;   // pinned host word: error flag of the banded median's hand-off (read back after every Match)
+    int bgrx_valid;       // bgrx_l holds the packed left image of the current pair (written by the arms stage)
     uint32_t* bgrx_l;     // left image packed B | G<<8 | R<<16 per pixel (interpolation gathers)
     uint16_t* st16;      // region voting: 16-bit state map [H][st16_pitch] {bin:11 | final | eligible} (k_voting.hip)
     int st16_pitch;      // row pitch of st16 in elements (multiple of 8: rows start 16-byte aligned)

@@ -58,8 +58,10 @@ static hipError_t alloc_all(adc_handle* h)
     const AdcParams& p = h->p;
     const size_t P = (size_t)p.W * p.H;
     const size_t VB = P * p.Dp * sizeof(float);
-    HIP_OK(hipMalloc(&h->img_l, P * 3));
-    HIP_OK(hipMalloc(&h->img_r, P * 3));
+    HIP_OK(hipMalloc(&h->img_l_own, P * 3));
+    HIP_OK(hipMalloc(&h->img_r_own, P * 3));
+    h->img_l = h->img_l_own;
+    h->img_r = h->img_r_own;
     HIP_OK(hipMalloc(&h->gray_l, P));
     HIP_OK(hipMalloc(&h->bgrx_l, P * 4));
     // sized from the PADDED range: the fused-cost pass also marches over padding chunks / lanes (d >= D), whose
@@ -243,7 +245,7 @@ void adc_destroy(adc_handle* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->heavy) hipStreamSynchronize(h->heavy);
-    void* bufs[] = {h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
+    void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->interp_list, h->interp_counters, h->st16, h->disp_vote, h->vote_counters,
                     h->chg_a, h->edge};
@@ -416,8 +418,10 @@ int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, voi
     if (!h || !d_left || !d_right || !d_disp) return 1; // ADCensusStereo.cpp:71-76
     hipSetDevice(h->device);
     const size_t P = (size_t)h->p.W * h->p.H;
-    if (hipMemcpyAsync(h->img_l, d_left, P * 3, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
-    if (hipMemcpyAsync(h->img_r, d_right, P * 3, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return 2;
+    // the caller's device images are BORROWED until adc_wait returns (like the reference borrows the host pointers for the
+    // duration of Match, ADCensusStereo.cpp:78-79): no copy
+    h->img_l = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_left));
+    h->img_r = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_right));
     if (run_pipeline(h) != hipSuccess) return 2;
     h->device_dst = d_disp;
     h->async_dst = nullptr;
@@ -430,6 +434,8 @@ int adc_match_async(adc_handle* h, const uint8_t* left, const uint8_t* right, fl
     if (!h || !left || !right || !disp) return 1;
     hipSetDevice(h->device);
     const size_t P = (size_t)h->p.W * h->p.H;
+    h->img_l = h->img_l_own;
+    h->img_r = h->img_r_own;
     memcpy(h->pin_in, left, P * 3);
     memcpy(h->pin_in + P * 3, right, P * 3);
     if (hipMemcpyAsync(h->img_l, h->pin_in, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
@@ -687,8 +693,11 @@ int adc_debug_set_images(adc_handle* h, const uint8_t* left, const uint8_t* righ
     if (!h || !left || !right) return 1;
     hipSetDevice(h->device);
     const size_t P = (size_t)h->p.W * h->p.H;
+    h->img_l = h->img_l_own;
+    h->img_r = h->img_r_own;
     if (hipMemcpy(h->img_l, left, P * 3, hipMemcpyHostToDevice) != hipSuccess) return 2;
     if (hipMemcpy(h->img_r, right, P * 3, hipMemcpyHostToDevice) != hipSuccess) return 2;
+    h->bgrx_valid = 0;
     return 0;
 }
 

@@ -8,36 +8,42 @@
 #include "adc_internal.h"
 #include "adc_device_fn.h"
 
+// Left image packed B | G<<8 | R<<16 per pixel: the arm search reads ONE dword per visited pixel instead of three bytes
+// (it is a chain of dependent L2 hits: 213 -> ~... us on the structured 1080p pair), and the interpolation gathers reuse it.
+__global__ __launch_bounds__(256) void k_pack_bgr(const uint8_t* __restrict__ img, uint32_t* __restrict__ out, int P)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < P) out[p] = (uint32_t)img[3 * (size_t)p] | ((uint32_t)img[3 * (size_t)p + 1] << 8) | ((uint32_t)img[3 * (size_t)p + 2] << 16);
+}
+
 // One arm from (x,y) along (dx,dy): rules of cross_aggregator.cpp:151-198.
-__device__ __forceinline__ int arm_length(const uint8_t* __restrict__ img, int W, int H, int x, int y, int dx, int dy,
+__device__ __forceinline__ int arm_length(const uint32_t* __restrict__ img, int W, int H, int x, int y, int dx, int dy,
                                           int L1, int L2, int t1, int t2)
 {
-    const uint8_t* p0 = img + ((size_t)y * W + x) * 3;
-    const int b0 = p0[0], g0 = p0[1], r0 = p0[2];
-    int bl = b0, gl = g0, rl = r0;
+    const uint32_t c0 = img[(size_t)y * W + x];
+    uint32_t cl = c0;
     int len = 0;
     int xn = x + dx, yn = y + dy;
     const int nmax = adc_imin(L1, 255); // MAX_ARM_LENGTH, cross_aggregator.h:22
     for (int n = 0; n < nmax; n++) {
         if (xn < 0 || xn >= W || yn < 0 || yn >= H) break;
-        const uint8_t* p = img + ((size_t)yn * W + xn) * 3;
-        const int b = p[0], g = p[1], r = p[2];
-        const int d1 = adc_imax(adc_iabs(r - r0), adc_imax(adc_iabs(g - g0), adc_iabs(b - b0)));
+        const uint32_t c = img[(size_t)yn * W + xn];
+        const int d1 = adc_color_dist_max_u32(c, c0);
         if (d1 >= t1) break;
         if (n > 0) {
-            const int d2 = adc_imax(adc_iabs(r - rl), adc_imax(adc_iabs(g - gl), adc_iabs(b - bl)));
+            const int d2 = adc_color_dist_max_u32(c, cl);
             if (d2 >= t1) break;
         }
         if (n + 1 > L2 && d1 >= t2) break;
         len++;
-        bl = b; gl = g; rl = r;
+        cl = c;
         xn += dx;
         yn += dy;
     }
     return len;
 }
 
-__global__ __launch_bounds__(256) void k_build_arms(const uint8_t* __restrict__ img_l, uchar4* __restrict__ arms, int W,
+__global__ __launch_bounds__(256) void k_build_arms(const uint32_t* __restrict__ img_l, uchar4* __restrict__ arms, int W,
                                                     int H, int L1, int L2, int t1, int t2, int* __restrict__ armmax)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -148,7 +154,9 @@ hipError_t adc_launch_arms(adc_handle* h)
     const AdcParams& p = h->p;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     hipMemsetAsync(h->armmax, 0, 4 * sizeof(int), h->heavy); // [0],[1] maxima, [3] "assumed ring depth too small" flag (k_aggregate.hip)
-    hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->img_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
+    hipLaunchKernelGGL(k_pack_bgr, dim3((p.W * p.H + 255) / 256), dim3(256), 0, h->heavy, h->img_l, h->bgrx_l, p.W * p.H);
+    h->bgrx_valid = 1;
+    hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->bgrx_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
                        p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2, h->armmax);
     hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
                        p.W, p.H);

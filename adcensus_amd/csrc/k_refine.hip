@@ -260,11 +260,7 @@ __global__ __launch_bounds__(256) void k_interpolate_rays(const int32_t* __restr
 // checked to be > 1e-9 away from a tie; otherwise the f64 kernel above is used).  Table layout [m][16] of
 // packed (dy << 16 | dx & 0xffff): one 64-byte segment per step for the 16 rays of a pixel.  The walk issues
 // 4 steps' loads at once (the loads past the hit are clamped in-image and ignored).
-__global__ __launch_bounds__(256) void k_pack_bgr(const uint8_t* __restrict__ img, uint32_t* __restrict__ out, int P)
-{
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < P) out[p] = (uint32_t)img[3 * (size_t)p] | ((uint32_t)img[3 * (size_t)p + 1] << 8) | ((uint32_t)img[3 * (size_t)p + 2] << 16);
-}
+__global__ void k_pack_bgr(const uint8_t* __restrict__ img, uint32_t* __restrict__ out, int P); // k_arms.hip
 __device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_dist_l1 on packed B | G<<8 | R<<16
 {
     return adc_iabs((int)(a & 255u) - (int)(b & 255u)) + adc_iabs((int)((a >> 8) & 255u) - (int)((b >> 8) & 255u)) +
@@ -384,7 +380,7 @@ hipError_t adc_launch_interpolation(adc_handle* h)
                                h->interp_list, h->interp_counters, which, P, -1, (int32_t*)nullptr, (int2*)nullptr);
             if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
             if (h->ray_tab && max_search == h->ray_tab_rows) {
-                if (k == 0) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
+                if (k == 0 && !h->bgrx_valid) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
                 static const int ns = [] { const char* e = getenv("ADC_INTERP_NS"); return e ? atoi(e) : 4; }(); // ray steps per trip
 #define INTERP_TAB(NS_)                                                                                                \
     hipLaunchKernelGGL(k_interpolate_tab<NS_>, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters,    \

@@ -86,12 +86,15 @@ void adc_destroy(adc_handle* h);
  */
 int adc_match(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left);
 
-/* Same pipeline, device-resident buffers (already in HBM); asynchronous on the handle's
- * stream; call adc_wait() before reading d_disp_left.  The call returns with the tail of the pipeline
- * (interpolation, median, download) still queued, but it does synchronise internally where the host has to
- * decide something: once early (the maximum arm lengths, ~0.15 ms in, select the aggregation kernels) and
- * once per batch of region-voting rounds (when do_filling is set).  To overlap several pairs on one GPU, drive
- * several handles from several host threads (bench.py --inflight N). */
+/* Same pipeline, device-resident buffers (already in HBM); asynchronous on the handle's stream: the call only ENQUEUES
+ * (no host synchronisation anywhere in the pipeline) and returns; call adc_wait() before reading d_disp_left.  The two
+ * image buffers are borrowed until adc_wait returns (not copied).  Where the reference would decide something on the
+ * host in mid-pipeline, the device decides or verifies: the aggregation uses the ring depth of the previous Match of the
+ * handle and checks it on the device; the region voting is a kernel chain driven by a device-side state machine with a
+ * launch budget adapted from the previous Match.  adc_wait completes whatever such an assumption left open (redo with
+ * the full aggregation ring, continuation of the voting chain) -- slower for that one call, identical results always.
+ * To overlap several pairs on one GPU, keep several handles in flight from ONE host thread (bench.py --inflight N,
+ * adc_farm_* below). */
 int adc_match_device(adc_handle* h, const void* d_bgr_left, const void* d_bgr_right, void* d_disp_left);
 
 /* Host buffers, asynchronous (pinned staging inside the handle); adc_wait() completes it and
