@@ -15,13 +15,13 @@ enum { IRV_NONE = 0, IRV_BEGIN, IRV_VOTE, IRV_CHECK, IRV_FINAL_WB, IRV_DONE };
 // ctrl layout (int32): state slot s at ctrl[16*s ..]: {did, pass, round, filled_any, n, rounds_total, evals};
 // accumulator ring at ctrl[IRV_ACC + (k & 63)]
 #define IRV_ACC 64
-struct IrvState { int did, pass, round, filled_any, n, rounds, evals; };
+struct IrvState { int did, pass, round, filled_any, n, rounds, evals, kdone; }; // kdone: index of the kernel that found the chain finished
 struct IrvPlan { int act; IrvState s; int nwork; };
 
 ADC_HD IrvPlan irv_plan(const int32_t* ctrl, int k)
 {
     const int32_t* in = ctrl + 16 * (k & 1);
-    IrvState s = {in[0], in[1], in[2], in[3], in[4], in[5], in[6]};
+    IrvState s = {in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7]};
     const int prev = k > 0 ? ctrl[IRV_ACC + ((k - 1) & 63)] : 0;
     IrvPlan p;
     p.nwork = 0;
@@ -63,6 +63,7 @@ ADC_HD IrvPlan irv_plan(const int32_t* ctrl, int k)
         }
         if (p.act == IRV_VOTE) { s.rounds++; s.evals += p.nwork; }
     }
+    if (p.act == IRV_DONE && s.did != IRV_DONE) s.kdone = k; // first kernel with nothing left to do
     s.did = p.act;
     p.s = s;
     return p;
@@ -70,7 +71,7 @@ ADC_HD IrvPlan irv_plan(const int32_t* ctrl, int k)
 ADC_HD void irv_publish(int32_t* ctrl, int k, const IrvState& s)
 {
     int32_t* out = ctrl + 16 * ((k + 1) & 1);
-    out[0] = s.did; out[1] = s.pass; out[2] = s.round; out[3] = s.filled_any; out[4] = s.n; out[5] = s.rounds; out[6] = s.evals;
+    out[0] = s.did; out[1] = s.pass; out[2] = s.round; out[3] = s.filled_any; out[4] = s.n; out[5] = s.rounds; out[6] = s.evals; out[7] = s.kdone;
     ctrl[IRV_ACC + ((k + 2) & 63)] = 0;
 }
 

@@ -64,6 +64,7 @@ __device__ __forceinline__ uint32_t irv_byte_range_mask(int lo, int hi)
 
 // ------------------------------------------------------------------------------------------------------- kernel A
 __global__ __launch_bounds__(256) void k_irv_a(int32_t* __restrict__ ctrl, int k, const uint8_t* __restrict__ label, float* __restrict__ disp,
+                                               float* disp_io, /* the pipeline's map: read by the first BEGIN, written by FINAL (no copies) */
                                                const uint16_t* __restrict__ sup_h, uint16_t* __restrict__ st16, int2* __restrict__ list,
                                                int2* __restrict__ dlist, uint8_t* __restrict__ chg, const uchar4* __restrict__ bbox,
                                                const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin, int D, int min_region,
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_irv_a(int32_t* __restrict__ ctrl, int k
                 if (p < P) {
                     const int y = p / W, x = p - y * W;
                     const size_t i16 = (size_t)y * SP + x;
-                    float dv = disp[p];
+                    float dv = have_state ? disp[p] : disp_io[p]; // pass 0 starts from the LR-checked map itself
                     if (have_state) { // fills of the previous pass: the vote result is best_bin + min_disparity (:211)
                         const uint32_t s = st16[i16];
                         if ((s & IRV_ELIG) && (s & IRV_BIN_MASK) != IRV_BIN_MASK) {
@@ -100,6 +101,8 @@ __global__ __launch_bounds__(256) void k_irv_a(int32_t* __restrict__ ctrl, int k
                             disp[p] = dv;
                         }
                     }
+                    if (!have_state) disp[p] = dv;              // ... and seeds the working copy
+                    if (pl.act == IRV_FINAL_WB) disp_io[p] = dv; // the result goes straight back into the pipeline's map
                     if (pl.act == IRV_BEGIN) {
                         const bool e = (label[p] == which) && (dv == ADC_INVALID_FLOAT);
                         // the vote needs count > irv_ts and count <= region size == horizontal-first support count, so
@@ -331,7 +334,7 @@ static hipError_t irv_launch_pair(adc_handle* h, int k0, int npairs)
     int2* dlist = reinterpret_cast<int2*>(h->vote_dirty);
     for (int i = 0; i < npairs; i++) {
         const int k = k0 + 2 * i;
-        hipLaunchKernelGGL(k_irv_a, dim3(ga), dim3(256), 0, h->stream, h->vote_counters, k, h->label, h->disp_vote, h->sup_h, h->st16,
+        hipLaunchKernelGGL(k_irv_a, dim3(ga), dim3(256), 0, h->stream, h->vote_counters, k, h->label, h->disp_vote, h->disp_l, h->sup_h, h->st16,
                            list, dlist, chg, reinterpret_cast<const uchar4*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H,
                            h->st16_pitch, p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch);
         hipLaunchKernelGGL(k_irv_b, dim3(gb), dim3(256), (size_t)4 * p.D * sizeof(int), h->stream, h->vote_counters, k + 1, list, dlist,
@@ -341,21 +344,19 @@ static hipError_t irv_launch_pair(adc_handle* h, int k0, int npairs)
     return hipGetLastError();
 }
 
-// Enqueue-only: bbox, working copy of the LR-checked map, the budgeted chain, copy back, state read-back (pinned).
+// Enqueue-only: bbox, the budgeted chain (its first kernel reads the LR-checked map disp_l and seeds the working copy
+// disp_vote, its FINAL kernel writes the result back into disp_l), state read-back (pinned).
 hipError_t adc_run_region_voting(adc_handle* h)
 {
     const AdcParams& p = h->p;
-    const size_t P = (size_t)p.W * p.H;
     hipError_t e;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_irv_bbox, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms),
                        reinterpret_cast<uchar4*>(h->irv_bbox), p.W, p.H);
-    if ((e = hipMemcpyAsync(h->disp_vote, h->disp_l, P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(h->vote_counters, 0, 160 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
     if (h->irv_budget < 4) h->irv_budget = 4;
     if ((e = irv_launch_pair(h, 0, h->irv_budget)) != hipSuccess) return e;
     h->irv_chain = 2 * h->irv_budget;
-    if ((e = hipMemcpyAsync(h->disp_l, h->disp_vote, P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
     // the state the last kernel published (slot chain & 1), read by adc_wait / adc_voting_finish
     if (h->pin_flags)
         e = hipMemcpyAsync(h->pin_flags + 16, h->vote_counters + 16 * (h->irv_chain & 1), 8 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
@@ -371,7 +372,6 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     *continued = 0;
     if (!h->irv_pending || !h->pin_flags) return hipSuccess;
     h->irv_pending = 0;
-    const size_t P = (size_t)h->p.W * h->p.H;
     hipError_t e;
     int32_t* st = h->pin_flags + 16;
     int guard = 0;
@@ -385,13 +385,11 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     }
     h->vote_rounds = st[5];
     h->vote_evals = st[6];
-    if (*continued) {
-        h->irv_overflows++;
-        if ((e = hipMemcpyAsync(h->disp_l, h->disp_vote, P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
-    }
-    // budget of the next Match: kernel pairs actually needed (rounds + BEGIN/FINAL slots: at most 2 per pass) + 12 % + 4
-    const int used = st[5] + 2 * (st[1] + 1) + 2;
+    if (*continued) h->irv_overflows++; // (the FINAL kernel of the continued chain has written the result into disp_l)
+    // budget of the next Match: the kernel pairs this one actually needed (st[7] = index of the first kernel that found
+    // nothing left to do) + 12 % + 2
+    const int used = (st[7] + 2) / 2;
     static const int fixed = [] { const char* ev = getenv("ADC_IRV_BUDGET"); return ev ? atoi(ev) : 0; }();
-    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 15, used + used / 8 + 4);
+    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 15, used + used / 8 + 2);
     return hipSuccess;
 }
