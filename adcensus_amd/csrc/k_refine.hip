@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_interpolate_rays(const int32_t* __restr
             any = val != ADC_INVALID_FLOAT;
             best = val;
         }
-        if (live && s == 0) dout[p] = any ? best : 0.0f; // no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
+        if (live && s == 0) dout[e] = any ? best : 0.0f; // fill value of list entry e; no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
     }
 }
 
@@ -359,8 +359,16 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
             any = val != ADC_INVALID_FLOAT;
             best = val;
         }
-        if (live && s == 0) dout[p] = any ? best : 0.0f; // no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
+        if (live && s == 0) dout[e] = any ? best : 0.0f; // fill value of list entry e; no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
     }
+}
+
+// deferred write-back of a list (multistep_refiner.cpp:298-303): disp[list[e]] = fill[e]
+__global__ __launch_bounds__(256) void k_interp_scatter(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
+                                                        const float* __restrict__ fill, float* __restrict__ disp)
+{
+    const int n = counters[0];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) disp[list[e]] = fill[e];
 }
 
 hipError_t adc_launch_interpolation(adc_handle* h)
@@ -374,11 +382,13 @@ hipError_t adc_launch_interpolation(adc_handle* h)
     for (int k = 0; k < 2; k++) {
         const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
         if (rays) {
+            // The reference computes the fill values of a whole list from the UNCHANGED map and writes them back afterwards
+            // (fill_disps, multistep_refiner.cpp:246-303): same structure here -- fill[e] per list entry (disp_tmp serves
+            // as the array), then a scatter into the map in place.  No copy of the map, no buffer swap.
             hipError_t e;
             if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_irv_begin, dim3((P + 256 * IRV_BEGIN_PPT - 1) / (256 * IRV_BEGIN_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
                                h->interp_list, h->interp_counters, which, P, -1, (int32_t*)nullptr, (int2*)nullptr);
-            if ((e = hipMemcpyAsync(h->disp_tmp, h->disp_l, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return e;
             if (h->ray_tab && max_search == h->ray_tab_rows) {
                 if (k == 0 && !h->bgrx_valid) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
                 static const int ns = [] { const char* e = getenv("ADC_INTERP_NS"); return e ? atoi(e) : 4; }(); // ray steps per trip
@@ -394,6 +404,8 @@ hipError_t adc_launch_interpolation(adc_handle* h)
             else
                 hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_l,
                                    h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
+            hipLaunchKernelGGL(k_interp_scatter, dim3(1024), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_tmp, h->disp_l);
+            continue;
         } else {
             hipLaunchKernelGGL(k_interpolate, grid, block, 0, h->stream, h->disp_l, h->disp_tmp, h->label, h->img_l, h->ray_sincos,
                                p.W, p.H, which, max_search);
