@@ -207,17 +207,25 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(reexec_under_torchrun(a))
+    # stdout carries exactly ONE line (the JSON of rank 0): everything else that writes to fd 1 underneath us (the RCCL version
+    # banner at communicator creation, the reference's printf()s in the CPU-baseline leg) is sent to stderr until then
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     tensor_device = "cpu"
-    if world > 1:
+    if world > 1 or os.environ.get("ADC_BENCH_FORCE_DIST") == "1":  # (FORCE_DIST: exercise the RCCL calls with one rank)
         # torch first: its bundled HIP runtime (same SONAME) is then shared by the C-ABI library
         import torch
         import torch.distributed as _dist
         dist = _dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("ADC_BENCH_BACKEND", "nccl")  # "gloo": test hook (several ranks on one GPU)
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -315,7 +323,15 @@ def main():
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(make_pair(a.workload, W, H, D, 0), D, a.cpu_rows, H)
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)  # C-level buffers (RCCL / the reference) go where fd 1 points NOW: stderr
+        except Exception:
+            pass
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)  # (anything printed during teardown must not follow the JSON line)
     if dist is not None:
         dist.destroy_process_group()
 
