@@ -702,7 +702,10 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
         if ((which == 1 && variant == 0 && small_L > 0 && small_L < L) || (which == 2 && variant == 1)) continue;
         // the ring only has to be as deep as the longest arm of this direction when the host knows it (which == 1)
-        const int Lknown = adc_imax(1, h->armmax_host[VERT ? 1 : 0]);
+        // armmax_valid == 2: the depth is ASSUMED from the previous Match of the handle -- one entry of margin, so that the
+        // next image of a similar stream (a longest arm of 3 after 2) does not force a redo (ADC_AGG_ASSUME_MARGIN)
+        static const int assume_margin = env_int("ADC_AGG_ASSUME_MARGIN", 1);
+        const int Lknown = adc_imax(1, h->armmax_host[VERT ? 1 : 0]) + (h->armmax_valid == 2 ? assume_margin : 0);
         const int Lv = variant ? ((which == 1 && h->armmax_valid) ? adc_imin(small_L, Lknown) : small_L) : L;
         // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring, the pair variant a second
         // ring and a record ring

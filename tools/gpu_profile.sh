@@ -7,7 +7,7 @@ timeout 600 python bench.py --steps 160 --warmup 3 --no-cpu-baseline --no-extra-
 cp $O/farm_digests.json tests/golden/farm_digests.json
 timeout 900 python bench.py > $O/r2_bench_default.json 2> $O/r2_bench_default.err; echo "default rc=$?"; cut -c1-600 $O/r2_bench_default.json
 timeout 900 python bench.py --workload structured --steps 10 > $O/r2_bench_structured.json 2> $O/r2_bench_structured.err; echo "structured rc=$?"
-ADC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/s3_bench_2ranks_gloo.json 2> $O/s3_bench_2ranks_gloo.err; echo "2ranks rc=$?"; cut -c1-900 $O/s3_bench_2ranks_gloo.json
+ADC_BENCH_BACKEND=gloo ADC_BENCH_DEVICE=0 timeout 600 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/s3_bench_2ranks_gloo.json 2> $O/s3_bench_2ranks_gloo.err; echo "2ranks rc=$?"; cut -c1-900 $O/s3_bench_2ranks_gloo.json
 for WL in noise structured; do
   timeout 600 python bench.py --width 1242 --height 375 --workload $WL --steps 20 --no-cpu-baseline --no-extra-legs > $O/r2_bench_kitti_$WL.json 2> $O/r2_bench_kitti_$WL.err; echo "kitti $WL rc=$?"
 done
