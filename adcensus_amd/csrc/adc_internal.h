@@ -65,10 +65,10 @@ struct adc_handle {
     uint8_t* label;
     uint8_t* elig;       // region voting: eligible mask of the current pass
     uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
-    int32_t* vote_list;  // compact list of eligible pixels
+    int32_t* vote_list;  // work list of the voting pass: int4 entries (k_voting.hip)
+    int32_t* vote_evals_arr; // evaluation counter per wave of the chain's grid (statistics)
     int32_t* interp_list;     // target list of the interpolation (its own buffers: the voting chain may be CONTINUED after
     int32_t* interp_counters; // the interpolation has run once, and must find its list and control block untouched)
-    int32_t* vote_dirty; // compact list of the entries to re-evaluate in the current round
     int32_t* ray_tab;     // [max_search][16] packed ray offsets (dy<<16 | dx&0xffff), NULL when a step is too close to a .5 tie
     int ray_tab_rows;
     uint32_t* cost_rrec;  // [H][rrec_pitch] uint4 {bgrx, census lo, census hi, 0} of the RIGHT image, padded with out-of-image
@@ -95,7 +95,7 @@ struct adc_handle {
     uint16_t* st16;      // region voting: 16-bit state map [H][st16_pitch] {bin:11 | final | eligible} (k_voting.hip)
     int st16_pitch;      // row pitch of st16 in elements (multiple of 8: rows start 16-byte aligned)
     float* disp_vote;    // the map the voting chain works on (copy of the LR-checked map, copied back when the chain ends)
-    int irv_budget;      // kernel pairs (A,B) the next Match enqueues for the voting chain (adapted from the last Match)
+    int irv_budget;      // kernels the next Match enqueues for the voting chain (adapted from the last Match)
     int irv_chain;       // kernels of the chain enqueued so far (continuation starts here)
     int irv_pending;     // a chain was enqueued and its final state has not been looked at yet
     int irv_overflows;   // how often adc_wait had to continue the chain (budget too small)
@@ -137,6 +137,8 @@ size_t adc_so_cls_bytes(int W, int H);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_lrcheck(adc_handle* h);
+size_t adc_irv_waves();                        // waves of the voting chain's grid
+size_t adc_irv_list_entries(size_t pixels, int D);    // capacity of the voting work list (whole batches)
 hipError_t adc_run_region_voting(adc_handle* h); // enqueue only (device-driven chain with a launch budget)
 hipError_t adc_voting_finish(adc_handle* h, int* continued); // after a sync: continue the chain if the budget was too small
 hipError_t adc_launch_interpolation(adc_handle* h);

@@ -101,8 +101,9 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->label, P));
     HIP_OK(hipMalloc(&h->elig, P));
     HIP_OK(hipMalloc(&h->irv_bbox, P * 4));
-    HIP_OK(hipMalloc(&h->vote_list, P * 8));  // int2 {pixel, arms} per entry
-    HIP_OK(hipMalloc(&h->vote_dirty, P * 8));
+    HIP_OK(hipMalloc(&h->vote_list, adc_irv_list_entries(P, p.D) * 16)); // int4 per entry, whole batches (irv_plan.h: irv_list_slot)
+    HIP_OK(hipMemset(h->vote_list, 0, adc_irv_list_entries(P, p.D) * 16));
+    HIP_OK(hipMalloc(&h->vote_evals_arr, adc_irv_waves() * sizeof(int32_t)));
     HIP_OK(hipMalloc(&h->interp_list, P * 4));
     HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));
     h->st16_pitch = (p.W + 7) & ~7;
@@ -110,19 +111,19 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin
     HIP_OK(hipMalloc(&h->disp_vote, P * 4));
     HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
-    h->irv_budget = 48;
+    h->irv_budget = 96;
     // change-tile map of the voting rounds: one BYTE per 8x8 tile, rows padded to a multiple of 4 (+16: a 16-byte load
     // may start at the last dword of a row)
     h->chg_pitch = (((p.W + 7) / 8 + 3) & ~3) + 16;
     const size_t tiles = (size_t)h->chg_pitch * ((p.H + 7) / 8) + 64;
-    HIP_OK(hipMalloc(&h->chg_a, tiles));
+    HIP_OK(hipMalloc(&h->chg_a, 2 * tiles)); // two planes (round parity)
     HIP_OK(hipMalloc(&h->edge, P));
     HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_flags, 64 * sizeof(int32_t), hipHostMallocDefault));
     memset(h->pin_flags, 0, 64 * sizeof(int32_t)); // [0] median error, [4..7] armmax + violation flag, [16..23] voting state
     HIP_OK(hipMemset(h->label, 0, P));
-    HIP_OK(hipMemset(h->chg_a, 0, tiles));
+    HIP_OK(hipMemset(h->chg_a, 0, 2 * tiles));
     HIP_OK(hipMemset(h->vol_a, 0, VB));
     HIP_OK(hipMemset(h->vol_b, 0, VB));
     return hipSuccess;
@@ -247,7 +248,7 @@ void adc_destroy(adc_handle* h)
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_dirty, h->interp_list, h->interp_counters, h->st16, h->disp_vote, h->vote_counters,
+                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->st16, h->disp_vote, h->vote_counters,
                     h->chg_a, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
@@ -737,7 +738,7 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
         break;
     case ADC_RUN_WTA: e = adc_launch_wta(h); break;
     case ADC_RUN_LRCHECK: e = adc_launch_lrcheck(h); break;
-    case ADC_RUN_REGION_VOTING: // arg > 0: launch budget (kernel pairs) of this run, e.g. 4 to force the continuation path
+    case ADC_RUN_REGION_VOTING: // arg > 0: launch budget (kernels) of this run, e.g. 4 to force the continuation path
         if (arg > 0) h->irv_budget = arg;
         e = adc_run_region_voting(h);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

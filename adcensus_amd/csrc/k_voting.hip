@@ -1,6 +1,6 @@
 // k_voting.hip -- K8 iterative region voting (MultiStepRefiner::IterativeRegionVoting, multistep_refiner.cpp:153-227),
-// DEVICE-DRIVEN: the host enqueues a fixed chain of kernels A, B, A, B, ... and never looks at the data; which list is
-// being filled, which round runs and when a pass has converged is decided on the device.
+// DEVICE-DRIVEN: the host enqueues a fixed chain of identical kernels and never looks at the data; which list is being
+// filled, which round runs and when a pass has converged is decided on the device.
 //
 // Semantics kept exactly: 5 iterations x {mismatches, occlusions}; inside a pass the reference fills the
 // still-invalid pixels of the list in raster order IN PLACE, so a vote sees the fills of the list pixels that precede
@@ -16,16 +16,19 @@
 // eligible predecessors were all final get the final bit and are never evaluated again; from round 1 on only entries
 // whose dependency box (k_irv_bbox) saw a change in the previous round are re-evaluated (8x8 change tiles).
 //
-// The chain.  Kernel k (even = A, odd = B) reads the state its predecessor wrote (slot k & 1) and the predecessor's
-// accumulator acc[(k-1) & 63] (list length / number of dirty entries / "something changed"), derives its own action --
-// every block derives the same one -- and block 0 publishes the new state into slot (k+1) & 1 and clears the
-// accumulator kernel k+2 will use.  No host round trip, no grid barrier, no ticket atomics:
-//     A: BEGIN  write the previous pass's fills back to the float map, mark the eligible pixels of the next list, compact
-//               the work list (pixels whose region is too small to ever pass the vote are left out)
-//        CHECK  compact the entries that must be re-evaluated in this round
-//        FINAL  write the last pass's fills back
-//     B: VOTE   evaluate the work list (round 0) or the dirty list
-// The chain length is a BUDGET (adc_handle::irv_budget, adapted from the rounds the previous Match of the handle needed);
+// The chain.  Kernel k reads the state its predecessor wrote (slot k & 1) and the predecessor's accumulator
+// acc[(k-1) & 63] (list length / "something changed"), derives its own action -- every block derives the same one -- and
+// block 0 publishes the new state into slot (k+1) & 1 and clears the accumulators kernel k+2 will use.  No host round
+// trip, no grid barrier (measured: 4.2-4.8 us on this chip against 2.4-2.9 us for a dependent launch,
+// tools/ubench/grid_sync.hip), no ticket atomics:
+//     BEGIN  write the previous pass's fills back to the float map, mark the eligible pixels of the next list, build the
+//            work list (pixels whose region is too small to ever pass the vote are left out)
+//     ROUND  ONE kernel per round: every wave holds (up to) 64 list entries, one per lane, decides per lane whether the
+//            entry has to be re-evaluated and evaluates its dirty entries one after the other.  (The first version ran a
+//            compaction kernel and a vote kernel per round; a round of the long tail is a chain of dependent memory round
+//            trips, and the second kernel boundary + plan + list round trip were 40 % of it.)
+//     FINAL  write the last pass's fills back
+// The chain length is a BUDGET (adc_handle::irv_budget, adapted from the kernels the previous Match of the handle needed);
 // when it is exhausted before the state machine reaches DONE, adc_wait continues the same chain synchronously and redoes
 // the stages behind it -- a performance cliff, never a different result.
 #include "adc_internal.h"
@@ -35,6 +38,21 @@
 #include <stdlib.h>
 
 #include "irv_plan.h"
+
+#ifdef IRV_TIMING // diagnosis build (tools/build_variant.sh): where does a kernel of the chain spend its time?
+// wave 0 of every 64th workgroup stamps s_memtime at the stage boundaries (drained loads) and s_memrealtime at entry / exit
+__device__ long long g_irv_t[8][8192][10];
+#define IRV_TSEL ((blockIdx.x & 63) == 0 && blockIdx.x < 512 && threadIdx.x < 64)
+#define IRV_T(slot) do { if (IRV_TSEL) { long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (threadIdx.x == 0 && k < 8192) g_irv_t[blockIdx.x >> 6][k][slot] = t_; } } while (0)
+#define IRV_TR(slot) do { if (IRV_TSEL) { long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (threadIdx.x == 0 && k < 8192) g_irv_t[blockIdx.x >> 6][k][slot] = t_; } } while (0)
+extern "C" int adc_debug_irv_timing(long long* out, int which, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_irv_t), (size_t)n * 10 * sizeof(long long), (size_t)which * 8192 * 10 * sizeof(long long));
+}
+#else
+#define IRV_T(slot) do { } while (0)
+#define IRV_TR(slot) do { } while (0)
+#endif
 
 // Dependency box of a pixel's vote: the cross region of p spans rows y-top..y+bottom, but only pixels that PRECEDE p in
 // raster order can influence it, i.e. rows y-top..y; its horizontal extent is the widest H arm of those rows.
@@ -54,42 +72,163 @@ __global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arm
     bbox[(size_t)y * W + x] = make_uchar4(a.z, (unsigned char)ml, (unsigned char)mr, 0);
 }
 
-// mask of the bytes [lo, hi) of a dword, 0 <= lo, hi <= 4
-__device__ __forceinline__ uint32_t irv_byte_range_mask(int lo, int hi)
+// bits 0..3 of n -> bytes 0..3 (0xFF where the bit is set)
+__device__ __forceinline__ uint32_t irv_expand_nibble(uint32_t n) { return ((n * 0x00204081u) & 0x01010101u) * 0xFFu; }
+
+// Did a pixel of the tile box [tx0, tx1] x [ty0, ty1] change in the round whose stamp is want4 (replicated byte)?  A
+// tile row of the box = 16 bytes from a dword-aligned column; bytes outside the box are forced non-zero (nk = ~byte
+// mask per dword, from a 16-bit byte-valid mask) before the any-zero-byte test of (word ^ stamp); three tile rows are
+// in flight (rows past ty1 repeat row ty1: harmless duplicates).  One iteration of each loop for arm limits <= 34 and
+// boxes of <= 17 rows.  Not inlined: the round kernel has to stay at 64 VGPRs (8 waves per SIMD, the whole grid
+// co-resident), and inlined the compiler interleaves this with the surrounding code at 80-110.
+__device__ __forceinline__ bool irv_box_dirty(const uint8_t* __restrict__ chg_rd, int tpitch, int tx0, int tx1, int ty0, int ty1,
+                                                        uint32_t want4)
 {
-    const uint32_t a = hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
-    const uint32_t b = lo >= 4 ? 0xFFFFFFFFu : ((1u << (8 * lo)) - 1u);
-    return hi > lo ? (a & ~b) : 0u;
+    bool dirty = false;
+    // (interleave(disable): the loop vectoriser otherwise runs two iterations of these OR-reductions side by side)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int txb = tx0; txb <= tx1; txb += 12) {
+        const int cb = txb & ~3, last = adc_imin(tx1, txb + 11);
+        const uint32_t m16 = ((1u << (last + 1 - cb)) - 1u) & ~((1u << (txb - cb)) - 1u);
+        const uint32_t nk0 = ~irv_expand_nibble(m16 & 15u), nk1 = ~irv_expand_nibble((m16 >> 4) & 15u),
+                       nk2 = ~irv_expand_nibble((m16 >> 8) & 15u), nk3 = ~irv_expand_nibble(m16 >> 12);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int tyb = ty0; tyb <= ty1; tyb += 3) {
+            const uint4 v0 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 0, ty1) * tpitch + cb));
+            const uint4 v1 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 1, ty1) * tpitch + cb));
+            const uint4 v2 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 2, ty1) * tpitch + cb));
+#define IRV_ANYZ(WORD, NK) ((((((WORD) ^ want4) | (NK)) - 0x01010101u) & ~(((WORD) ^ want4) | (NK))) & 0x80808080u)
+            const uint32_t hit = IRV_ANYZ(v0.x, nk0) | IRV_ANYZ(v0.y, nk1) | IRV_ANYZ(v0.z, nk2) | IRV_ANYZ(v0.w, nk3) |
+                                 IRV_ANYZ(v1.x, nk0) | IRV_ANYZ(v1.y, nk1) | IRV_ANYZ(v1.z, nk2) | IRV_ANYZ(v1.w, nk3) |
+                                 IRV_ANYZ(v2.x, nk0) | IRV_ANYZ(v2.y, nk1) | IRV_ANYZ(v2.z, nk2) | IRV_ANYZ(v2.w, nk3);
+#undef IRV_ANYZ
+            dirty |= hit != 0u;
+        }
+    }
+    return dirty;
 }
 
-// ------------------------------------------------------------------------------------------------------- kernel A
-__global__ __launch_bounds__(256) void k_irv_a(int32_t* __restrict__ ctrl, int k, const uint8_t* __restrict__ label, float* __restrict__ disp,
-                                               float* disp_io, /* the pipeline's map: read by the first BEGIN, written by FINAL (no copies) */
-                                               const uint16_t* __restrict__ sup_h, uint16_t* __restrict__ st16, int2* __restrict__ list,
-                                               int2* __restrict__ dlist, uint8_t* __restrict__ chg, const uchar4* __restrict__ bbox,
-                                               const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin, int D, int min_region,
-                                               int chg_bytes, int tpitch)
+// bit k of the words t0..t3 -> bits 0, 2, 4, 6 and bit k + 16 -> bits 1, 3, 5, 7 (k >= 6): the same flag of the 8 packed
+// halfwords of a 16-byte block as one 8-bit mask
+__device__ __forceinline__ uint32_t irv_gather8(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, int k)
 {
-    const IrvPlan pl = irv_plan(ctrl, k);
-    if (blockIdx.x == 0 && threadIdx.x == 0) irv_publish(ctrl, k, pl.s);
+    const uint32_t sel = 0x00010001u;
+    const uint32_t u = ((t0 >> k) & sel) | ((t1 >> (k - 2)) & (sel << 2)) | ((t2 >> (k - 4)) & (sel << 4)) | ((t3 >> (k - 6)) & (sel << 6));
+    return (u | (u >> 15)) & 0xffu;
+}
+
+// Wave-wide maximum / sum of non-negative ints in 6 DPP steps (row rotations, then the two row broadcasts of gfx9); the
+// result is valid in lane 63 and returned wave-uniform.  (__shfl_xor is a ds_bpermute: ~100 cycles per step.)
+#define IRV_DPP(V, CTRL, RMASK) __builtin_amdgcn_update_dpp(0, (V), (CTRL), (RMASK), 0xf, false)
+__device__ __forceinline__ int irv_wave_max(int v)
+{
+    v = adc_imax(v, IRV_DPP(v, 0x121, 0xf)); // row_ror:1
+    v = adc_imax(v, IRV_DPP(v, 0x122, 0xf));
+    v = adc_imax(v, IRV_DPP(v, 0x124, 0xf));
+    v = adc_imax(v, IRV_DPP(v, 0x128, 0xf));
+    v = adc_imax(v, IRV_DPP(v, 0x142, 0xa)); // row_bcast:15 into rows 1, 3
+    v = adc_imax(v, IRV_DPP(v, 0x143, 0xc)); // row_bcast:31 into rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int irv_wave_sum(int v)
+{
+    v += IRV_DPP(v, 0x121, 0xf);
+    v += IRV_DPP(v, 0x122, 0xf);
+    v += IRV_DPP(v, 0x124, 0xf);
+    v += IRV_DPP(v, 0x128, 0xf);
+    v += IRV_DPP(v, 0x142, 0xa);
+    v += IRV_DPP(v, 0x143, 0xc);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum within each row of 16 lanes (row_shr with zero fill)
+__device__ __forceinline__ int irv_row_prefix(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    return v;
+}
+#undef IRV_DPP
+
+// ------------------------------------------------------------------------------------------- the kernel of the chain
+// Work-list entry: {pixel, arms of the pixel, max left | max right << 8 of its dependency box, row y}.
+// Workgroups of up to 16 waves (blockDim.x = 64 * waves): the dirty entries of a workgroup's waves are
+// pooled in LDS and dealt out to its waves round-robin, so a round takes ceil(pool / waves) votes per wave -- without
+// the pooling a tail round is as slow as the unluckiest wave (3-4 votes of ~3 us each where the average is 0.2).
+#define IRV_MAXW 16
+__global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, int k, const uint8_t* __restrict__ label, float* __restrict__ disp,
+                                                float* disp_io, /* the pipeline's map: read by the first BEGIN, written by FINAL (no copies) */
+                                                const uint16_t* __restrict__ sup_h, uint16_t* st16, int4* list, uint8_t* chg,
+                                                const uchar4* __restrict__ bbox, const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
+                                                int D, int min_region, int chg_bytes, int tpitch, int irv_ts, float irv_th,
+                                                int32_t* __restrict__ evals_arr)
+{
+    IRV_TR(8);
+    IRV_T(0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, WPB = blockDim.x >> 6, T = blockDim.x;
+    const int gw = blockIdx.x * WPB + wave, NW = gridDim.x * WPB;
+    // Everything the first phase of a ROUND needs is known at launch time: this wave's entries of batch 0, and -- the change
+    // tiles being stamped and double-buffered by KERNEL index -- which plane and which stamp to look for.  So the entry,
+    // state and tile loads are issued before the chain state (written by another XCD's workgroup 0 of the previous kernel:
+    // the slowest load of the kernel) has arrived.  Slots beyond the list hold older entries or zeros: always in-bounds.
+    // (The state is fetched with a VECTOR load -- lane l reads word l, lane 8 the accumulator -- because scalar loads return
+    // out of order: the kernel-argument loads would wait for it.)
+    const int4 spec = list[(size_t)gw * 64 + lane];
+    const int cword = ctrl[lane < 8 ? 16 * (k & 1) + lane : IRV_ACC + ((k + 63) & 63)];
+    const uint32_t want4 = ((uint32_t)((k + 254) % 255) + 1u) * 0x01010101u; // stamp of kernel k - 1
+    const uint32_t stamp = (uint32_t)(k % 255) + 1u;
+    const uint8_t* chg_rd = chg + (size_t)((k + 1) & 1) * chg_bytes;
+    uint8_t* chg_wr = chg + (size_t)(k & 1) * chg_bytes;
+    uint32_t spec_state;
+    bool spec_box;
+    {
+        const int p = spec.x, y = spec.w, x = p - y * W;
+        spec_state = st16[(uint32_t)(y * SP + x)]; // (32-bit offsets from a uniform base: saddr addressing, no 64-bit VGPR pairs)
+        const int top = (int)(((uint32_t)spec.y >> 16) & 255u), ml = spec.z & 255, mr = (spec.z >> 8) & 255;
+        spec_box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, adc_imin(W - 1, x + mr) / IRV_TILE,
+                                 adc_imax(0, y - top) / IRV_TILE, y / IRV_TILE, want4);
+    }
+    const IrvState sprev = {__builtin_amdgcn_readlane(cword, 0), __builtin_amdgcn_readlane(cword, 1), __builtin_amdgcn_readlane(cword, 2),
+                            __builtin_amdgcn_readlane(cword, 3), __builtin_amdgcn_readlane(cword, 4), __builtin_amdgcn_readlane(cword, 5),
+                            __builtin_amdgcn_readlane(cword, 6), __builtin_amdgcn_readlane(cword, 7)};
+    const IrvPlan pl = irv_plan_from(sprev, k > 0 ? __builtin_amdgcn_readlane(cword, 8) : 0, k);
+    IRV_T(1);
+    if (pl.act != IRV_FINAL_WB && blockIdx.x == 0 && threadIdx.x == 0) irv_publish(ctrl, k, pl.s);
     if (pl.act == IRV_DONE) return;
     int32_t* acc = ctrl + IRV_ACC + (k & 63);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int P = W * H;
     if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
+        // evaluation statistics: every wave counts in its own slot (a same-address atomic per wave and round cost more
+        // than the votes of a tail round: they retire at ~8 ns each); cleared by the first kernel, summed by the last
+        if (pl.act == IRV_BEGIN && pl.s.pass == 0)
+            for (int t = blockIdx.x * T + threadIdx.x; t < NW; t += gridDim.x * T) evals_arr[t] = 0;
+        if (pl.act == IRV_FINAL_WB && blockIdx.x == 0) {
+            __shared__ int esum[IRV_MAXW];
+            int e = 0;
+            for (int t = threadIdx.x; t < NW; t += T) e += evals_arr[t];
+            e = irv_wave_sum(e);
+            if (lane == 0) esum[wave] = e;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                IrvState fs = pl.s;
+                fs.evals = 0;
+                for (int w = 0; w < WPB; w++) fs.evals += esum[w];
+                irv_publish(ctrl, k, fs);
+            }
+        }
         const bool have_state = !(pl.act == IRV_BEGIN && pl.s.pass == 0); // pass 0: the state map is not initialised yet
         const int which = (pl.s.pass & 1) ? ADC_LABEL_OCCLUSION : ADC_LABEL_MISMATCH; // mismatches, then occlusions (:170-171)
-        if (pl.act == IRV_BEGIN) // clear the change-tile map of the pass (bytes, written as dwords)
-            for (int t = blockIdx.x * 256 + threadIdx.x; t < chg_bytes / 4; t += gridDim.x * 256) reinterpret_cast<uint32_t*>(chg)[t] = 0u;
-        __shared__ int wcnt[IRV_PPT][4];
+        if (pl.act == IRV_BEGIN) // clear both change-tile planes of the pass (bytes, written as dwords)
+            for (int t = blockIdx.x * T + threadIdx.x; t < chg_bytes / 2; t += gridDim.x * T) reinterpret_cast<uint32_t*>(chg)[t] = 0u;
+        __shared__ int wcnt[IRV_PPT][IRV_MAXW];
         __shared__ int base;
-        for (int c0 = blockIdx.x * (256 * IRV_PPT); c0 < P; c0 += gridDim.x * (256 * IRV_PPT)) {
-            unsigned long long m[IRV_PPT];
-            bool listed[IRV_PPT];
-#pragma unroll
+        for (int c0 = blockIdx.x * (T * IRV_PPT); c0 < P; c0 += gridDim.x * (T * IRV_PPT)) {
+            uint32_t listed = 0u; // bit q: pixel c0 + q * T + threadIdx.x goes on the work list
+#pragma unroll 1
             for (int q = 0; q < IRV_PPT; q++) {
-                const int p = c0 + q * 256 + threadIdx.x;
-                listed[q] = false;
+                const int p = c0 + q * T + threadIdx.x;
+                bool li = false;
                 if (p < P) {
                     const int y = p / W, x = p - y * W;
                     const size_t i16 = (size_t)y * SP + x;
@@ -108,212 +247,203 @@ __global__ __launch_bounds__(256) void k_irv_a(int32_t* __restrict__ ctrl, int k
                         // the vote needs count > irv_ts and count <= region size == horizontal-first support count, so
                         // pixels with sup_h <= irv_ts stay invalid whatever happens: eligible (they order the pass) but
                         // final from the start and not on the work list
-                        listed[q] = e && ((int)sup_h[p] > min_region);
+                        li = e && ((int)sup_h[p] > min_region);
                         uint32_t bin = IRV_BIN_MASK;
                         if (dv != ADC_INVALID_FLOAT) {
                             const long b = lroundf(dv) - dmin; // multistep_refiner.cpp:193-196
                             if (b >= 0 && b < D) bin = (uint32_t)b; // (outside the histogram: never counted)
                         }
-                        st16[i16] = (uint16_t)(bin | (e ? IRV_ELIG : 0u) | (listed[q] ? 0u : IRV_FINAL));
+                        st16[i16] = (uint16_t)(bin | (e ? IRV_ELIG : 0u) | (li ? 0u : IRV_FINAL));
                     }
                 }
-                m[q] = __ballot(listed[q]);
-                if (lane == 0) wcnt[q][wave] = __popcll(m[q]);
+                listed |= (li ? 1u : 0u) << q;
+                const unsigned long long m = __ballot(li);
+                if (lane == 0) wcnt[q][wave] = __popcll(m);
             }
             if (pl.act != IRV_BEGIN) continue; // (uniform)
             __syncthreads();
             if (threadIdx.x == 0) {
                 int tot = 0;
-#pragma unroll
-                for (int q = 0; q < IRV_PPT; q++) tot += wcnt[q][0] + wcnt[q][1] + wcnt[q][2] + wcnt[q][3];
-                base = tot ? atomicAdd(acc, tot) : 0; // one same-address atomic per 2048 pixels (they retire at ~8 ns each)
+                for (int q = 0; q < IRV_PPT; q++)
+                    for (int w = 0; w < WPB; w++) tot += wcnt[q][w];
+                base = tot ? atomicAdd(acc, tot) : 0; // one same-address atomic per chunk of pixels (they retire at ~8 ns each)
             }
             __syncthreads();
             int off = base;
-#pragma unroll
+#pragma unroll 1
             for (int q = 0; q < IRV_PPT; q++) {
-                const int p = c0 + q * 256 + threadIdx.x;
+                const int p = c0 + q * T + threadIdx.x;
+                const bool li = (listed >> q) & 1u;
+                const unsigned long long m = __ballot(li);
                 int mine = off;
-                for (int w = 0; w < wave; w++) mine += wcnt[q][w];
-                // entry = {pixel, its arms}: the vote starts from ONE 8-byte load (no dependent arms[p] round trip)
-                if (listed[q]) list[mine + __popcll(m[q] & ((1ull << lane) - 1ull))] = make_int2(p, (int)arms32[p]);
-                off += wcnt[q][0] + wcnt[q][1] + wcnt[q][2] + wcnt[q][3];
+                for (int w = 0; w < WPB; w++) {
+                    const int c = wcnt[q][w];
+                    mine += w < wave ? c : 0;
+                    off += c;
+                }
+                if (li) { // everything a round needs to know about the entry in ONE 16-byte load
+                    const uchar4 bb = bbox[p];
+                    const long i = mine + __popcll(m & ((1ull << lane) - 1ull));
+                    list[irv_list_slot(i, (int)gridDim.x, WPB)] = make_int4(p, (int)arms32[p], (int)bb.y | ((int)bb.z << 8), p / W);
+                }
             }
             __syncthreads();
         }
         return;
     }
-    // CHECK: one thread per open list entry decides whether some pixel of its dependency box changed in the previous
-    // round; dirty entries are compacted into dlist.  Change tiles are BYTES holding (round % 255) + 1 of the last round
-    // that changed a pixel of the 8x8 tile (0 = never; a stamp aliasing a round 255 rounds earlier can only cause a
-    // redundant evaluation, never a missed one), so one 16-byte load covers a tile row of the box (<= 11 tiles for arms
-    // <= 34) and the 6 rows of a box are in flight together -- the 30 dependent dword loads of the first version were
-    // what this kernel spent its time on.
-    const int round = pl.s.round, n = pl.nwork;
-    const uint32_t want4 = ((uint32_t)((round - 1) % 255) + 1u) * 0x01010101u;
-    __shared__ int cw[4];
-    __shared__ int cbase;
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-        const int i = i0 + threadIdx.x;
-        bool dirty = false;
-        int2 ent = make_int2(-1, 0);
-        if (i < n) {
-            ent = list[i];
-            const int p = ent.x;
-            const int y = p / W, x = p - y * W;
-            if (!(st16[(size_t)y * SP + x] & IRV_FINAL)) { // final values are never re-evaluated
-                const uchar4 bb = bbox[p];
-                const int tx0 = adc_imax(0, x - (int)bb.y) / IRV_TILE, tx1 = adc_imin(W - 1, x + (int)bb.z) / IRV_TILE;
-                const int ty0 = adc_imax(0, y - (int)bb.x) / IRV_TILE, ty1 = y / IRV_TILE;
-#pragma unroll 1
-                for (int tyb = ty0; tyb <= ty1; tyb += 6)
-#pragma unroll 1
-                    for (int txb = tx0; txb <= tx1; txb += 12) { // (one iteration each for arm limits <= 34)
-                        const int cb = txb & ~3, last = adc_imin(tx1, txb + 11); // 16 bytes from a dword-aligned column
-                        uint4 v0, v1, v2, v3, v4, v5; // the (up to) 6 tile rows of the box, all in flight
-                        const uint8_t* cp = chg + cb;
-                        v0 = *reinterpret_cast<const uint4*>(cp + (size_t)adc_imin(tyb + 0, ty1) * tpitch);
-                        v1 = *reinterpret_cast<const uint4*>(cp + (size_t)adc_imin(tyb + 1, ty1) * tpitch);
-                        v2 = *reinterpret_cast<const uint4*>(cp + (size_t)adc_imin(tyb + 2, ty1) * tpitch);
-                        v3 = *reinterpret_cast<const uint4*>(cp + (size_t)adc_imin(tyb + 3, ty1) * tpitch);
-                        v4 = *reinterpret_cast<const uint4*>(cp + (size_t)adc_imin(tyb + 4, ty1) * tpitch);
-                        v5 = *reinterpret_cast<const uint4*>(cp + (size_t)adc_imin(tyb + 5, ty1) * tpitch);
-                        // (rows past ty1 repeat row ty1: harmless duplicates.)  Bytes outside [txb, last] are forced non-zero
-                        // before the "any zero byte" test of (word ^ want4)
-                        uint32_t hit = 0u;
-#define IRV_ANYZ(WORD, CW)                                                                                          \
-    do {                                                                                                            \
-        const int lo_ = adc_imax(0, adc_imin(4, txb - (cb + 4 * (CW)))), hi_ = adc_imax(0, adc_imin(4, last + 1 - (cb + 4 * (CW)))); \
-        const uint32_t vm_ = irv_byte_range_mask(lo_, hi_);                                                          \
-        const uint32_t x_ = ((WORD) ^ want4) | ~vm_;                                                                \
-        hit |= (x_ - 0x01010101u) & ~x_ & 0x80808080u;                                                               \
-    } while (0)
-#define IRV_ROW(V) do { IRV_ANYZ((V).x, 0); IRV_ANYZ((V).y, 1); IRV_ANYZ((V).z, 2); IRV_ANYZ((V).w, 3); } while (0)
-                        IRV_ROW(v0); IRV_ROW(v1); IRV_ROW(v2); IRV_ROW(v3); IRV_ROW(v4); IRV_ROW(v5);
-#undef IRV_ROW
-#undef IRV_ANYZ
-                        dirty |= hit != 0u;
-                    }
-            }
-        }
-        const unsigned long long mm = __ballot(dirty);
-        if (lane == 0) cw[wave] = __popcll(mm);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int tot = cw[0] + cw[1] + cw[2] + cw[3];
-            cbase = tot ? atomicAdd(acc, tot) : 0;
-        }
-        __syncthreads();
-        if (dirty) {
-            int off = cbase;
-            for (int w = 0; w < wave; w++) off += cw[w];
-            dlist[off + __popcll(mm & ((1ull << lane) - 1ull))] = ent;
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------- kernel B
-// One wave per entry.  Trip = 16 region rows x 4 row blocks of 8 pixels (lane = row slot * 4 + block slot).
-__global__ __launch_bounds__(256) void k_irv_b(int32_t* __restrict__ ctrl, int k, const int2* __restrict__ list,
-                                               const int2* __restrict__ dlist, uint16_t* st16, const uchar4* __restrict__ arms,
-                                               uint8_t* __restrict__ chg, int W, int H, int SP, int dmin, int D, int irv_ts, float irv_th,
-                                               int tpitch, int list_cap)
-{
-    // the first entry of this wave from BOTH lists, issued before the plan is known (one dependent round trip less)
-    const int e_first = adc_imin((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), list_cap - 1);
-    const int2 spec_l = list[e_first], spec_d = dlist[e_first];
-    const IrvPlan pl = irv_plan(ctrl, k);
-    if (blockIdx.x == 0 && threadIdx.x == 0) irv_publish(ctrl, k, pl.s);
-    if (pl.act != IRV_VOTE) return;
-    const int round = pl.s.round, n = pl.nwork;
-    const int2* work = round == 0 ? list : dlist;
-    const uint32_t stamp = (uint32_t)(round % 255) + 1u;
-    int32_t* acc = ctrl + IRV_ACC + (k & 63);
-    extern __shared__ int hist_all[]; // [4][D]: one histogram per wave
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int* hist = hist_all + wave * D;
-    const int nwaves = gridDim.x * 4;
+    // ROUND.  Phase 1 (one entry per lane; done above for batch 0): is the entry still open, and did a pixel of its
+    // dependency box change in the previous round?  Change tiles are BYTES holding the stamp of the last kernel that changed
+    // a pixel of the 8x8 tile (0 = never; a stamp aliasing a kernel 510 launches earlier can only cause a redundant
+    // evaluation, never a missed one).  Phase 2: the dirty entries of the workgroup are pooled in LDS.  Phase 3: wave w
+    // evaluates pool entries w, w + waves, ...
+    const int round = pl.s.round, n = pl.s.n;
+    extern __shared__ int lds_dyn[]; // [waves][D] histograms, then the pool: [waves][64] int4
+    int* hist = lds_dyn + wave * D;
+    int4* pool = reinterpret_cast<int4*>(lds_dyn + WPB * D);
+    __shared__ int pcount[IRV_MAXW];
     const int sub = lane >> 2, bslot = lane & 3;
-    for (int e = blockIdx.x * 4 + wave; e < n; e += nwaves) {
-        int2 ent;
-        if (e == e_first) { ent.x = round == 0 ? spec_l.x : spec_d.x; ent.y = round == 0 ? spec_l.y : spec_d.y; }
-        else ent = work[e];
-        const int p = ent.x;
-        const int y = p / W, x = p - y * W;
-        for (int b = lane; b < D; b += 64) hist[b] = 0;
-        bool deps_open = false;
-        const int top = (int)(((uint32_t)ent.y >> 16) & 255u), nrows = top + (int)((uint32_t)ent.y >> 24) + 1; // region rows y-top .. y+bottom
-        const uint32_t cur = st16[(size_t)y * SP + x]; // (only this wave writes the entry in this round)
-        const size_t own = ((size_t)y * SP + x) & ~(size_t)7;     // the entry's own block: address of masked-out loads
-        for (int rbase = 0; rbase < nrows; rbase += 64) {
-            // the H arms of (up to 64) region rows in ONE round trip (lane r holds row rbase + r), handed to the row
-            // slots with a shuffle
-            const int myr = rbase + lane;
-            uint32_t a2 = 0;
-            if (myr < nrows) a2 = reinterpret_cast<const uint32_t*>(arms)[(size_t)(y - top + myr) * W + x];
-            const int rend = adc_imin(nrows - rbase, 64);
-            for (int r0 = 0; r0 < rend; r0 += 16) {
-                const int r = r0 + sub;
-                const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
-                const bool rowok = r < rend;
-                const int yt = y - top + rbase + r;
-                const int xl = x - (int)(arm2 & 255u), xr = x + (int)((arm2 >> 8) & 255u);
-                const int b0 = xl >> 3, b1 = xr >> 3;
-                for (int bo = 0;; bo += 4) { // one iteration unless a row spans more than 4 blocks
-                    const int blk = b0 + bo + bslot;
-                    const bool use = rowok && blk <= b1;
-                    const size_t addr = use ? (size_t)yt * SP + (size_t)blk * 8 : own;
-                    const uint4 v = *reinterpret_cast<const uint4*>(st16 + addr); // loads stay unconditional
-                    if (use) {
-#pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            const int px = blk * 8 + q;
-                            const uint32_t wq = q < 2 ? v.x : (q < 4 ? v.y : (q < 6 ? v.z : v.w)); // (q is a constant after unrolling)
-                            const uint32_t s = (wq >> (16 * (q & 1))) & 0xffffu;
-                            const bool in = px >= xl && px <= xr;
-                            const bool el = (s & IRV_ELIG) != 0;
-                            const bool pre = yt < y || (yt == y && px < x); // precedes p in raster order
-                            const uint32_t bin = s & IRV_BIN_MASK;
+    const long B = 64L * NW;
+    int evals = 0;
+    for (long b0 = 0; b0 < n; b0 += B) {
+        const long i = b0 + (long)(lane * WPB + wave) * gridDim.x + blockIdx.x; // (irv_list_slot)
+        int4 ent = spec;
+        if (b0 != 0) {
+            ent = list[b0 + (size_t)gw * 64 + lane];
+            __syncthreads(); // the previous batch's pool has been consumed
+        }
+        uint32_t mystate = spec_state;
+        bool box = spec_box;
+        if (b0 != 0) {
+            const int p = ent.x, y = ent.w, x = p - y * W;
+            mystate = st16[(uint32_t)(y * SP + x)];
+            const int top = (int)(((uint32_t)ent.y >> 16) & 255u), ml = ent.z & 255, mr = (ent.z >> 8) & 255;
+            box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, adc_imin(W - 1, x + mr) / IRV_TILE,
+                                adc_imax(0, y - top) / IRV_TILE, y / IRV_TILE, want4);
+        }
+        const bool dirty = i < n && (round == 0 || box) && !(mystate & IRV_FINAL); // final values are never re-evaluated
+        IRV_T(2);
+        // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
+        // consumers find pool item t by a prefix sum over the (<= 16) counts
+        const unsigned long long dm = __ballot(dirty);
+        if (lane == 0) pcount[wave] = __popcll(dm);
+        if (dirty) pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)mystate, ent.w);
+        __syncthreads();
+        const int cnt_l = lane < WPB ? pcount[lane] : 0;
+        const int incl = irv_row_prefix(cnt_l); // inclusive prefix over the first 16 lanes
+        const int excl = incl - cnt_l;
+        const int total = __builtin_amdgcn_readlane(incl, 15);
+        IRV_T(3);
+        for (int t = wave; t < total; t += WPB) {
+            evals++;
+            const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
+            const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
+            const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
+            const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z); // (only this wave writes the entry in this round)
+            const int x = p - y * W;
+            for (int b = lane; b < D; b += 64) hist[b] = 0;
+            bool deps_open = false;
+            const int top = (int)(((uint32_t)armsp >> 16) & 255u), nrows = top + (int)((uint32_t)armsp >> 24) + 1; // region rows y-top .. y+bottom
+            const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            for (int rbase = 0; rbase < nrows; rbase += 64) {
+                // the H arms of (up to 64) region rows in ONE round trip (lane r holds row rbase + r), handed to the row
+                // slots with a shuffle
+                const int myr = rbase + lane;
+                uint32_t a2 = 0;
+                if (myr < nrows) a2 = arms32[(uint32_t)((y - top + myr) * W + x)];
+                IRV_T(4);
+                const int rend = adc_imin(nrows - rbase, 64);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int r0 = 0; r0 < rend; r0 += 16) {
+                    const int r = r0 + sub;
+                    const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
+                    const bool rowok = r < rend;
+                    const int yt = y - top + rbase + r;
+                    const int xl = x - (int)(arm2 & 255u), xr = x + (int)((arm2 >> 8) & 255u);
+                    const int b0x = xl >> 3, b1x = xr >> 3;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                    for (int bo = 0;; bo += 4) { // one iteration unless a row spans more than 4 blocks
+                        const int blk = b0x + bo + bslot;
+                        const bool use = rowok && blk <= b1x;
+                        const uint32_t addr = use ? (uint32_t)(yt * SP + blk * 8) : own;
+                        const uint4 v = *reinterpret_cast<const uint4*>(st16 + addr); // loads stay unconditional
+                        IRV_T(5);
+                        uint32_t okm = 0u, first = 0u;
+                        bool single = false;
+                        uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u;
+                        if (use) {
+                            // The 8 pixels of the block, decoded as packed halfwords (bit q of a mask = pixel blk * 8 + q).
+                            // Which pixels count, and do they all fall into ONE bin?
+                            const int px0 = blk * 8;
+                            const uint32_t inm = (((2u << adc_imin(xr - px0, 7)) - 1u) & ~((1u << adc_imax(xl - px0, 0)) - 1u)) & 0xffu;
+                            // pixels that precede p in raster order
+                            const uint32_t prem = yt < y ? 0xffu : (yt == y ? ((1u << adc_imax(0, adc_imin(x - px0, 8))) - 1u) : 0u);
+                            b0 = v.x & 0x07FF07FFu; b1 = v.y & 0x07FF07FFu; b2 = v.z & 0x07FF07FFu; b3 = v.w & 0x07FF07FFu; // bins
+                            const uint32_t elm = irv_gather8(v.x, v.y, v.z, v.w, 15);   // eligible
+                            const uint32_t finm = irv_gather8(v.x, v.y, v.z, v.w, 14);  // final
+                            // bin == 0x7FF (invalid / never counted): 0x7FF + 1 carries into bit 11 of the halfword
+                            const uint32_t invm = irv_gather8(b0 + 0x00010001u, b1 + 0x00010001u, b2 + 0x00010001u, b3 + 0x00010001u, 11);
                             // eligible pixels of this pass are visible only if they precede p (already processed by the
                             // sequential scan); otherwise they are still invalid
-                            if (in && bin != IRV_BIN_MASK && (!el || pre)) atomicAdd(&hist[bin], 1);
+                            okm = inm & ~invm & (~elm | prem);
                             // an eligible predecessor that is not final yet: this vote may still change
-                            if (in && el && pre && !(s & IRV_FINAL)) deps_open = true;
+                            deps_open = deps_open || (inm & elm & prem & ~finm) != 0u;
+                            if (okm != 0u) {
+                                const int q0 = __ffs((int)okm) - 1;
+                                const uint32_t wsel = q0 < 2 ? b0 : (q0 < 4 ? b1 : (q0 < 6 ? b2 : b3));
+                                first = (wsel >> (16 * (q0 & 1))) & IRV_BIN_MASK;
+                                const uint32_t f2 = first * 0x00010001u;
+                                // halfwords that differ from the first counted bin: (d + 0x7FF) carries into bit 11 iff d != 0
+                                const uint32_t difm = irv_gather8((b0 ^ f2) + 0x07FF07FFu, (b1 ^ f2) + 0x07FF07FFu, (b2 ^ f2) + 0x07FF07FFu,
+                                                                  (b3 ^ f2) + 0x07FF07FFu, 11);
+                                single = (difm & okm) == 0u;
+                            }
                         }
+                        if (okm != 0u) {
+                            // (same-address LDS atomics serialise: one per lane instead of eight.  Counting the dominant bin in
+                            // registers across the wave was measured too: slower, the extra wave reduction costs more.)
+                            if (single) atomicAdd(&hist[first], __popc(okm));
+                            else {
+#pragma clang loop unroll(disable)
+                                for (uint32_t m = okm; m != 0u; m &= m - 1u) {
+                                    const int q = __ffs((int)m) - 1;
+                                    const uint32_t wq = q < 2 ? b0 : (q < 4 ? b1 : (q < 6 ? b2 : b3));
+                                    atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
+                                }
+                            }
+                        }
+                        if (!__any(rowok && (b0x + bo + 4 <= b1x))) break;
                     }
-                    if (!__any(rowok && (b0 + bo + 4 <= b1))) break;
+                }
+            }
+            IRV_T(6);
+            // first maximum (lowest bin on ties) and total count (multistep_refiner.cpp:199-209): key = count << 11 | (2047 - bin)
+            int key = 0, cnt = 0;
+            for (int b = lane; b < D; b += 64) {
+                const int hv = hist[b];
+                cnt += hv;
+                key = adc_imax(key, hv > 0 ? ((hv << 11) | (0x7FF - b)) : 0);
+            }
+            key = irv_wave_max(key);
+            cnt = irv_wave_sum(cnt);
+            const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
+            const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
+            const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
+            IRV_T(7);
+            if (lane == 0) {
+                const uint32_t i16 = (uint32_t)(y * SP + x);
+                const uint32_t nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
+                const uint32_t ns = nb | IRV_ELIG | (all_final ? IRV_FINAL : 0u);
+                if (ns != cur) st16[i16] = (uint16_t)ns; // value and final bit in ONE store
+                if (nb != (cur & IRV_BIN_MASK)) {
+                    chg_wr[(uint32_t)((y / IRV_TILE) * tpitch + x / IRV_TILE)] = (uint8_t)stamp;
+                    *acc = 1;
                 }
             }
         }
-        // first maximum (lowest bin on ties) and total count (multistep_refiner.cpp:199-209)
-        int bh = 0, bbin = 0x7fffffff, cnt = 0;
-        for (int b = lane; b < D; b += 64) {
-            const int hv = hist[b];
-            cnt += hv;
-            if (hv > bh) { bh = hv; bbin = b; }
-        }
-#pragma unroll
-        for (int mk = 32; mk >= 1; mk >>= 1) {
-            const int oh = __shfl_xor(bh, mk, 64), ob = __shfl_xor(bbin, mk, 64);
-            cnt += __shfl_xor(cnt, mk, 64);
-            const bool take = (oh > bh) || (oh == bh && ob < bbin);
-            bh = take ? oh : bh;
-            bbin = take ? ob : bbin;
-        }
-        const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-        const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
-        if (lane == 0) {
-            const size_t i16 = (size_t)y * SP + x;
-            const uint32_t nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
-            const uint32_t ns = nb | IRV_ELIG | (all_final ? IRV_FINAL : 0u);
-            if (ns != cur) st16[i16] = (uint16_t)ns; // value and final bit in ONE store
-            if (nb != (cur & IRV_BIN_MASK)) {
-                chg[(size_t)(y / IRV_TILE) * tpitch + x / IRV_TILE] = (uint8_t)stamp;
-                *acc = 1;
-            }
-        }
     }
+    if (lane == 0 && evals) evals_arr[gw] += evals;
+    IRV_TR(9);
 }
 
 // --------------------------------------------------------------------------------------------------------- host side
@@ -322,25 +452,39 @@ static int irv_min_region(const adc_handle* h)
     const int Lmax = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
     return Lmax <= 127 ? h->p.opt.irv_ts : -1; // u16 support counts cannot wrap for L <= 127
 }
-static hipError_t irv_launch_pair(adc_handle* h, int k0, int npairs)
+// Launch shape of the chain: IRV_WPB waves per workgroup (16 unless the histograms + pool would not fit into 64 KB of
+// LDS), ADC_IRV_GRID workgroups (default: two per CU of an MI355X).
+static unsigned irv_grid()
+{
+    static const unsigned g = [] { const char* e = getenv("ADC_IRV_GRID"); const int v = e ? atoi(e) : 512; return (unsigned)(v > 0 ? v : 512); }();
+    return g;
+}
+static int irv_wpb(int D)
+{
+    static const int wmax = [] { const char* e = getenv("ADC_IRV_WPB"); const int v = e ? atoi(e) : IRV_MAXW; return v >= 1 && v <= IRV_MAXW ? v : IRV_MAXW; }();
+    int w = 1;
+    while (2 * w <= wmax) w *= 2;
+    while (w > 1 && (size_t)w * D * 4 + (size_t)w * 64 * 16 > 60 * 1024) w >>= 1;
+    return w;
+}
+size_t adc_irv_waves() { return (size_t)IRV_MAXW * irv_grid(); } // (upper bound over all block shapes)
+// entries the work list must hold: whole batches of 64 entries per wave of the chain's grid (irv_list_slot)
+size_t adc_irv_list_entries(size_t pixels, int D)
+{
+    const size_t B = (size_t)64 * irv_wpb(D) * irv_grid();
+    return ((pixels + B - 1) / B) * B;
+}
+static hipError_t irv_launch(adc_handle* h, int k0, int count)
 {
     const AdcParams& p = h->p;
-    const int P = p.W * p.H;
     const int tpitch = h->chg_pitch, chg_bytes = tpitch * ((p.H + IRV_TILE - 1) / IRV_TILE);
-    const unsigned ga = (unsigned)adc_imax(1, adc_imin((P + 256 * IRV_PPT - 1) / (256 * IRV_PPT), 1024));
-    static const unsigned gb = [] { const char* e = getenv("ADC_IRV_GRID"); const int v = e ? atoi(e) : 2048; return (unsigned)(v > 0 ? v : 2048); }();
-    uint8_t* chg = h->chg_a;
-    int2* list = reinterpret_cast<int2*>(h->vote_list);
-    int2* dlist = reinterpret_cast<int2*>(h->vote_dirty);
-    for (int i = 0; i < npairs; i++) {
-        const int k = k0 + 2 * i;
-        hipLaunchKernelGGL(k_irv_a, dim3(ga), dim3(256), 0, h->stream, h->vote_counters, k, h->label, h->disp_vote, h->disp_l, h->sup_h, h->st16,
-                           list, dlist, chg, reinterpret_cast<const uchar4*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H,
-                           h->st16_pitch, p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch);
-        hipLaunchKernelGGL(k_irv_b, dim3(gb), dim3(256), (size_t)4 * p.D * sizeof(int), h->stream, h->vote_counters, k + 1, list, dlist,
-                           h->st16, reinterpret_cast<const uchar4*>(h->arms), chg, p.W, p.H, h->st16_pitch, p.dmin, p.D, p.opt.irv_ts,
-                           p.opt.irv_th, tpitch, P);
-    }
+    const int wpb = irv_wpb(p.D);
+    const size_t lds = (size_t)wpb * p.D * 4 + (size_t)wpb * 64 * 16;
+    for (int i = 0; i < count; i++)
+        hipLaunchKernelGGL(k_irv_u, dim3(irv_grid()), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
+                           h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
+                           reinterpret_cast<const uchar4*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
+                           p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr);
     return hipGetLastError();
 }
 
@@ -353,10 +497,10 @@ hipError_t adc_run_region_voting(adc_handle* h)
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     hipLaunchKernelGGL(k_irv_bbox, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms),
                        reinterpret_cast<uchar4*>(h->irv_bbox), p.W, p.H);
-    if ((e = hipMemsetAsync(h->vote_counters, 0, 160 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(h->vote_counters, 0, IRV_CTRL_INTS * sizeof(int32_t), h->stream)) != hipSuccess) return e;
     if (h->irv_budget < 4) h->irv_budget = 4;
-    if ((e = irv_launch_pair(h, 0, h->irv_budget)) != hipSuccess) return e;
-    h->irv_chain = 2 * h->irv_budget;
+    if ((e = irv_launch(h, 0, h->irv_budget)) != hipSuccess) return e;
+    h->irv_chain = h->irv_budget;
     // the state the last kernel published (slot chain & 1), read by adc_wait / adc_voting_finish
     if (h->pin_flags)
         e = hipMemcpyAsync(h->pin_flags + 16, h->vote_counters + 16 * (h->irv_chain & 1), 8 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
@@ -364,7 +508,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
     return e;
 }
 
-// After the stream has drained: did the chain reach DONE?  If not, continue it synchronously (batches of 32 rounds) until
+// After the stream has drained: did the chain reach DONE?  If not, continue it synchronously (batches of 64 kernels) until
 // it does, and copy the result to disp_l.  Adapts the budget of the next Match.  *continued = 1 when the stages behind
 // the voting have to be redone.
 hipError_t adc_voting_finish(adc_handle* h, int* continued)
@@ -377,7 +521,7 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     int guard = 0;
     while (st[0] != IRV_DONE) {
         *continued = 1;
-        if ((e = irv_launch_pair(h, h->irv_chain, 32)) != hipSuccess) return e;
+        if ((e = irv_launch(h, h->irv_chain, 64)) != hipSuccess) return e;
         h->irv_chain += 64;
         if ((e = hipMemcpyAsync(st, h->vote_counters + 16 * (h->irv_chain & 1), 8 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
@@ -386,10 +530,10 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     h->vote_rounds = st[5];
     h->vote_evals = st[6];
     if (*continued) h->irv_overflows++; // (the FINAL kernel of the continued chain has written the result into disp_l)
-    // budget of the next Match: the kernel pairs this one actually needed (st[7] = index of the first kernel that found
-    // nothing left to do) + 12 % + 2
-    const int used = (st[7] + 2) / 2;
+    // budget of the next Match: the kernels this one actually needed (st[7] = index of the first kernel that found
+    // nothing left to do) + 12 % + 4
+    const int used = st[7] + 1;
     static const int fixed = [] { const char* ev = getenv("ADC_IRV_BUDGET"); return ev ? atoi(ev) : 0; }();
-    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 15, used + used / 8 + 2);
+    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, used + used / 8 + 4);
     return hipSuccess;
 }

@@ -1,7 +1,8 @@
 // CPU model of the device-driven region-voting chain (adcensus_amd/csrc/k_voting.hip): the SAME state machine
-// (irv_plan.h: every kernel derives its action from the state and the accumulator its predecessor left) drives plain-loop
-// versions of the kernels' phases on the same 16-bit state map (bin | final | eligible), with the votes of a round
-// evaluated in a shuffled order against the in-place map (arbitrary wave scheduling).  Test infrastructure.
+// (irv_plan.h: every kernel derives its action from the state and the accumulators its predecessor left) and the SAME
+// work-list layout (irv_list_slot) drive plain-loop versions of the kernel's phases on the same 16-bit state map
+// (bin | final | eligible) and the two change-tile planes, with the waves of a round visited in a shuffled order against
+// the in-place map (arbitrary scheduling).  Test infrastructure.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -10,12 +11,17 @@
 #include "../../adcensus_amd/csrc/irv_plan.h"
 
 extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
-                               int D, int irv_ts, float irv_th, int min_region, unsigned seed, int budget_pairs, long* out_stats)
+                               int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats)
 {
     const int P = W * H, SP = (W + 7) & ~7, T = IRV_TILE;
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+    const int G = groups > 0 ? groups : 2, WPB = wpb > 0 ? wpb : 4, NW = G * WPB; // the (emulated) grid: decides the list layout (irv_list_slot)
+    const long B = 64L * NW, cap = ((P + B - 1) / B) * B;
+    struct Ent { int p, arms, mlmr, y; };
     std::vector<uint16_t> st((size_t)SP * H + 64, 0xFFFF);
-    std::vector<int32_t> ctrl(160, 0), list(P), dlist(P), chg(tiles_x * tiles_y, 0), hist(D);
+    std::vector<int32_t> ctrl(IRV_CTRL_INTS, 0), hist(D);
+    std::vector<int32_t> chg(2 * (size_t)tiles_x * tiles_y, 0); // two planes (round parity)
+    std::vector<Ent> list(cap, Ent{0, 0, 0, 0});
     std::vector<uint8_t> bb((size_t)P * 3);
     for (int y = 0; y < H; y++)
         for (int x = 0; x < W; x++) {
@@ -30,20 +36,25 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
             o[0] = a[2]; o[1] = (uint8_t)ml; o[2] = (uint8_t)mr;
         }
     srand(seed);
-    long kernels = 0;
+    long kernels = 0, total_evals = 0;
     const int32_t* fin = nullptr;
-    (void)budget_pairs;
     for (int k = 0;; k++) {
         if (ctrl[16 * (k & 1)] == IRV_DONE) { fin = &ctrl[16 * (k & 1)]; break; } // the state the previous kernel published
         const IrvPlan pl = irv_plan(ctrl.data(), k);
         int32_t* acc = &ctrl[IRV_ACC + (k & 63)];
         kernels++;
-        if ((k & 1) == 0) { // kernel A
-            if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
-                const bool have_state = !(pl.act == IRV_BEGIN && pl.s.pass == 0);
-                const int which = (pl.s.pass & 1) ? ADC_LABEL_OCCLUSION : ADC_LABEL_MISMATCH;
-                if (pl.act == IRV_BEGIN) std::fill(chg.begin(), chg.end(), 0);
-                for (int p = 0; p < P; p++) {
+        if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
+            const bool have_state = !(pl.act == IRV_BEGIN && pl.s.pass == 0);
+            const int which = (pl.s.pass & 1) ? ADC_LABEL_OCCLUSION : ADC_LABEL_MISMATCH;
+            if (pl.act == IRV_BEGIN) std::fill(chg.begin(), chg.end(), 0);
+            // the blocks of the kernel claim list ranges with an atomic in arbitrary order: model it by visiting the
+            // chunks of pixels (one per workgroup iteration) in a shuffled order
+            const int CH = 1024 * IRV_PPT;
+            std::vector<int> chunks((P + CH - 1) / CH);
+            for (size_t c = 0; c < chunks.size(); c++) chunks[c] = (int)c;
+            for (size_t c = chunks.size(); c > 1; c--) std::swap(chunks[c - 1], chunks[rand() % c]);
+            for (int c : chunks)
+                for (int p = c * CH; p < std::min(P, (c + 1) * CH); p++) {
                     const int y = p / W, x = p - y * W;
                     const size_t i16 = (size_t)y * SP + x;
                     float dv = disp[p];
@@ -57,51 +68,76 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
                         uint32_t bin = IRV_BIN_MASK;
                         if (dv != ADC_INVALID_FLOAT) { const long b = lroundf(dv) - dmin; if (b >= 0 && b < D) bin = (uint32_t)b; }
                         st[i16] = (uint16_t)(bin | (e ? IRV_ELIG : 0u) | (listed ? 0u : IRV_FINAL));
-                        if (listed) list[(*acc)++] = p;
+                        if (listed) {
+                            const uint8_t* o = &bb[(size_t)p * 3];
+                            const uint8_t* a = arms + (size_t)p * 4;
+                            const int arms32 = (int)((uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)a[2] << 16) | ((uint32_t)a[3] << 24));
+                            list[irv_list_slot((*acc)++, G, WPB)] = Ent{p, arms32, (int)o[1] | ((int)o[2] << 8), y};
+                        }
                     }
                 }
-            } else if (pl.act == IRV_CHECK) {
-                for (int i = 0; i < pl.nwork; i++) {
-                    const int p = list[i], y = p / W, x = p - y * W;
-                    if (st[(size_t)y * SP + x] & IRV_FINAL) continue;
-                    const uint8_t* o = &bb[(size_t)p * 3];
-                    const int tx0 = std::max(0, x - (int)o[1]) / T, tx1 = std::min(W - 1, x + (int)o[2]) / T;
-                    const int ty0 = std::max(0, y - (int)o[0]) / T, ty1 = y / T;
-                    bool dirty = false;
-                    for (int ty = ty0; ty <= ty1; ty++)
-                        for (int tx = tx0; tx <= tx1; tx++) dirty |= chg[ty * tiles_x + tx] == ((pl.s.round - 1) % 255) + 1; // byte stamps (k_voting.hip)
-                    if (dirty) dlist[(*acc)++] = p;
-                }
-            }
-        } else if (pl.act == IRV_VOTE) { // kernel B
-            std::vector<int32_t> work(pl.s.round == 0 ? list.begin() : dlist.begin(), (pl.s.round == 0 ? list.begin() : dlist.begin()) + pl.nwork);
-            for (size_t i = work.size(); i > 1; i--) std::swap(work[i - 1], work[rand() % i]);
-            for (int p : work) {
-                const int y = p / W, x = p - y * W;
-                std::fill(hist.begin(), hist.end(), 0);
-                bool deps_open = false;
-                const uint8_t* arm = arms + (size_t)p * 4;
-                for (int t = -(int)arm[2]; t <= (int)arm[3]; t++) {
-                    const int yt = y + t;
-                    const uint8_t* a2 = arms + ((size_t)yt * W + x) * 4;
-                    for (int px = x - (int)a2[0]; px <= x + (int)a2[1]; px++) {
-                        const uint32_t s = st[(size_t)yt * SP + px];
-                        const bool el = (s & IRV_ELIG) != 0, pre = yt < y || (yt == y && px < x);
-                        const uint32_t bin = s & IRV_BIN_MASK;
-                        if (bin != IRV_BIN_MASK && (!el || pre)) hist[bin]++;
-                        if (el && pre && !(s & IRV_FINAL)) deps_open = true;
+        } else if (pl.act == IRV_ROUND) {
+            // every wave: phase 1 (one entry per lane: open and dirty?), phase 2 (evaluate the dirty ones); waves in a
+            // shuffled order against the in-place map (arbitrary scheduling)
+            const int round = pl.s.round, n = pl.s.n;
+            const int32_t want = ((k + 254) % 255) + 1, stamp = (k % 255) + 1; // stamps and planes go by KERNEL index
+            const int32_t* chg_rd = chg.data() + (size_t)((k + 1) & 1) * tiles_x * tiles_y;
+            int32_t* chg_wr = chg.data() + (size_t)(k & 1) * tiles_x * tiles_y;
+            std::vector<int> waves(NW);
+            for (int w = 0; w < NW; w++) waves[w] = w;
+            for (int w = NW; w > 1; w--) std::swap(waves[w - 1], waves[rand() % w]);
+            for (long b0 = 0; b0 < n; b0 += B)
+                for (int gw : waves) {
+                    int todo[64], nt = 0;
+                    for (int lane = 0; lane < 64; lane++) {
+                        const long i = b0 + (long)(lane * WPB + gw % WPB) * G + gw / WPB;
+                        if (i >= n) continue;
+                        const Ent& e = list[b0 + (size_t)gw * 64 + lane];
+                        const int p = e.p, y = e.y, x = p - y * W;
+                        if (st[(size_t)y * SP + x] & IRV_FINAL) continue;
+                        bool dirty = round == 0;
+                        if (!dirty) {
+                            const int top = (e.arms >> 16) & 255, ml = e.mlmr & 255, mr = (e.mlmr >> 8) & 255;
+                            const int tx0 = std::max(0, x - ml) / T, tx1 = std::min(W - 1, x + mr) / T;
+                            const int ty0 = std::max(0, y - top) / T, ty1 = y / T;
+                            for (int ty = ty0; ty <= ty1; ty++)
+                                for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want; // byte stamps (k_voting.hip)
+                        }
+                        if (dirty) todo[nt++] = lane;
+                    }
+                    total_evals += nt;
+                    for (int t = 0; t < nt; t++) {
+                        const Ent& e = list[b0 + (size_t)gw * 64 + todo[t]];
+                        const int p = e.p, y = e.y, x = p - y * W;
+                        std::fill(hist.begin(), hist.end(), 0);
+                        bool deps_open = false;
+                        const uint8_t* arm = arms + (size_t)p * 4;
+                        for (int dy = -(int)arm[2]; dy <= (int)arm[3]; dy++) {
+                            const int yt = y + dy;
+                            const uint8_t* a2 = arms + ((size_t)yt * W + x) * 4;
+                            for (int px = x - (int)a2[0]; px <= x + (int)a2[1]; px++) {
+                                const uint32_t s = st[(size_t)yt * SP + px];
+                                const bool el = (s & IRV_ELIG) != 0, pre = yt < y || (yt == y && px < x);
+                                const uint32_t bin = s & IRV_BIN_MASK;
+                                if (bin != IRV_BIN_MASK && (!el || pre)) hist[bin]++;
+                                if (el && pre && !(s & IRV_FINAL)) deps_open = true;
+                            }
+                        }
+                        // the kernel's key: count << 11 | (2047 - bin), maximum = highest count, lowest bin on ties
+                        int key = 0, cnt = 0;
+                        for (int b = 0; b < D; b++) { cnt += hist[b]; if (hist[b] > 0) key = std::max(key, (hist[b] << 11) | (0x7FF - b)); }
+                        const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
+                        const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
+                        const size_t i16 = (size_t)y * SP + x;
+                        const uint32_t cur = st[i16], nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
+                        st[i16] = (uint16_t)(nb | IRV_ELIG | (deps_open ? 0u : IRV_FINAL));
+                        if (nb != (cur & IRV_BIN_MASK)) { chg_wr[(y / T) * tiles_x + x / T] = stamp; *acc = 1; }
                     }
                 }
-                int bh = 0, bbin = 0x7fffffff, cnt = 0;
-                for (int b = 0; b < D; b++) { cnt += hist[b]; if (hist[b] > bh) { bh = hist[b]; bbin = b; } }
-                const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-                const size_t i16 = (size_t)y * SP + x;
-                const uint32_t cur = st[i16], nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
-                st[i16] = (uint16_t)(nb | IRV_ELIG | (deps_open ? 0u : IRV_FINAL));
-                if (nb != (cur & IRV_BIN_MASK)) { chg[(y / T) * tiles_x + x / T] = (pl.s.round % 255) + 1; *acc = 1; }
-            }
         }
-        irv_publish(ctrl.data(), k, pl.s);
+        IrvState ps = pl.s;
+        if (pl.act == IRV_FINAL_WB) ps.evals = (int)total_evals; // (summed from the per-wave counters by the kernel)
+        irv_publish(ctrl.data(), k, ps);
         if (kernels > 4000000) return -1;
     }
     if (out_stats) { out_stats[0] = fin[5]; out_stats[1] = fin[6]; out_stats[2] = kernels; }

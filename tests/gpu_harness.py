@@ -108,10 +108,10 @@ def stage_report(left, right, opt, o, device=0):
                 st.debug_run(A.RUN_REGION_VOTING)
                 rec("disp_after_irv", st.debug_read(A.BUF_DISP_LEFT), o["disp_after_irv"])
                 rep["disp_after_irv"]["voting_rounds_evals"] = st.voting_stats()
-                # the same with a launch budget of two kernel pairs: the chain stops early and is continued by the host
+                # the same with a launch budget of four kernels: the chain stops early and is continued by the host
                 before = st.debug_counter(1)
                 st.debug_write(A.BUF_DISP_LEFT, o["disp_after_lr"])
-                st.debug_run(A.RUN_REGION_VOTING, 2)
+                st.debug_run(A.RUN_REGION_VOTING, 4)
                 rec("disp_after_irv(chain continued)", st.debug_read(A.BUF_DISP_LEFT), o["disp_after_irv"])
                 if st.voting_stats()[0] > 2:
                     assert st.debug_counter(1) == before + 1, "the continuation path was not taken"

@@ -216,12 +216,13 @@ def test_refiner_parallel_forms(emul, dumps, name):
         assert same(d, o["disp_after_irv"])
     # the device-driven chain (k_voting.hip): state machine of irv_plan.h on the 16-bit state map, shuffled vote order
     emul.emul_irv_chain.restype = C.c_long
-    for seed in (3, 77):
+    # (the grid decides the work-list layout; 2 x 4 and 5 x 1 waves = batches of 512 / 320 entries: lists span several batches)
+    for seed, groups, wpb in ((3, 2, 4), (77, 5, 1)):
         d = o["disp_after_lr"].copy()
         stats = (C.c_long * 3)()
         L = max(0, min(opt.cross_L1, 255))
         rounds = emul.emul_irv_chain(P(d), P(o["outlier_label"]), P(o["arms"]), P(o["sup_count_h"]), w, h, dmin, D, opt.irv_ts,
-                                     C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, 0, stats)
+                                     C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, groups, wpb, stats)
         assert rounds >= 0, rounds
         assert same(d, o["disp_after_irv"])
     a, b = o["disp_after_irv"].copy(), np.empty((h, w), np.float32)

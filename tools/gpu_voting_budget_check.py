@@ -8,7 +8,7 @@ w, h, d = 200, 150, 32
 left, right = workloads.structured_pair(w, h, d, seed=5)
 opt = pyoracle.Option(max_disparity=d)
 o = pyoracle.load("auto").run(left, right, opt)
-for budget in (400, 48, 2):
+for budget in (800, 96, 4):
     st = A.ADCensusStereo(device=0)
     assert st.Initialize(w, h, cases.to_product_option(opt))
     st.debug_set_images(left, right)
