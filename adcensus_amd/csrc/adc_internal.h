@@ -104,6 +104,8 @@ struct adc_handle {
     uint8_t* chg_a;      // change-tile map of the voting rounds: one byte stamp per 8x8 tile, row pitch chg_pitch
     int chg_pitch;
     uint8_t* edge;       // discontinuity adjustment edge mask
+    uint8_t* itp_cells;  // interpolation: 3 byte maps of 2x2-pixel cells (cell has a valid pixel / row distance / Chebyshev distance
+                         // in cells to the nearest cell with a valid pixel): empty-space skipping of the ray walk (k_refine.hip)
     // pinned staging for adc_match / adc_match_async
     uint8_t* pin_in;  // 2 * 3*W*H
     float* pin_out;   // W*H

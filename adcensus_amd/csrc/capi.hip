@@ -106,6 +106,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->vote_evals_arr, adc_irv_waves() * sizeof(int32_t)));
     HIP_OK(hipMalloc(&h->interp_list, P * 4));
     HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&h->itp_cells, 3 * (size_t)((p.W + 1) / 2) * ((p.H + 1) / 2) + 64)); // 2x2 cells (ITP_CELL, k_refine.hip)
     h->st16_pitch = (p.W + 7) & ~7;
     HIP_OK(hipMalloc(&h->st16, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t)));
     HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin
@@ -248,7 +249,7 @@ void adc_destroy(adc_handle* h)
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->st16, h->disp_vote, h->vote_counters,
+                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
                     h->chg_a, h->edge};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
@@ -418,7 +419,6 @@ int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, voi
 {
     if (!h || !d_left || !d_right || !d_disp) return 1; // ADCensusStereo.cpp:71-76
     hipSetDevice(h->device);
-    const size_t P = (size_t)h->p.W * h->p.H;
     // the caller's device images are BORROWED until adc_wait returns (like the reference borrows the host pointers for the
     // duration of Match, ADCensusStereo.cpp:78-79): no copy
     h->img_l = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_left));
