@@ -165,6 +165,20 @@ def test_pair_farm_host_buffers(hip, oracle):
     farm.close()
 
 
+def test_voting_chain_launch_shapes(hip, oracle):
+    """The voting chain's work-list layout depends on its launch shape (workgroups x waves, irv_plan.h: irv_list_slot).  Tiny
+    shapes make the list span many batches of 64 x waves entries and leave one wave per pool -- paths the default shape
+    (512 x 16) never takes below ~500 k list entries.  The shape is read once per process: subprocess."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for grid, wpb in ((3, 2), (1, 1), (7, 16)):
+        env = dict(os.environ, ADC_IRV_GRID=str(grid), ADC_IRV_WPB=str(wpb))
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_voting_budget_check.py")], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (grid, wpb, r.stdout[-2000:], r.stderr[-2000:])
+        assert r.stdout.count("bad 0 ") == 3, r.stdout
+
+
 def test_aggregation_fast_path_equals_direct(hip, oracle, monkeypatch):
     """A/B: the marching-ring kernel and the one-thread-per-element direct kernel agree bit-for-bit."""
     A = hip

@@ -1,3 +1,7 @@
+"""Region-voting chain on one structured case against the oracle, for three launch budgets (the smallest forces the host-side
+continuation).  The launch shape comes from the environment (ADC_IRV_GRID workgroups x ADC_IRV_WPB waves): small shapes make
+the work list span several batches (tests/test_gpu_api.py runs this script in a subprocess because the shape is read once
+per process).  Exit code 1 on any difference."""
 import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 import adcensus_amd as A
@@ -20,5 +24,7 @@ for budget in (800, 96, 4):
     bad = int((got.view(np.uint32) != o["disp_after_irv"].view(np.uint32)).sum())
     filled_ref = int((np.isinf(o["disp_after_lr"]) & ~np.isinf(o["disp_after_irv"])).sum())
     filled_got = int((np.isinf(o["disp_after_lr"]) & ~np.isinf(got)).sum())
+    worst = max(globals().get("worst", 0), bad + abs(filled_ref - filled_got))
     print("budget", budget, "bad", bad, "filled ref/got", filled_ref, filled_got, "stats(rounds,evals)", st.voting_stats(), "overflows", st.debug_counter(1), "next budget", st.debug_counter(3), flush=True)
     st.Release()
+sys.exit(1 if worst else 0)
