@@ -139,6 +139,7 @@ size_t adc_so_cls_bytes(int W, int H);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_lrcheck(adc_handle* h);
+size_t adc_itp_cell_bytes(int W, int H);       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
 size_t adc_irv_waves();                        // waves of the voting chain's grid
 size_t adc_irv_list_entries(size_t pixels, int D);    // capacity of the voting work list (whole batches)
 hipError_t adc_run_region_voting(adc_handle* h); // enqueue only (device-driven chain with a launch budget)

@@ -106,7 +106,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->vote_evals_arr, adc_irv_waves() * sizeof(int32_t)));
     HIP_OK(hipMalloc(&h->interp_list, P * 4));
     HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));
-    HIP_OK(hipMalloc(&h->itp_cells, 3 * (size_t)((p.W + 1) / 2) * ((p.H + 1) / 2) + 64)); // 2x2 cells (ITP_CELL, k_refine.hip)
+    HIP_OK(hipMalloc(&h->itp_cells, adc_itp_cell_bytes(p.W, p.H)));
     h->st16_pitch = (p.W + 7) & ~7;
     HIP_OK(hipMalloc(&h->st16, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t)));
     HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin

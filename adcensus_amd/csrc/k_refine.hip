@@ -282,6 +282,7 @@ __device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_di
 // invalid (or outside the image, where the ray ends anyway) are passed over.
 #define ITP_CELL 2
 #define ITP_CAP 16
+size_t adc_itp_cell_bytes(int W, int H) { return 3 * (size_t)((W + ITP_CELL - 1) / ITP_CELL) * ((H + ITP_CELL - 1) / ITP_CELL) + 64; } // cell / row / distance maps
 __global__ __launch_bounds__(256) void k_itp_cells(const float* __restrict__ disp, uint8_t* __restrict__ cell, int W, int H, int cw, int ch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
