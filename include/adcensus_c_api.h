@@ -203,8 +203,10 @@ enum {
  * production form whose last pass also writes DISP_LEFT (the fused left-view winner-takes-all);
  * ADC_RUN_MEDIAN: 100 = do not run, arm the fallback path of the next adc_wait; else ignored). */
 int adc_debug_run(adc_handle* h, int stage, int arg);
-/* Test-only event counters: which = 0 -> number of times adc_wait had to redo the median filter
- * with the single-workgroup kernel (hand-off time-out of the banded kernel). */
+/* Test-only event counters of the handle: which = 0 -> number of times adc_wait had to redo the median filter with the
+ * single-workgroup kernel (hand-off time-out of the banded kernel); 1 -> continuations of the voting chain (launch budget
+ * too small); 2 -> aggregation redos (assumed ring depth too small); 3 -> launch budget (kernels) of the next Match's
+ * voting chain.  ADC_RUN_REGION_VOTING of adc_debug_run takes the budget of that run as `arg` (0 = keep). */
 int64_t adc_debug_counter(adc_handle* h, int which);
 /* Statistics of the last region-voting run: total fixed-point rounds over the 10 passes and
  * total vote evaluations. */
