@@ -217,6 +217,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     tensor_device = "cpu"
+    backend = None
     if world > 1 or os.environ.get("ADC_BENCH_FORCE_DIST") == "1":  # (FORCE_DIST: exercise the RCCL calls with one rank)
         # torch first: its bundled HIP runtime (same SONAME) is then shared by the C-ABI library
         import torch
@@ -228,9 +229,24 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("ADC_BENCH_BACKEND", "nccl")  # "gloo": test hook (several ranks on one GPU)
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            tensor_device = "cuda"
+            # RCCL carries a barrier, two scalar all-reduces and one all-gather of digests: nothing of the data path.  If
+            # the communicator cannot be created on this node, the same four calls run over gloo instead of failing the job
+            try:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == int(os.environ["WORLD_SIZE"])
+                tensor_device = "cuda"
+            except Exception as exc:  # noqa: BLE001
+                print("bench.py: RCCL initialisation failed (%s: %s); falling back to gloo" % (type(exc).__name__, exc), file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = "gloo (RCCL failed)"
+                dist.init_process_group(backend="gloo")
         else:
             local_rank = int(os.environ.get("ADC_BENCH_DEVICE", local_rank))
             dist.init_process_group(backend=backend)
@@ -292,7 +308,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d D=%d%s" % (a.workload, W, H, D, sizes.get((W, H, D), "")),
                        "batch": "%d distinct pairs (seeds 12345+i), %d per GPU" % (batch, a.steps),
-                       "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs, round-robin partition)" % world},
+                       "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs, round-robin partition)" % world,
+                       "comm_backend": (backend if dist is not None else None)},
             "farm_check": check,
             "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
             "stage_ms": stage,
