@@ -121,6 +121,35 @@ ADC_HD void adc_so_class_offsets_interior(const uint32_t* rb, int c1byte, int ts
     }
 }
 
+// ---- interpolation: empty-space skipping of the ray walk (k_refine.hip; CPU emulation: tests/emul/emul.cpp) ----
+// cdist[cell] = a LOWER BOUND of the Chebyshev distance, in cells of ADC_ITP_CELL x ADC_ITP_CELL pixels, from the cell to
+// the nearest cell that holds a valid pixel (0 = the cell itself; search window +-ADC_ITP_CAP cells, ADC_ITP_CAP + 1 =
+// "further").  A ray standing in a cell with cdist = c >= 2 cannot meet a valid pixel during its next
+// (c - 1) * ADC_ITP_CELL - 1 steps: a step moves at most one pixel per axis (+1 for the rounding of lround(m * sin)).
+#define ADC_ITP_CELL 2
+#define ADC_ITP_CAP 16
+ADC_HD int adc_itp_skip(int c) { return c >= 2 ? (c - 1) * ADC_ITP_CELL - 1 : 0; }
+// distance (cells) to the nearest non-empty cell of the same cell row, within the window
+ADC_HD int adc_itp_rowdist(const uint8_t* cell, int cw, int cx, int cy)
+{
+    int best = ADC_ITP_CAP + 1;
+    for (int dx = -ADC_ITP_CAP; dx <= ADC_ITP_CAP; dx++) {
+        const int x = cx + dx;
+        if (x >= 0 && x < cw && cell[cy * cw + x]) best = adc_imin(best, adc_iabs(dx));
+    }
+    return best;
+}
+// Chebyshev combination over the cell rows of the window: min over dy of max(rowdist(cx, cy + dy), |dy|)
+ADC_HD int adc_itp_coldist(const uint8_t* rowd, int cw, int ch, int cx, int cy)
+{
+    int best = ADC_ITP_CAP + 1;
+    for (int dy = -ADC_ITP_CAP; dy <= ADC_ITP_CAP; dy++) {
+        const int y = cy + dy;
+        if (y >= 0 && y < ch) best = adc_imin(best, adc_imax((int)rowd[y * cw + cx], adc_iabs(dy)));
+    }
+    return best;
+}
+
 // ---- WTA sub-pixel (ADCensusStereo.cpp:227-240) ----
 ADC_HD float adc_subpixel(int best, float c1, float c2, float cmin)
 {

@@ -276,12 +276,11 @@ __device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_di
 // Empty-space skipping.  Most of the walk's steps are spent where there is next to nothing to find: in the band of columns
 // x < D of the left view 99.7 % of the pixels are invalid, and 70 % of all ray steps of a noise pair are taken inside it
 // (~90 per ray against ~8 elsewhere).  cdist[cell] = a LOWER BOUND of the Chebyshev distance, in cells of 2x2 pixels, from
-// the cell to the nearest cell that holds a valid pixel (0 = the cell itself, search window +-ITP_CAP cells, ITP_CAP + 1 =
+// the cell to the nearest cell that holds a valid pixel (0 = the cell itself, search window +-ADC_ITP_CAP cells, ADC_ITP_CAP + 1 =
 // "further").  A ray standing in a cell with cdist = c >= 2 cannot meet a valid pixel during its next (c - 1) * 2 - 1 steps
 // -- a step moves at most one pixel per axis (+1 for the rounding) -- so they are skipped.  Exact: only pixels proven
 // invalid (or outside the image, where the ray ends anyway) are passed over.
-#define ITP_CELL 2
-#define ITP_CAP 16
+#define ITP_CELL ADC_ITP_CELL
 size_t adc_itp_cell_bytes(int W, int H) { return 3 * (size_t)((W + ITP_CELL - 1) / ITP_CELL) * ((H + ITP_CELL - 1) / ITP_CELL) + 64; } // cell / row / distance maps
 __global__ __launch_bounds__(256) void k_itp_cells(const float* __restrict__ disp, uint8_t* __restrict__ cell, int W, int H, int cw, int ch)
 {
@@ -302,25 +301,13 @@ __global__ __launch_bounds__(256) void k_itp_rowdist(const uint8_t* __restrict__
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cw * ch) return;
-    const int cy = c / cw, cx = c - cy * cw;
-    int best = ITP_CAP + 1;
-    for (int dx = -ITP_CAP; dx <= ITP_CAP; dx++) {
-        const int x = cx + dx;
-        if (x >= 0 && x < cw && cell[cy * cw + x]) best = adc_imin(best, adc_iabs(dx));
-    }
-    rowd[c] = (uint8_t)best;
+    rowd[c] = (uint8_t)adc_itp_rowdist(cell, cw, c % cw, c / cw);
 }
 __global__ __launch_bounds__(256) void k_itp_coldist(const uint8_t* __restrict__ rowd, uint8_t* __restrict__ cdist, int cw, int ch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cw * ch) return;
-    const int cy = c / cw, cx = c - cy * cw;
-    int best = ITP_CAP + 1;
-    for (int dy = -ITP_CAP; dy <= ITP_CAP; dy++) {
-        const int y = cy + dy;
-        if (y >= 0 && y < ch) best = adc_imin(best, adc_imax((int)rowd[y * cw + cx], adc_iabs(dy)));
-    }
-    cdist[c] = (uint8_t)best;
+    cdist[c] = (uint8_t)adc_itp_coldist(rowd, cw, ch, c % cw, c / cw);
 }
 
 template <int NS>
@@ -348,8 +335,7 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
         // the ray's own step counter: next step to evaluate (steps proven empty are skipped, see k_itp_cells)
         int m = 1;
         {
-            const int c = cdist[(y / ITP_CELL) * cw + (x / ITP_CELL)];
-            if (c >= 2) m += (c - 1) * ITP_CELL - 1;
+            m += adc_itp_skip(cdist[(y / ITP_CELL) * cw + (x / ITP_CELL)]);
         }
         while (__any(walking && m < max_search)) {
             int q[NS], yy[NS], xx[NS];
@@ -377,7 +363,7 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
                 }
             }
             m += NS;
-            if (cl >= 2) m += (cl - 1) * ITP_CELL - 1;
+            m += adc_itp_skip(cl);
         }
         // combine the 16 rays of this pixel (lanes with equal lane&3)
         float best;

@@ -693,6 +693,83 @@ void emul_interpolate(const float* din, float* dout, const uint8_t* label, const
         }
 }
 
+// ------------------------------------------------------------------ k_interpolate_tab with empty-space skipping
+// The list kernel's walk: per ray its own step counter m, trips of NS steps whose map values are requested together, a
+// skip of adc_itp_skip(cell distance) steps at the start and after every trip (cell distance at the LAST position of the
+// trip), on the cell maps built by the same three passes as k_itp_cells / k_itp_rowdist / k_itp_coldist.  Must equal
+// emul_interpolate (the plain walk) on any input.  Returns the number of map look-ups (the plain walk's count goes to
+// *plain_lookups) so that a test can also see that steps were really skipped.
+long emul_interpolate_skip(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
+                           int max_search, int NS, long* plain_lookups)
+{
+    double sc[32];
+    const float pi = 3.1415926f;
+    double ang = 0.0;
+    for (int s = 0; s < 16; s++) { sc[2 * s] = sin(ang); sc[2 * s + 1] = cos(ang); ang += pi / 16; }
+    const int cw = (W + ADC_ITP_CELL - 1) / ADC_ITP_CELL, ch = (H + ADC_ITP_CELL - 1) / ADC_ITP_CELL;
+    std::vector<uint8_t> cell((size_t)cw * ch), rowd((size_t)cw * ch), cdist((size_t)cw * ch);
+    for (int cy = 0; cy < ch; cy++)
+        for (int cx = 0; cx < cw; cx++) {
+            bool any = false;
+            for (int r = 0; r < ADC_ITP_CELL; r++)
+                for (int q = 0; q < ADC_ITP_CELL; q++) {
+                    const int y = cy * ADC_ITP_CELL + r, x = cx * ADC_ITP_CELL + q;
+                    if (y < H && x < W) any = any || din[(size_t)y * W + x] != ADC_INVALID_FLOAT;
+                }
+            cell[(size_t)cy * cw + cx] = any ? 1 : 0;
+        }
+    for (int c = 0; c < cw * ch; c++) rowd[c] = (uint8_t)adc_itp_rowdist(cell.data(), cw, c % cw, c / cw);
+    for (int c = 0; c < cw * ch; c++) cdist[c] = (uint8_t)adc_itp_coldist(rowd.data(), cw, ch, c % cw, c / cw);
+    long lookups = 0, plain = 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const float d0 = din[p];
+            if (!(label[p] == which && d0 == ADC_INVALID_FLOAT)) { dout[p] = d0; continue; }
+            const uint8_t* c0 = img_l + p * 3;
+            const bool mismatch = which == ADC_LABEL_MISMATCH;
+            int min_dist = 9999;
+            float best = mismatch ? 0.0f : ADC_LARGE_FLOAT;
+            bool any = false;
+            for (int s = 0; s < 16; s++) {
+                const double sina = sc[2 * s], cosa = sc[2 * s + 1];
+                for (int m = 1; m < max_search; m++) { // (look-ups of the plain walk, for the statistics only)
+                    const int yy = (int)lround((double)y + (double)m * sina), xx = (int)lround((double)x + (double)m * cosa);
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) break;
+                    plain++;
+                    if (din[(size_t)yy * W + xx] != ADC_INVALID_FLOAT) break;
+                }
+                bool walking = true;
+                float hit = ADC_INVALID_FLOAT;
+                size_t hitq = p;
+                int m = 1 + adc_itp_skip(cdist[(size_t)(y / ADC_ITP_CELL) * cw + x / ADC_ITP_CELL]);
+                while (walking && m < max_search) {
+                    int cl = 0;
+                    for (int j = 0; j < NS && walking; j++) {
+                        if (m + j >= max_search) { walking = false; break; }
+                        const int yy = (int)lround((double)y + (double)(m + j) * sina), xx = (int)lround((double)x + (double)(m + j) * cosa);
+                        if (yy < 0 || yy >= H || xx < 0 || xx >= W) { walking = false; break; }
+                        lookups++;
+                        const float d = din[(size_t)yy * W + xx];
+                        if (d != ADC_INVALID_FLOAT) { hit = d; hitq = (size_t)yy * W + xx; walking = false; break; }
+                        if (j == NS - 1) cl = cdist[(size_t)(yy / ADC_ITP_CELL) * cw + xx / ADC_ITP_CELL];
+                    }
+                    m += NS + adc_itp_skip(cl);
+                }
+                if (hit != ADC_INVALID_FLOAT) {
+                    any = true;
+                    if (mismatch) {
+                        const int dist = adc_color_dist_l1(c0, img_l + hitq * 3);
+                        if (min_dist > dist) { min_dist = dist; best = hit; }
+                    } else best = hit < best ? hit : best;
+                }
+            }
+            dout[p] = any ? best : 0.0f;
+        }
+    if (plain_lookups) *plain_lookups = plain;
+    return lookups;
+}
+
 // ------------------------------------------------------------------ k_median_wavefront
 void emul_median_wavefront(const float* in, float* out, int W, int H)
 {

@@ -230,6 +230,12 @@ def test_refiner_parallel_forms(emul, dumps, name):
     emul.emul_interpolate(P(a), P(b), P(o["outlier_label"]), P(left), w, h, 1, ms)
     emul.emul_interpolate(P(b), P(a), P(o["outlier_label"]), P(left), w, h, 2, ms)
     assert same(a, o["disp_after_interp"])
+    # the list kernel's walk with empty-space skipping (per-ray step counter, trips of 4 steps, cell-distance skips)
+    emul.emul_interpolate_skip.restype = C.c_long
+    a2, b2 = o["disp_after_irv"].copy(), np.empty((h, w), np.float32)
+    emul.emul_interpolate_skip(P(a2), P(b2), P(o["outlier_label"]), P(left), w, h, 1, ms, 4, None)
+    emul.emul_interpolate_skip(P(b2), P(a2), P(o["outlier_label"]), P(left), w, h, 2, ms, 4, None)
+    assert same(a2, o["disp_after_interp"])
     m = np.empty((h, w), np.float32)
     emul.emul_median_wavefront(P(o["disp_after_dda"]), P(m), w, h)
     assert same(m, o["disp_final"])
@@ -292,3 +298,26 @@ def test_markstein_division_is_ieee_division(tmp_path):
     for lo, hi in ((1, 96), (4700, 4761), (65500, 65535)):
         out = subprocess.run([exe, str(lo), str(hi)], capture_output=True, text=True, timeout=600).stdout
         assert "mismatches 0" in out, out
+
+
+@pytest.mark.parametrize("seed,density,ns", [(1, 0.003, 4), (2, 0.02, 4), (3, 0.25, 4), (4, 0.003, 2), (5, 0.0005, 8), (6, 0.0, 4)])
+def test_interpolation_skipping_is_exact(emul, seed, density, ns):
+    """Empty-space skipping of the ray walk (adc_device_fn.h: adc_itp_*; k_refine.hip): on maps with a nearly empty band (the
+    situation the skipping is for: 0.3 % valid pixels), dense regions and empty images, the skipping walk fills every target
+    exactly like the plain walk -- and does take fewer look-ups where the map is sparse."""
+    rng = np.random.default_rng(seed)
+    w, h, ms = 157, 83, 96
+    valid = rng.random((h, w)) < density
+    valid[:, 100:] |= rng.random((h, w - 100)) < 0.3          # a dense region next to the sparse band
+    disp = np.where(valid, rng.integers(0, 90, (h, w)).astype(np.float32) + rng.random((h, w)).astype(np.float32), np.float32(np.inf)).astype(np.float32)
+    label = rng.integers(0, 3, (h, w)).astype(np.uint8)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    emul.emul_interpolate_skip.restype = C.c_long
+    for which in (1, 2):
+        want, got = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+        emul.emul_interpolate(P(disp), P(want), P(label), P(img), w, h, which, ms)
+        plain = C.c_long(0)
+        n = emul.emul_interpolate_skip(P(disp), P(got), P(label), P(img), w, h, which, ms, ns, C.byref(plain))
+        assert same(got, want)
+        if density <= 0.003:
+            assert n < 0.6 * plain.value, (n, plain.value)   # the sparse band is crossed in jumps
