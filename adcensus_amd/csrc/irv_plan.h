@@ -85,3 +85,68 @@ ADC_HD long irv_list_slot(long i, int G, int WPB)
     const long blk = r % G, t = r / G;
     return (i / B) * B + (blk * WPB + t % WPB) * 64 + t / WPB;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Packed-halfword decode of a region row block (8 pixels of the 16-bit state map in four dwords) and of a change-tile row,
+// shared with the CPU tests (tests/emul/emul_irv.cpp checks them against per-pixel loops).
+// bits 0..3 of n -> bytes 0..3 (0xFF where the bit is set)
+ADC_HD uint32_t irv_expand_nibble(uint32_t n) { return ((n * 0x00204081u) & 0x01010101u) * 0xFFu; }
+// bit k of the words t0..t3 -> bits 0, 2, 4, 6 and bit k + 16 -> bits 1, 3, 5, 7 (k >= 6): the same flag of the 8 packed
+// halfwords of a 16-byte block as one 8-bit mask
+ADC_HD uint32_t irv_gather8(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, int k)
+{
+    const uint32_t sel = 0x00010001u;
+    const uint32_t u = ((t0 >> k) & sel) | ((t1 >> (k - 2)) & (sel << 2)) | ((t2 >> (k - 4)) & (sel << 4)) | ((t3 >> (k - 6)) & (sel << 6));
+    return (u | (u >> 15)) & 0xffu;
+}
+// ~(byte mask) of the four dwords of a 16-byte tile row for the tiles [txb, last] of a row that starts at tile cb
+// (cb = txb & ~3, last <= txb + 11): bytes outside the range are forced non-zero before the any-zero-byte test
+ADC_HD void irv_tile_row_masks(int txb, int last, uint32_t* nk)
+{
+    const int cb = txb & ~3;
+    const uint32_t m16 = ((1u << (last + 1 - cb)) - 1u) & ~((1u << (txb - cb)) - 1u);
+    nk[0] = ~irv_expand_nibble(m16 & 15u); nk[1] = ~irv_expand_nibble((m16 >> 4) & 15u);
+    nk[2] = ~irv_expand_nibble((m16 >> 8) & 15u); nk[3] = ~irv_expand_nibble(m16 >> 12);
+}
+// non-zero iff a byte of `word` that is not masked out by nk equals the stamp replicated in want4
+ADC_HD uint32_t irv_tile_hit(uint32_t word, uint32_t nk, uint32_t want4)
+{
+    const uint32_t x = (word ^ want4) | nk;
+    return (x - 0x01010101u) & ~x & 0x80808080u;
+}
+struct IrvBlock {
+    uint32_t okm;   // pixels that count in the vote (bit q = pixel px0 + q)
+    uint32_t first; // bin of the lowest counted pixel
+    bool single;    // all counted pixels fall into `first`
+    bool open;      // an eligible predecessor of p in this block is not final yet
+};
+// Block of 8 pixels px0 .. px0 + 7 of region row yt, of which [xl, xr] belong to the region of p = (x, y).
+ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t vw, int px0, int xl, int xr, int yt, int y, int x)
+{
+    IrvBlock r;
+    const uint32_t inm = (((2u << adc_imin(xr - px0, 7)) - 1u) & ~((1u << adc_imax(xl - px0, 0)) - 1u)) & 0xffu;
+    // pixels that precede p in raster order
+    const uint32_t prem = yt < y ? 0xffu : (yt == y ? ((1u << adc_imax(0, adc_imin(x - px0, 8))) - 1u) : 0u);
+    const uint32_t b0 = vx & 0x07FF07FFu, b1 = vy & 0x07FF07FFu, b2 = vz & 0x07FF07FFu, b3 = vw & 0x07FF07FFu; // bins
+    const uint32_t elm = irv_gather8(vx, vy, vz, vw, 15);  // eligible
+    const uint32_t finm = irv_gather8(vx, vy, vz, vw, 14); // final
+    // bin == 0x7FF (invalid / never counted): 0x7FF + 1 carries into bit 11 of the halfword
+    const uint32_t invm = irv_gather8(b0 + 0x00010001u, b1 + 0x00010001u, b2 + 0x00010001u, b3 + 0x00010001u, 11);
+    // eligible pixels of this pass are visible only if they precede p (already processed by the sequential scan);
+    // otherwise they are still invalid
+    r.okm = inm & ~invm & (~elm | prem);
+    // an eligible predecessor that is not final yet: this vote may still change
+    r.open = (inm & elm & prem & ~finm) != 0u;
+    r.first = 0u;
+    r.single = false;
+    if (r.okm != 0u) {
+        const int q0 = __builtin_ffs((int)r.okm) - 1;
+        const uint32_t wsel = q0 < 2 ? b0 : (q0 < 4 ? b1 : (q0 < 6 ? b2 : b3));
+        r.first = (wsel >> (16 * (q0 & 1))) & IRV_BIN_MASK;
+        const uint32_t f2 = r.first * 0x00010001u;
+        // halfwords that differ from the first counted bin: (d + 0x7FF) carries into bit 11 iff d != 0
+        const uint32_t difm = irv_gather8((b0 ^ f2) + 0x07FF07FFu, (b1 ^ f2) + 0x07FF07FFu, (b2 ^ f2) + 0x07FF07FFu, (b3 ^ f2) + 0x07FF07FFu, 11);
+        r.single = (difm & r.okm) == 0u;
+    }
+    return r;
+}

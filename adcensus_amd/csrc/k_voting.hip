@@ -72,9 +72,6 @@ __global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arm
     bbox[(size_t)y * W + x] = make_uchar4(a.z, (unsigned char)ml, (unsigned char)mr, 0);
 }
 
-// bits 0..3 of n -> bytes 0..3 (0xFF where the bit is set)
-__device__ __forceinline__ uint32_t irv_expand_nibble(uint32_t n) { return ((n * 0x00204081u) & 0x01010101u) * 0xFFu; }
-
 // Did a pixel of the tile box [tx0, tx1] x [ty0, ty1] change in the round whose stamp is want4 (replicated byte)?  A
 // tile row of the box = 16 bytes from a dword-aligned column; bytes outside the box are forced non-zero (nk = ~byte
 // mask per dword, from a 16-bit byte-valid mask) before the any-zero-byte test of (word ^ stamp); three tile rows are
@@ -89,32 +86,21 @@ __device__ __forceinline__ bool irv_box_dirty(const uint8_t* __restrict__ chg_rd
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int txb = tx0; txb <= tx1; txb += 12) {
         const int cb = txb & ~3, last = adc_imin(tx1, txb + 11);
-        const uint32_t m16 = ((1u << (last + 1 - cb)) - 1u) & ~((1u << (txb - cb)) - 1u);
-        const uint32_t nk0 = ~irv_expand_nibble(m16 & 15u), nk1 = ~irv_expand_nibble((m16 >> 4) & 15u),
-                       nk2 = ~irv_expand_nibble((m16 >> 8) & 15u), nk3 = ~irv_expand_nibble(m16 >> 12);
+        uint32_t nk[4];
+        irv_tile_row_masks(txb, last, nk);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int tyb = ty0; tyb <= ty1; tyb += 3) {
             const uint4 v0 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 0, ty1) * tpitch + cb));
             const uint4 v1 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 1, ty1) * tpitch + cb));
             const uint4 v2 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 2, ty1) * tpitch + cb));
-#define IRV_ANYZ(WORD, NK) ((((((WORD) ^ want4) | (NK)) - 0x01010101u) & ~(((WORD) ^ want4) | (NK))) & 0x80808080u)
-            const uint32_t hit = IRV_ANYZ(v0.x, nk0) | IRV_ANYZ(v0.y, nk1) | IRV_ANYZ(v0.z, nk2) | IRV_ANYZ(v0.w, nk3) |
-                                 IRV_ANYZ(v1.x, nk0) | IRV_ANYZ(v1.y, nk1) | IRV_ANYZ(v1.z, nk2) | IRV_ANYZ(v1.w, nk3) |
-                                 IRV_ANYZ(v2.x, nk0) | IRV_ANYZ(v2.y, nk1) | IRV_ANYZ(v2.z, nk2) | IRV_ANYZ(v2.w, nk3);
-#undef IRV_ANYZ
+            const uint32_t hit = irv_tile_hit(v0.x, nk[0], want4) | irv_tile_hit(v0.y, nk[1], want4) | irv_tile_hit(v0.z, nk[2], want4) |
+                                 irv_tile_hit(v0.w, nk[3], want4) | irv_tile_hit(v1.x, nk[0], want4) | irv_tile_hit(v1.y, nk[1], want4) |
+                                 irv_tile_hit(v1.z, nk[2], want4) | irv_tile_hit(v1.w, nk[3], want4) | irv_tile_hit(v2.x, nk[0], want4) |
+                                 irv_tile_hit(v2.y, nk[1], want4) | irv_tile_hit(v2.z, nk[2], want4) | irv_tile_hit(v2.w, nk[3], want4);
             dirty |= hit != 0u;
         }
     }
     return dirty;
-}
-
-// bit k of the words t0..t3 -> bits 0, 2, 4, 6 and bit k + 16 -> bits 1, 3, 5, 7 (k >= 6): the same flag of the 8 packed
-// halfwords of a 16-byte block as one 8-bit mask
-__device__ __forceinline__ uint32_t irv_gather8(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, int k)
-{
-    const uint32_t sel = 0x00010001u;
-    const uint32_t u = ((t0 >> k) & sel) | ((t1 >> (k - 2)) & (sel << 2)) | ((t2 >> (k - 4)) & (sel << 4)) | ((t3 >> (k - 6)) & (sel << 6));
-    return (u | (u >> 15)) & 0xffu;
 }
 
 // Wave-wide maximum / sum of non-negative ints in 6 DPP steps (row rotations, then the two row broadcasts of gfx9); the
@@ -368,48 +354,26 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                         const uint32_t addr = use ? (uint32_t)(yt * SP + blk * 8) : own;
                         const uint4 v = *reinterpret_cast<const uint4*>(st16 + addr); // loads stay unconditional
                         IRV_T(5);
-                        uint32_t okm = 0u, first = 0u;
-                        bool single = false;
-                        uint32_t b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u;
+                        // The 8 pixels of the block, decoded as packed halfwords (irv_plan.h: irv_decode_block): which pixels
+                        // count, and do they all fall into ONE bin?
+                        uint32_t okm = 0u;
                         if (use) {
-                            // The 8 pixels of the block, decoded as packed halfwords (bit q of a mask = pixel blk * 8 + q).
-                            // Which pixels count, and do they all fall into ONE bin?
-                            const int px0 = blk * 8;
-                            const uint32_t inm = (((2u << adc_imin(xr - px0, 7)) - 1u) & ~((1u << adc_imax(xl - px0, 0)) - 1u)) & 0xffu;
-                            // pixels that precede p in raster order
-                            const uint32_t prem = yt < y ? 0xffu : (yt == y ? ((1u << adc_imax(0, adc_imin(x - px0, 8))) - 1u) : 0u);
-                            b0 = v.x & 0x07FF07FFu; b1 = v.y & 0x07FF07FFu; b2 = v.z & 0x07FF07FFu; b3 = v.w & 0x07FF07FFu; // bins
-                            const uint32_t elm = irv_gather8(v.x, v.y, v.z, v.w, 15);   // eligible
-                            const uint32_t finm = irv_gather8(v.x, v.y, v.z, v.w, 14);  // final
-                            // bin == 0x7FF (invalid / never counted): 0x7FF + 1 carries into bit 11 of the halfword
-                            const uint32_t invm = irv_gather8(b0 + 0x00010001u, b1 + 0x00010001u, b2 + 0x00010001u, b3 + 0x00010001u, 11);
-                            // eligible pixels of this pass are visible only if they precede p (already processed by the
-                            // sequential scan); otherwise they are still invalid
-                            okm = inm & ~invm & (~elm | prem);
-                            // an eligible predecessor that is not final yet: this vote may still change
-                            deps_open = deps_open || (inm & elm & prem & ~finm) != 0u;
-                            if (okm != 0u) {
-                                const int q0 = __ffs((int)okm) - 1;
-                                const uint32_t wsel = q0 < 2 ? b0 : (q0 < 4 ? b1 : (q0 < 6 ? b2 : b3));
-                                first = (wsel >> (16 * (q0 & 1))) & IRV_BIN_MASK;
-                                const uint32_t f2 = first * 0x00010001u;
-                                // halfwords that differ from the first counted bin: (d + 0x7FF) carries into bit 11 iff d != 0
-                                const uint32_t difm = irv_gather8((b0 ^ f2) + 0x07FF07FFu, (b1 ^ f2) + 0x07FF07FFu, (b2 ^ f2) + 0x07FF07FFu,
-                                                                  (b3 ^ f2) + 0x07FF07FFu, 11);
-                                single = (difm & okm) == 0u;
-                            }
-                        }
-                        if (okm != 0u) {
+                            const IrvBlock bd = irv_decode_block(v.x, v.y, v.z, v.w, blk * 8, xl, xr, yt, y, x);
+                            deps_open = deps_open || bd.open;
+                            okm = bd.okm;
                             // (same-address LDS atomics serialise: one per lane instead of eight.  Counting the dominant bin in
                             // registers across the wave was measured too: slower, the extra wave reduction costs more.)
-                            if (single) atomicAdd(&hist[first], __popc(okm));
-                            else {
+                            if (okm != 0u && bd.single) {
+                                atomicAdd(&hist[bd.first], __popc(okm));
+                                okm = 0u;
+                            }
+                        }
+                        if (okm != 0u) { // pixels of several bins: one atomic each
 #pragma clang loop unroll(disable)
-                                for (uint32_t m = okm; m != 0u; m &= m - 1u) {
-                                    const int q = __ffs((int)m) - 1;
-                                    const uint32_t wq = q < 2 ? b0 : (q < 4 ? b1 : (q < 6 ? b2 : b3));
-                                    atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
-                                }
+                            for (uint32_t m = okm; m != 0u; m &= m - 1u) {
+                                const int q = __ffs((int)m) - 1;
+                                const uint32_t wq = q < 2 ? v.x : (q < 4 ? v.y : (q < 6 ? v.z : v.w));
+                                atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
                             }
                         }
                         if (!__any(rowok && (b0x + bo + 4 <= b1x))) break;

@@ -143,3 +143,63 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
     if (out_stats) { out_stats[0] = fin[5]; out_stats[1] = fin[6]; out_stats[2] = kernels; }
     return fin[0] == IRV_DONE ? fin[5] : -2;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The packed-halfword helpers of irv_plan.h against per-pixel loops on random inputs (values drawn so that equal bins,
+// invalid bins, eligible / final flags and range edges all occur often).  Returns the number of disagreements.
+extern "C" long emul_irv_swar_check(unsigned seed, long trials)
+{
+    srand(seed);
+    long bad = 0;
+    for (long t = 0; t < trials; t++) {
+        // ---- region row block
+        uint16_t s16[8];
+        const int nb = 1 + rand() % 4;                   // few distinct bins -> "single bin" happens
+        const int pool[4] = {rand() % 2047, rand() % 2047, IRV_BIN_MASK, rand() % 2047};
+        for (int q = 0; q < 8; q++) {
+            uint32_t v = (uint32_t)pool[rand() % nb];
+            if (rand() % 3 == 0) v |= IRV_ELIG;
+            if (rand() % 2 == 0) v |= IRV_FINAL;
+            if (rand() % 4 == 0) v |= 0x3800u;           // bits 11..13 are unused: must not matter
+            s16[q] = (uint16_t)v;
+        }
+        uint32_t w[4];
+        for (int j = 0; j < 4; j++) w[j] = (uint32_t)s16[2 * j] | ((uint32_t)s16[2 * j + 1] << 16);
+        const int px0 = 8 * (rand() % 50), y = 5 + rand() % 5, yt = y - 2 + rand() % 5, x = px0 - 6 + rand() % 20;
+        int xl = px0 - 4 + rand() % 12, xr = xl + rand() % 14;
+        if (xr < px0) xr = px0;                           // (the kernel only decodes blocks that intersect [xl, xr])
+        if (xl > px0 + 7) xl = px0 + 7;
+        if (xr < xl) xr = xl;
+        const IrvBlock got = irv_decode_block(w[0], w[1], w[2], w[3], px0, xl, xr, yt, y, x);
+        uint32_t okm = 0, first = 0;
+        bool single = true, open = false, have = false;
+        for (int q = 0; q < 8; q++) {
+            const int px = px0 + q;
+            const uint32_t sv = s16[q], bin = sv & IRV_BIN_MASK;
+            const bool in = px >= xl && px <= xr, el = (sv & IRV_ELIG) != 0, pre = yt < y || (yt == y && px < x);
+            if (in && bin != IRV_BIN_MASK && (!el || pre)) {
+                okm |= 1u << q;
+                if (!have) { first = bin; have = true; }
+                single = single && bin == first;
+            }
+            if (in && el && pre && !(sv & IRV_FINAL)) open = true;
+        }
+        if (got.okm != okm || got.open != open) bad++;
+        else if (okm && (got.first != first || got.single != single)) bad++;
+        // ---- change-tile row
+        uint8_t tb[16];
+        const uint32_t stamp = 1 + rand() % 255;
+        for (int i = 0; i < 16; i++) tb[i] = rand() % 5 == 0 ? (uint8_t)stamp : (uint8_t)(rand() % 256 == (int)stamp ? 0 : rand() % 256);
+        const int cb = 4 * (rand() % 30), txb = cb + rand() % 4, last = txb + rand() % 12;
+        uint32_t nk[4], tw[4], hit = 0;
+        irv_tile_row_masks(txb, last, nk);
+        for (int j = 0; j < 4; j++) {
+            tw[j] = (uint32_t)tb[4 * j] | ((uint32_t)tb[4 * j + 1] << 8) | ((uint32_t)tb[4 * j + 2] << 16) | ((uint32_t)tb[4 * j + 3] << 24);
+            hit |= irv_tile_hit(tw[j], nk[j], stamp * 0x01010101u);
+        }
+        bool want = false;
+        for (int tx = txb; tx <= last; tx++) want = want || tb[tx - cb] == stamp;
+        if ((hit != 0) != want) bad++;
+    }
+    return bad;
+}

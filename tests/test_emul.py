@@ -321,3 +321,12 @@ def test_interpolation_skipping_is_exact(emul, seed, density, ns):
         assert same(got, want)
         if density <= 0.003:
             assert n < 0.6 * plain.value, (n, plain.value)   # the sparse band is crossed in jumps
+
+
+def test_voting_packed_halfword_helpers(emul):
+    """irv_plan.h: irv_decode_block (eligible / final / invalid-bin / same-bin masks of 8 packed state halfwords by SWAR
+    carries) and the change-tile row test (byte masks from a nibble expansion, any-zero-byte trick) agree with per-pixel
+    loops on two million random blocks."""
+    emul.emul_irv_swar_check.restype = C.c_long
+    for seed in (1, 2):
+        assert emul.emul_irv_swar_check(seed, C.c_long(1000000)) == 0
