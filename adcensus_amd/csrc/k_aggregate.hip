@@ -813,7 +813,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     for (int k = 0; k < iterations && e == hipSuccess; k++) {
         const bool hf = horizontal_first;
         if (!second_done) {
-            if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
+            if (h->profiling && launch < 2) hipEventRecord(h->ev_agg[launch], h->heavy); // (only the marks adc_wait reads: start of the first / first regular launch)
             if (hf) {
                 // first pass of the pipeline: the matching cost is computed inside the pass (no input volume)
                 const bool fused = k == 0 && h->fuse_cost && !direct && lds_fits;
@@ -829,7 +829,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
         }
         second_done = false;
         if (e != hipSuccess) break;
-        if (h->profiling && launch < 8) hipEventRecord(h->ev_agg[launch], h->heavy);
+        if (h->profiling && launch < 2) hipEventRecord(h->ev_agg[launch], h->heavy); // (only the marks adc_wait reads: start of the first / first regular launch)
         // second pass of the iteration (dividing): vertical after a horizontal first pass and vice versa
         const int wsec = hf ? which_v : which_h;
         const bool pair = pair_env && marching && k + 1 < iterations &&
