@@ -285,7 +285,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     const int round = pl.s.round, n = pl.s.n;
     extern __shared__ int lds_dyn[]; // [waves][D] histograms, then the pool: [waves][64] int4
     int* hist = lds_dyn + wave * D;
-    int4* pool = reinterpret_cast<int4*>(lds_dyn + WPB * D);
+    int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * D + 3) & ~3)); // (16-byte aligned whatever D is)
     __shared__ int pcount[IRV_MAXW];
     const int sub = lane >> 2, bslot = lane & 3;
     const long B = 64L * NW;
@@ -443,7 +443,7 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count)
     const AdcParams& p = h->p;
     const int tpitch = h->chg_pitch, chg_bytes = tpitch * ((p.H + IRV_TILE - 1) / IRV_TILE);
     const int wpb = irv_wpb(p.D);
-    const size_t lds = (size_t)wpb * p.D * 4 + (size_t)wpb * 64 * 16;
+    const size_t lds = (size_t)((wpb * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
     for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(k_irv_u, dim3(irv_grid()), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
                            h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,

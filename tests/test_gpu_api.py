@@ -171,8 +171,8 @@ def test_voting_chain_launch_shapes(hip, oracle):
     (512 x 16) never takes below ~500 k list entries.  The shape is read once per process: subprocess."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for grid, wpb in ((3, 2), (1, 1), (7, 16)):
-        env = dict(os.environ, ADC_IRV_GRID=str(grid), ADC_IRV_WPB=str(wpb))
+    for grid, wpb, d in ((3, 2, 32), (1, 1, 33), (7, 16, 32)):
+        env = dict(os.environ, ADC_IRV_GRID=str(grid), ADC_IRV_WPB=str(wpb), ADC_CHECK_D=str(d))
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_voting_budget_check.py")], cwd=root, env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (grid, wpb, r.stdout[-2000:], r.stderr[-2000:])

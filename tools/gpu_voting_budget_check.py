@@ -8,7 +8,7 @@ import adcensus_amd as A
 from adcensus_amd import workloads
 from oracle import pyoracle
 from tests import cases
-w, h, d = 200, 150, 32
+w, h, d = 200, 150, int(os.environ.get("ADC_CHECK_D", "32"))  # (an odd range: the LDS pool behind the histograms must stay aligned)
 left, right = workloads.structured_pair(w, h, d, seed=5)
 opt = pyoracle.Option(max_disparity=d)
 o = pyoracle.load("auto").run(left, right, opt)
