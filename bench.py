@@ -196,6 +196,11 @@ def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair
     elapsed, total = farm.timed_region(run, steps, warmup, dist=dist, device_sync=m.lib.adc_device_synchronize,
                                        tensor_device=tensor_device)
     keep = max(1, (steps + inflight - 1) // inflight)
+    # how often adc_wait had to complete an assumption of the asynchronous pipeline (warm-up + timed region, all pipelines)
+    m.fallbacks = {"median_handoff": 0, "voting_continuations": 0, "aggregation_redos": 0, "matches": warmup + steps}
+    for st in m.handles:
+        for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2)):
+            m.fallbacks[key] += int(st.debug_counter(which))
     return m, elapsed, total, stages[-keep:], prof[-keep:]
 
 
@@ -314,6 +319,7 @@ def main():
             "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
             "stage_ms": stage,
             "roofline": k4_roofline(prof, W, H, D, lib, a.workload),
+            "async_fallbacks": m.fallbacks,
         }
     m.release()
 
@@ -325,7 +331,7 @@ def main():
         s2 = mean_stages(st2)
         out[other] = {"value": round(t2 / e2, 4), "unit": "pairs/s", "ms_per_step": round(1000.0 * e2 / n2, 4), "steps": n2,
                       "workload": "%s %dx%d D=%d (one pair repeated)" % (other, W, H, D), "stage_ms": s2,
-                      "roofline": k4_roofline(pf2, W, H, D, lib, other)}
+                      "roofline": k4_roofline(pf2, W, H, D, lib, other), "async_fallbacks": m2.fallbacks}
         m2.release()
         # ---- the drop-in entry point with pageable host buffers
         out["host_inclusive"] = host_inclusive_leg(A, local_rank, W, H, D, a.workload, max(5, min(10, a.steps)))
