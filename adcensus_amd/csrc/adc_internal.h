@@ -95,6 +95,7 @@ struct adc_handle {
     uint16_t* st16;      // region voting: 16-bit state map [H][st16_pitch] {bin:11 | final | eligible} (k_voting.hip)
     int st16_pitch;      // row pitch of st16 in elements (multiple of 8: rows start 16-byte aligned)
     float* disp_vote;    // the map the voting chain works on (copy of the LR-checked map, copied back when the chain ends)
+    int irv_grid;        // workgroups of the voting chain (adc_irv_grid, fixed per handle: the work-list layout depends on it)
     int irv_budget;      // kernels the next Match enqueues for the voting chain (adapted from the last Match)
     int irv_chain;       // kernels of the chain enqueued so far (continuation starts here)
     int irv_pending;     // a chain was enqueued and its final state has not been looked at yet
@@ -140,8 +141,9 @@ hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_lrcheck(adc_handle* h);
 size_t adc_itp_cell_bytes(int W, int H);       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
-size_t adc_irv_waves();                        // waves of the voting chain's grid
-size_t adc_irv_list_entries(size_t pixels, int D);    // capacity of the voting work list (whole batches)
+int adc_irv_grid(size_t pixels);                // workgroups of the voting chain for an image of this size
+size_t adc_irv_waves(int grid);                // waves of the voting chain's grid (upper bound)
+size_t adc_irv_list_entries(size_t pixels, int D, int grid);    // capacity of the voting work list (whole batches)
 hipError_t adc_run_region_voting(adc_handle* h); // enqueue only (device-driven chain with a launch budget)
 hipError_t adc_voting_finish(adc_handle* h, int* continued); // after a sync: continue the chain if the budget was too small
 hipError_t adc_launch_interpolation(adc_handle* h);

@@ -416,11 +416,15 @@ static int irv_min_region(const adc_handle* h)
     const int Lmax = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
     return Lmax <= 127 ? h->p.opt.irv_ts : -1; // u16 support counts cannot wrap for L <= 127
 }
-// Launch shape of the chain: IRV_WPB waves per workgroup (16 unless the histograms + pool would not fit into 64 KB of
-// LDS), ADC_IRV_GRID workgroups (default: two per CU of an MI355X).
-static unsigned irv_grid()
+// Launch shape of the chain: up to 16 waves per workgroup (fewer when the histograms + pool would not fit into 64 KB of
+// LDS); workgroups: one per 2048 pixels, rounded up to a power of two, between 64 and 512 (two per CU of an MI355X) --
+// measured at 1242x375: 256 workgroups 218 pairs/s, 512: 209, 128: 201; ADC_IRV_GRID / ADC_IRV_WPB override.
+int adc_irv_grid(size_t pixels)
 {
-    static const unsigned g = [] { const char* e = getenv("ADC_IRV_GRID"); const int v = e ? atoi(e) : 512; return (unsigned)(v > 0 ? v : 512); }();
+    static const int g_env = [] { const char* e = getenv("ADC_IRV_GRID"); return e ? atoi(e) : 0; }();
+    if (g_env > 0) return g_env;
+    int g = 64;
+    while (g < 512 && (size_t)g * 2048 < pixels) g *= 2;
     return g;
 }
 static int irv_wpb(int D)
@@ -431,11 +435,11 @@ static int irv_wpb(int D)
     while (w > 1 && (size_t)w * D * 4 + (size_t)w * 64 * 16 > 60 * 1024) w >>= 1;
     return w;
 }
-size_t adc_irv_waves() { return (size_t)IRV_MAXW * irv_grid(); } // (upper bound over all block shapes)
+size_t adc_irv_waves(int grid) { return (size_t)IRV_MAXW * grid; } // (upper bound over all block shapes)
 // entries the work list must hold: whole batches of 64 entries per wave of the chain's grid (irv_list_slot)
-size_t adc_irv_list_entries(size_t pixels, int D)
+size_t adc_irv_list_entries(size_t pixels, int D, int grid)
 {
-    const size_t B = (size_t)64 * irv_wpb(D) * irv_grid();
+    const size_t B = (size_t)64 * irv_wpb(D) * grid;
     return ((pixels + B - 1) / B) * B;
 }
 static hipError_t irv_launch(adc_handle* h, int k0, int count)
@@ -445,7 +449,7 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count)
     const int wpb = irv_wpb(p.D);
     const size_t lds = (size_t)((wpb * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
     for (int i = 0; i < count; i++)
-        hipLaunchKernelGGL(k_irv_u, dim3(irv_grid()), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
+        hipLaunchKernelGGL(k_irv_u, dim3((unsigned)h->irv_grid), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
                            h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
                            reinterpret_cast<const uchar4*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
                            p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr);
