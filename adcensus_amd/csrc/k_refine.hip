@@ -88,43 +88,23 @@ hipError_t adc_launch_lrcheck(adc_handle* h)
 }
 
 // ------------------------------------------------------------------------------ K8 region voting: k_voting.hip
-// (the list compaction below is what is left here: the interpolation uses it to build its target lists)
-// Pass set-up: elig = pixels of this list that are still invalid (the ordering mask of the pass);
-// the work list only keeps those that CAN be filled: the vote needs count > irv_ts and count <= region
-// size == horizontal-first support count, so pixels with sup_h <= irv_ts stay invalid whatever happens.
-// Block-aggregated compaction (one atomic per 256 pixels).
-#define IRV_BEGIN_PPT 8
-__global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ label, const float* __restrict__ disp,
-                                                   const uint16_t* __restrict__ sup_h, uint8_t* __restrict__ elig,
-                                                   int32_t* __restrict__ list, int32_t* __restrict__ counters, int which,
-                                                   int P, int min_region, int32_t* __restrict__ fin,
-                                                   int2* __restrict__ state)
+
+// Target list of one interpolation pass: the pixels of the list (`which`) that are still invalid, compacted in chunks of
+// 2048 pixels (ONE list-length atomic per workgroup: same-address atomics retire at roughly 8 ns each, so a
+// per-256-pixel atomic -- 8100 of them at 1080p -- alone cost ~65 us).
+#define ITP_LIST_PPT 8
+__global__ __launch_bounds__(256) void k_interp_list(const uint8_t* __restrict__ label, const float* __restrict__ disp,
+                                                     int32_t* __restrict__ list, int32_t* __restrict__ counters, int which, int P)
 {
-    // IRV_BEGIN_PPT x 256 pixels per block and ONE list-length atomic per block: same-address atomics retire
-    // at roughly 8 ns each, so a per-256-pixel atomic (8100 of them at 1080p) alone cost ~65 us per pass
-    __shared__ int wcnt[IRV_BEGIN_PPT][4];
+    __shared__ int wcnt[ITP_LIST_PPT][4];
     __shared__ int base;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long m[IRV_BEGIN_PPT];
-    bool listed[IRV_BEGIN_PPT];
+    unsigned long long m[ITP_LIST_PPT];
+    bool listed[ITP_LIST_PPT];
 #pragma unroll
-    for (int k = 0; k < IRV_BEGIN_PPT; k++) {
-        const int p = (blockIdx.x * IRV_BEGIN_PPT + k) * 256 + threadIdx.x;
-        bool e = false;
-        listed[k] = false;
-        if (p < P) {
-            const float dv = disp[p];
-            e = (label[p] == which) && (dv == ADC_INVALID_FLOAT);
-            elig[p] = e ? 1 : 0;
-            listed[k] = e && ((int)sup_h[p] > min_region);
-            // finality stamp: 0 = open, 1 = final before round 0, r+2 = "value became final in round r".  Pixels that
-            // cannot change in this pass (not eligible, or region too small to ever pass the vote) are final from the start
-            if (fin) fin[p] = listed[k] ? 0 : 1;
-            // packed per-pixel state read by the votes (ONE 8-byte gather per region pixel instead of three):
-            //   .x = disparity bits, .y = -1 not eligible (constant in this pass) | 0 eligible, open |
-            //   s > 0 eligible, final (1 = before round 0, r+2 = became final in round r)
-            if (state) state[p] = make_int2(__float_as_int(dv), !e ? -1 : (listed[k] ? 0 : 1));
-        }
+    for (int k = 0; k < ITP_LIST_PPT; k++) {
+        const int p = (blockIdx.x * ITP_LIST_PPT + k) * 256 + threadIdx.x;
+        listed[k] = p < P && label[p] == which && disp[p] == ADC_INVALID_FLOAT;
         m[k] = __ballot(listed[k]);
         if (lane == 0) wcnt[k][wave] = __popcll(m[k]);
     }
@@ -132,14 +112,14 @@ __global__ __launch_bounds__(256) void k_irv_begin(const uint8_t* __restrict__ l
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
-        for (int k = 0; k < IRV_BEGIN_PPT; k++) tot += wcnt[k][0] + wcnt[k][1] + wcnt[k][2] + wcnt[k][3];
+        for (int k = 0; k < ITP_LIST_PPT; k++) tot += wcnt[k][0] + wcnt[k][1] + wcnt[k][2] + wcnt[k][3];
         base = tot ? atomicAdd(&counters[0], tot) : 0;
     }
     __syncthreads();
     int off = base;
 #pragma unroll
-    for (int k = 0; k < IRV_BEGIN_PPT; k++) {
-        const int p = (blockIdx.x * IRV_BEGIN_PPT + k) * 256 + threadIdx.x;
+    for (int k = 0; k < ITP_LIST_PPT; k++) {
+        const int p = (blockIdx.x * ITP_LIST_PPT + k) * 256 + threadIdx.x;
         int mine = off;
         for (int w = 0; w < wave; w++) mine += wcnt[k][w];
         if (listed[k]) list[mine + __popcll(m[k] & ((1ull << lane) - 1ull))] = p;
@@ -189,7 +169,7 @@ __global__ __launch_bounds__(256) void k_interpolate(const float* __restrict__ d
     dout[p] = any ? best : 0.0f; // no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
 }
 
-// Ray-parallel variant: the target pixels of the list are compacted first (k_irv_begin), then 16 lanes
+// Ray-parallel variant: the target pixels of the list are compacted first (k_interp_list), then 16 lanes
 // work on one pixel, one ray each (4 pixels per wave); the 16 first-hits are combined with a 16-lane
 // butterfly: mismatch -> lexicographic min of (L1 colour distance, ray index) == "first minimum" of the
 // sequential scan over s; occlusion -> smallest disparity.
@@ -418,8 +398,8 @@ hipError_t adc_launch_interpolation(adc_handle* h)
             // as the array), then a scatter into the map in place.  No copy of the map, no buffer swap.
             hipError_t e;
             if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_irv_begin, dim3((P + 256 * IRV_BEGIN_PPT - 1) / (256 * IRV_BEGIN_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l, h->sup_h, h->elig,
-                               h->interp_list, h->interp_counters, which, P, -1, (int32_t*)nullptr, (int2*)nullptr);
+            hipLaunchKernelGGL(k_interp_list, dim3((P + 256 * ITP_LIST_PPT - 1) / (256 * ITP_LIST_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l,
+                               h->interp_list, h->interp_counters, which, P);
             if (h->ray_tab && max_search == h->ray_tab_rows) {
                 if (k == 0 && !h->bgrx_valid) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
                 static const int ns = [] { const char* e = getenv("ADC_INTERP_NS"); return e ? atoi(e) : 4; }(); // ray steps per trip
