@@ -18,6 +18,7 @@
 #include "adc_internal.h"
 #include "adc_device_fn.h"
 #include "k_aggregate_rr.h"
+#include "k_aggregate_rr2.h"
 
 // ------------------------------------------------------------------------------- direct (fallback)
 // One thread per volume element reading its arm span straight from global memory.  Used when the
@@ -138,13 +139,7 @@ __device__ __forceinline__ V agg_sum(V acc, const V* q, int cnt)
 // 16-byte records (k_cost_records, rows padded with out-of-image markers), prefetched like the arm records.
 // AD = v_sad_u8 of the packed colours, Hamming = two v_bcnt on the xor of the census words, cost = A[ad] - C[hm] from
 // the host-built tables (in LDS behind the ring) -- bit-identical to k_cost.  Saves writing V and reading it back.
-struct AggCostIn {
-    const uint4* rrec; // right records, row pitch rpitch, first real column at index padl
-    const uint4* lrec; // left records [H][W]
-    const float* lut_ad;
-    const float* lut_census;
-    int rpitch, padl, dmin, D;
-};
+// (struct AggCostIn: k_aggregate_rr2.h)
 typedef unsigned long long agg_u64;
 
 // PAIR: TWO consecutive passes of the same direction in one launch (the dividing second pass of an iteration and the
@@ -651,6 +646,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AGG_RING_V0))) v
                                                                small_variant, small_L, ci);
 }
 
+// third generation (k_aggregate_rr2.h): two disparities per lane, ring slots = VGPR pairs v96..v239, packed adds
+template <bool VERT, bool DIVIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(RR2_V0))) void k_agg_rr2(
+    const float* __restrict__ src, float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp, int L,
+    int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L)
+{
+    const AggCostIn none = {};
+    agg_rr2_body<VERT, DIVIDE, false>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax, small_variant, small_L, none);
+}
+// first pass of the pipeline on the same body: the matching cost is computed in registers (two lane windows)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(RR2_V0))) void k_agg_rr2_cost(
+    float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
+    const int* __restrict__ armmax, int small_variant, int small_L, AggCostIn ci)
+{
+    agg_rr2_body<false, false, true>(nullptr, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax, small_variant, small_L, ci);
+}
+
 static int env_int(const char* name, int dflt)
 {
     const char* s = getenv(name);
@@ -709,15 +721,18 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const int Lv = variant ? ((which == 1 && h->armmax_valid) ? adc_imin(small_L, Lknown) : small_L) : L;
         // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring, the pair variant a second
         // ring and a record ring
-        const int vpl = (variant == 1 && !COSTIN && (vpl2_env == 1 || (vpl2_env == 2 && PAIR)) && p.Dp % 128 == 0) ? 2 : 1;
-        const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
         // full ring of a plain pass: in registers when it fits (ADC_AGG_REGRING=0: LDS ring)
         static const bool regring_env = env_int("ADC_AGG_REGRING", 1) != 0;
         const bool regring = variant == 0 && regring_env && Lv >= 1 && 2 * Lv + 1 <= AGG_RING_REGS;
+        // ... as VGPR pairs, two disparities per lane (k_aggregate_rr2.h; ADC_AGG_RR2=0: the one-float register ring)
+        static const bool rr2_env = env_int("ADC_AGG_RR2", 1) != 0;
+        const bool rr2 = regring && rr2_env && !PAIR && p.Dp % 128 == 0 && 2 * Lv + 1 <= RR2_SLOTS;
+        const int vpl = rr2 ? 2 : ((variant == 1 && !COSTIN && (vpl2_env == 1 || (vpl2_env == 2 && PAIR)) && p.Dp % 128 == 0) ? 2 : 1);
+        const long long nlines = (long long)(VERT ? p.W : p.H) * (p.Dp / (64 * vpl));
         const size_t ring_bytes = regring ? 0 : (size_t)(2 * Lv + 1) * 64 * sizeof(float) * vpl;
         const size_t ldsv = ring_bytes + (COSTIN ? (768 + 64) * sizeof(float) : 0) + ((PAIR && !regring) ? ring_bytes + (2 * Lv + 1) * 4 + 64 : 0);
-        // register rings: 128 VGPRs -> 4 waves per SIMD; a pair (two rings, 200 VGPRs) -> 2
-        const int waves_per_cu = regring ? (PAIR ? 8 : 16) : adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
+        // register rings: 128 VGPRs -> 4 waves per SIMD; a pair (two rings, 200 VGPRs) or a ring of pairs (240) -> 2
+        const int waves_per_cu = regring ? ((PAIR || rr2) ? 8 : 16) : adc_imax(1, adc_imin(32, (int)((160 * 1024) / ((ldsv + 511) / 512 * 512))));
         int nseg = env_int(VERT ? "ADC_AGG_VSEG" : "ADC_AGG_HSEG", 0);
         if (nseg < 1) nseg = pick_nseg(nlines, N, PAIR ? 2 * Lv : Lv, 256 * waves_per_cu);
         int seg_len = (N + nseg - 1) / nseg;
@@ -734,7 +749,15 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         ci.lut_ad = h->lut_ad;
         ci.lut_census = h->lut_census;
         ci.rpitch = h->rrec_pitch; ci.padl = h->rrec_padl; ci.dmin = p.dmin; ci.D = p.D;
-        if (regring) {
+        if (rr2) {
+            if constexpr (COSTIN)
+                hipLaunchKernelGGL(k_agg_rr2_cost, dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, dst,
+                                   reinterpret_cast<const uint2*>(h->rec2_h), p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
+            else if constexpr (!PAIR)
+                hipLaunchKernelGGL((k_agg_rr2<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), 0, h->heavy, src, dst,
+                                   reinterpret_cast<const uint2*>(VERT ? h->rec2_v : h->rec2_h), p.W, p.H, p.Dp, Lv, seg_len, nseg,
+                                   per_xcd, h->armmax, sv, sl);
+        } else if (regring) {
             if constexpr (COSTIN)
                 hipLaunchKernelGGL(k_agg_regring_cost, dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,
                                    VERT ? h->rec_v : h->rec_h, p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);

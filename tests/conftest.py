@@ -51,6 +51,7 @@ def emul():
     srcs = [os.path.join(ROOT, "tests", "emul", "emul.cpp"), os.path.join(ROOT, "tests", "emul", "emul_rr.cpp"),
             os.path.join(ROOT, "tests", "emul", "emul_irv.cpp")]
     hdrs = [os.path.join(ROOT, "adcensus_amd", "csrc", "adc_device_fn.h"), os.path.join(ROOT, "adcensus_amd", "csrc", "k_aggregate_rr.h"),
+            os.path.join(ROOT, "adcensus_amd", "csrc", "k_aggregate_rr2.h"),
             os.path.join(ROOT, "adcensus_amd", "csrc", "irv_plan.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs + hdrs):
         os.makedirs(out_dir, exist_ok=True)

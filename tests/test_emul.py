@@ -119,6 +119,43 @@ def test_register_ring_body_pass_pairs(emul, dumps, name, hseg, vseg):
     assert same(a, o["cost_aggr"])
 
 
+RR2_CASES = RR_CASES + ["s2_320x180_d128", "s2_200x120_d200", "noise_160x90_d128_pos", "s2_150x100_neg"]
+
+
+@pytest.mark.parametrize("name", RR2_CASES)
+@pytest.mark.parametrize("hseg,vseg,fused", [(1, 1, True), (3, 2, True), (2, 5, False)])
+def test_register_ring_pairs_body(emul, dumps, name, hseg, vseg, fused):
+    """k_aggregate_rr2.h compiled for the CPU (RR_EMUL): two disparities per lane, ring slots = VGPR pairs addressed with
+    M0 = 2 * slot, packed 35-add blocks; 8 single passes == the reference's cost_aggr.  fused: the first pass computes the
+    matching cost itself from packed pixel records (two lane windows) instead of reading cost_init."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    L = max(0, min(opt.cross_L1, 255))
+    a, b = o["cost_init"].copy(), np.full_like(o["cost_init"], np.nan)
+    hfirst, first = True, True
+    for _ in range(4):
+        order = [(0, 0, o["sup_count_h"]), (1, 1, o["sup_count_h"])] if hfirst else [(1, 0, o["sup_count_v"]), (0, 1, o["sup_count_v"])]
+        for vert, div, sup in order:
+            ci = 1 if (fused and first) else 0
+            if ci:
+                a[:] = np.nan  # the fused pass must not read the cost volume
+            rc = emul.emul_rr2_pass(P(a), P(b), P(o["arms"]), P(sup), w, h, D, vert, div, L, vseg if vert else hseg, ci,
+                                    P(left), P(right), P(o["census_left"]), P(o["census_right"]), dmin, opt.lambda_ad, opt.lambda_census)
+            assert rc == 0
+            first = False
+            a, b = b, a
+        hfirst = not hfirst
+    assert same(a, o["cost_aggr"])
+
+
+def test_rr2_cost_windows_shift_identity(emul):
+    """The two lane windows of the fused cost at two disparities per lane: A' = shr(B) with the new column at lane 0,
+    B' = A keeps lane l on the columns x - 2l and x - 2l - 1 (whole-wave model of RR2_WIN_STEP)."""
+    for start in (0, 5, 1000):
+        assert emul.emul_rr2_window_identity(300, start) == 0
+
+
 @pytest.mark.parametrize("name", ["s2_96x64_d32", "q_20x40_d32", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "q_3x3_d2", "s2_150x100_neg",
                                   "s2_200x120_d200", "q_40x30_pos_wltd", "s2_150x100_pos", "s2_200x120_d160", "noise_96x50_d160_neg"])
 @pytest.mark.parametrize("seg", [0, 7, 50])
