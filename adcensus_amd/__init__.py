@@ -89,6 +89,8 @@ def lib():
     L.adc_get_aggregate_pass_ms.restype = C.c_int
     L.adc_get_aggregate_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.adc_get_aggregate_info.restype = C.c_int
+    L.adc_get_aggregate_kernel.argtypes = [vp]
+    L.adc_get_aggregate_kernel.restype = C.c_char_p
     L.adc_get_stream.argtypes = [vp]
     L.adc_get_stream.restype = vp
     L.adc_device_synchronize.restype = C.c_int
@@ -284,6 +286,9 @@ class ADCensusStereo:
         ms, n, p, f = C.c_float(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib().adc_get_aggregate_info(self._h, C.byref(ms), C.byref(n), C.byref(p), C.byref(f))
         return float(ms.value), int(n.value), int(p.value), bool(f.value)
+
+    def aggregate_kernel(self):
+        return lib().adc_get_aggregate_kernel(self._h).decode()
 
     # -- test-only debug surface ---------------------------------------------------------------
     def _buf_spec(self, which):

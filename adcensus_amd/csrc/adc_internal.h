@@ -120,6 +120,7 @@ struct adc_handle {
     float agg_pass_ms;
     int agg_launches;
     int agg_passes;    // algorithmic passes those launches covered (a pair launch covers two)
+    const char* agg_kernel; // kernel family of the last regular aggregation launch (static string)
     bool timings_pending;
     // region voting statistics of the last run
     int64_t vote_rounds, vote_evals;

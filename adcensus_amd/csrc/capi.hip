@@ -618,6 +618,7 @@ int adc_get_aggregate_info(adc_handle* h, float* avg_launch_ms, int* launches, i
     if (first_fused) *first_fused = ff;
     return 0;
 }
+const char* adc_get_aggregate_kernel(adc_handle* h) { return (h && h->agg_kernel) ? h->agg_kernel : ""; }
 void* adc_get_stream(adc_handle* h) { return h ? (void*)h->stream : nullptr; }
 int adc_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : 1; }
 void* adc_device_malloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }

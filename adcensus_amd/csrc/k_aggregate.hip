@@ -646,21 +646,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(AGG_RING_V0))) v
                                                                small_variant, small_L, ci);
 }
 
-// third generation (k_aggregate_rr2.h): two disparities per lane, ring slots = VGPR pairs v96..v239, packed adds
+// third generation (k_aggregate_rr2.h): two disparities per lane, ring slots = VGPR pairs v96..v239, packed adds; a wave =
+// one chunk of the flattened (line-major) output index space
 template <bool VERT, bool DIVIDE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(RR2_V0))) void k_agg_rr2(
     const float* __restrict__ src, float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp, int L,
-    int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L)
+    int chunk_len, int nwaves, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L)
 {
     const AggCostIn none = {};
-    agg_rr2_body<VERT, DIVIDE, false>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax, small_variant, small_L, none);
+    agg_rr2_body<VERT, DIVIDE, false>(src, dst, rec, W, H, Dp, L, chunk_len, nwaves, per_xcd, armmax, small_variant, small_L, none);
 }
 // first pass of the pipeline on the same body: the matching cost is computed in registers (two lane windows)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(RR2_V0))) void k_agg_rr2_cost(
-    float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
+    float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp, int L, int chunk_len, int nwaves, int per_xcd,
     const int* __restrict__ armmax, int small_variant, int small_L, AggCostIn ci)
 {
-    agg_rr2_body<false, false, true>(nullptr, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax, small_variant, small_L, ci);
+    agg_rr2_body<false, false, true>(nullptr, dst, rec, W, H, Dp, L, chunk_len, nwaves, per_xcd, armmax, small_variant, small_L, ci);
 }
 
 static int env_int(const char* name, int dflt)
@@ -693,6 +694,31 @@ static int pick_nseg(long long nlines, int N, int L, int slots)
     return best;
 }
 
+// Chunk length of the pair-register-ring kernels (a wave = chunk_len consecutive outputs of the line-major index space,
+// k_aggregate_rr2.h).  Candidates: whole-line segmentations N / k and equal shares of the whole pass per wave slot (1x, 2x, 3x
+// the slots); cost model = rounds x (steps + 2L halo entries + a fixed price per piece for its prologue / slow tail).
+static int pick_chunk(long long nlines, int N, int L, int slots)
+{
+    const long long total = nlines * N;
+    long long best_cost = -1;
+    int best = N;
+    auto consider = [&](long long c) {
+        if (c < 1) c = 1;
+        if (c < N && c < 4 * (long long)L) return; // halo-dominated
+        if (c > total) c = total;
+        const long long waves = (total + c - 1) / c;
+        const long long rounds = (waves + slots - 1) / slots;
+        const bool aligned = c >= N ? (c % N == 0) : (N % c == 0);
+        const long long pieces = aligned ? (c >= N ? c / N : 1) : (c >= N ? c / N + 2 : 2);
+        const long long halo = (c < N || !aligned) ? 2LL * L : 0;
+        const long long cost = rounds * (c + halo + 60 * pieces);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = (int)c; }
+    };
+    for (int k = 1; k <= 16; k++) consider((N + k - 1) / k);
+    for (int k = 1; k <= 3; k++) consider((total + (long long)slots * k - 1) / ((long long)slots * k));
+    return best;
+}
+
 // which: 0 = the host does not know the arms: launch the full-ring and the small-ring variant, the kernel decides;
 //        1 = small ring only, 2 = full ring only (the host has read armmax).  PAIR needs which == 1.
 template <bool VERT, bool DIVIDE, bool COSTIN = false, bool PAIR = false>
@@ -702,6 +728,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     const int L = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
     const size_t lds = (size_t)(2 * L + 1) * 64 * sizeof(float);
     if (direct || lds > 150 * 1024) {
+        h->agg_kernel = "k_agg_direct (one thread per volume element, no ring)";
         hipLaunchKernelGGL((k_agg_direct<VERT, DIVIDE>), dim3(256 * 16), dim3(256), 0, h->heavy, src, dst,
                            reinterpret_cast<const uchar4*>(h->arms), VERT ? h->sup_h : h->sup_v, p.W, p.H, p.Dp);
         return hipGetLastError();
@@ -749,14 +776,26 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         ci.lut_ad = h->lut_ad;
         ci.lut_census = h->lut_census;
         ci.rpitch = h->rrec_pitch; ci.padl = h->rrec_padl; ci.dmin = p.dmin; ci.D = p.D;
+        if (!COSTIN) // (which == 0, debug path: both variants are launched and the kernels decide; the label is then the last one)
+            h->agg_kernel = rr2 ? "k_agg_rr2 (register ring of VGPR pairs, 2 disparities per lane, one pass per launch)"
+                          : regring ? (PAIR ? "k_agg_regring_pair (two register rings, dividing pass + next first pass per launch)"
+                                            : "k_agg_regring (register ring, 1 disparity per lane, one pass per launch)")
+                          : variant ? (PAIR ? "k_agg_march<.., PAIR> (LDS small rings: dividing pass + next first pass per launch)"
+                                            : "k_agg_march<.., SMALL> (LDS small ring, one pass per launch)")
+                                    : "k_agg_march (LDS full ring, one pass per launch)";
         if (rr2) {
+            int chunk_len = env_int(VERT ? "ADC_AGG_VCHUNK" : "ADC_AGG_HCHUNK", 0);
+            if (chunk_len < 1) chunk_len = pick_chunk(nlines, N, Lv, 256 * waves_per_cu);
+            const long long total = nlines * N;
+            const int nwaves = (int)((total + chunk_len - 1) / chunk_len);
+            const int pxc = (nwaves + 7) / 8;
             if constexpr (COSTIN)
-                hipLaunchKernelGGL(k_agg_rr2_cost, dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, dst,
-                                   reinterpret_cast<const uint2*>(h->rec2_h), p.W, p.H, p.Dp, Lv, seg_len, nseg, per_xcd, h->armmax, sv, sl, ci);
+                hipLaunchKernelGGL(k_agg_rr2_cost, dim3((unsigned)pxc * 8), dim3(64), ldsv, h->heavy, dst,
+                                   reinterpret_cast<const uint2*>(h->rec2_h), p.W, p.H, p.Dp, Lv, chunk_len, nwaves, pxc, h->armmax, sv, sl, ci);
             else if constexpr (!PAIR)
-                hipLaunchKernelGGL((k_agg_rr2<VERT, DIVIDE>), dim3((unsigned)per_xcd * 8), dim3(64), 0, h->heavy, src, dst,
-                                   reinterpret_cast<const uint2*>(VERT ? h->rec2_v : h->rec2_h), p.W, p.H, p.Dp, Lv, seg_len, nseg,
-                                   per_xcd, h->armmax, sv, sl);
+                hipLaunchKernelGGL((k_agg_rr2<VERT, DIVIDE>), dim3((unsigned)pxc * 8), dim3(64), 0, h->heavy, src, dst,
+                                   reinterpret_cast<const uint2*>(VERT ? h->rec2_v : h->rec2_h), p.W, p.H, p.Dp, Lv, chunk_len, nwaves,
+                                   pxc, h->armmax, sv, sl);
         } else if (regring) {
             if constexpr (COSTIN)
                 hipLaunchKernelGGL(k_agg_regring_cost, dim3((unsigned)per_xcd * 8), dim3(64), ldsv, h->heavy, src, dst,

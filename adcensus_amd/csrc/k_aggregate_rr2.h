@@ -212,7 +212,7 @@ RR_FN rr2_f2 rr2_sum(rr2_f2 acc, int idx, int cnt)
 {
     idx = RR_UNIFORM(idx);
     cnt = RR_UNIFORM(cnt);
-    while (cnt > RR2_BLK) { // rare: 4 % of the spans of a natural image
+    while (__builtin_expect(cnt > RR2_BLK, 0)) { // rare: 4 % of the spans of a natural image (kept out of the fall-through path)
         rr2_run(acc, 2 * (idx + RR2_BLK), 12);
         idx += RR2_BLK;
         cnt -= RR2_BLK;
@@ -221,34 +221,16 @@ RR_FN rr2_f2 rr2_sum(rr2_f2 acc, int idx, int cnt)
     return acc;
 }
 
+// One PIECE: outputs [m0, m1) of line (fixed, chunk).
 template <bool VERT, bool DIVIDE, bool COSTIN>
-RR_FN void agg_rr2_body(const float* __restrict__ src, float* __restrict__ dst,
-                        const uint2* __restrict__ rec, // {lob | span<<8 | count<<16, RN(1/count)}, line-major
-                        int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd, const int* __restrict__ armmax,
-                        int small_variant, int small_L, const AggCostIn& ci)
+RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
+                         const uint2* __restrict__ rec, // {lob | span<<8 | count<<16, RN(1/count)}, line-major
+                         int W, int H, int Dp, int L, int fixed, int chunk, int m0, int m1, float* rr2_lds, const AggCostIn& ci)
 {
-    static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
-    if (small_variant >= 0) { // the host does not know the arms (debug path): see agg_march_body
-        const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
-        if ((small_variant != 0) != fits_small) return;
-    }
     const int R = 2 * L + 1;
     const int lane = RR_LANE;
-    const int chunks = Dp / 128;
     const int N = VERT ? H : W;
-    const int nlines = (VERT ? W : H) * chunks;
-    const int b = RR_BLOCK; // XCD-aware mapping: block b runs on XCD b % 8, each XCD gets a contiguous band of lines
-    const int gw = (b & 7) * per_xcd + (b >> 3);
-    if ((b >> 3) >= per_xcd || gw >= nlines * nseg) return;
-    const int seg = gw / nlines;
-    const int line = gw - seg * nlines;
-    const int fixed = line / chunks;
-    const int chunk = line - fixed * chunks;
-
-    // [m0, m1) = outputs this wave delivers; [lo, hi) = entries it reads
-    const int m0 = seg * seg_len;
-    const int m1 = adc_imin(N, m0 + seg_len);
-    if (m0 >= m1) return;
+    // [m0, m1) = outputs of this piece; [lo, hi) = entries it reads
     const int lo = adc_imax(0, m0 - L);
     const int hi = adc_imin(N, m1 + L);
 
@@ -267,17 +249,12 @@ RR_FN void agg_rr2_body(const float* __restrict__ src, float* __restrict__ dst,
     const uint4* lrow = nullptr;
     int roff = 0;                 // rrow == rbase + roff
     bool pad0 = false, pad1 = false;
-    RR2_LDS_TABLES;
     float* const lutA = rr2_lds;  // A[766] then C[64]
     float* const lutC = rr2_lds + 768;
 #ifdef RR_EMUL
     int win_j = 0;
 #endif
     if constexpr (COSTIN) {
-#ifndef RR_EMUL
-        for (int i = lane; i < 766; i += 64) lutA[i] = ci.lut_ad[i];
-        lutC[lane] = ci.lut_census[lane];
-#endif
         const int d_first = chunk * 128 + ci.dmin;
         pad0 = chunk * 128 + 2 * lane >= ci.D;
         pad1 = chunk * 128 + 2 * lane + 1 >= ci.D;
@@ -361,7 +338,7 @@ RR_FN void agg_rr2_body(const float* __restrict__ src, float* __restrict__ dst,
         i1_ = i1_ < i1_ + (uint32_t)R ? i1_ : i1_ + (uint32_t)R; /* min_u32: wraps a negative index */                \
         const int n1_ = adc_imin(an_, R - (int)i1_);                                                                 \
         rr2_f2 acc_ = rr2_sum(rr2_make(0.0f, 0.0f), (int)i1_, n1_); /* t = -arm .. +arm */                            \
-        if (an_ > n1_) acc_ = rr2_sum(acc_, 0, an_ - n1_);          /* wrapped part */                                \
+        if (__builtin_expect(an_ > n1_, 0)) acc_ = rr2_sum(acc_, 0, an_ - n1_); /* wrapped part */                    \
         if constexpr (DIVIDE) {                                                                                      \
             const float y_ = RR_BITS_TO_F32(RR_READLANE(c1y, (POS)));                                                \
             const float cf_ = (float)(r_ >> 16);                                                                     \
@@ -521,4 +498,45 @@ RR_FN void agg_rr2_body(const float* __restrict__ src, float* __restrict__ dst,
 #undef RR2_SLOT
 #undef RR2_PUSH
 #undef RR2_EMIT
+}
+
+// A wave = one CHUNK of the flattened output index space (line-major: line * N + m), chunk_len outputs: one piece when the
+// chunk lies inside a line, two when it straddles a line end, several whole lines when chunk_len > N.  With
+// chunk_len = ceil(lines * N / wave slots) every slot of the chip gets the same number of steps: a 1080p row pass
+// (1080 lines on 2048 slots) otherwise runs 5 segments per row in 2.6 -> 3 rounds with a 2L halo per segment
+// (17 % more entries read, profiles/r3_hseg_fetch.txt); whole-line segments are the special case N % chunk_len == 0.
+template <bool VERT, bool DIVIDE, bool COSTIN>
+RR_FN void agg_rr2_body(const float* __restrict__ src, float* __restrict__ dst, const uint2* __restrict__ rec, int W, int H, int Dp,
+                        int L, int chunk_len, int nwaves, int per_xcd, const int* __restrict__ armmax, int small_variant, int small_L,
+                        const AggCostIn& ci)
+{
+    static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
+    if (small_variant >= 0) { // the host does not know the arms (debug path): see agg_march_body
+        const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
+        if ((small_variant != 0) != fits_small) return;
+    }
+    const int chunks = Dp / 128;
+    const int N = VERT ? H : W;
+    const long long total = (long long)(VERT ? W : H) * chunks * N;
+    const int b = RR_BLOCK; // XCD-aware mapping: block b runs on XCD b % 8, each XCD gets a contiguous band of chunks
+    const int gw = (b & 7) * per_xcd + (b >> 3);
+    if ((b >> 3) >= per_xcd || gw >= nwaves) return;
+    RR2_LDS_TABLES;
+#ifndef RR_EMUL
+    if constexpr (COSTIN) {
+        for (int i = RR_LANE; i < 766; i += 64) rr2_lds[i] = ci.lut_ad[i];
+        rr2_lds[768 + RR_LANE] = ci.lut_census[RR_LANE];
+    }
+#endif
+    long long c = (long long)gw * chunk_len;
+    const long long c1 = c + chunk_len < total ? c + chunk_len : total;
+#pragma unroll 1
+    while (c < c1) {
+        const int line = (int)(c / N);
+        const int m0 = (int)(c - (long long)line * N);
+        const int m1 = (int)((long long)m0 + (c1 - c) < (long long)N ? (long long)m0 + (c1 - c) : (long long)N);
+        const int fixed = line / chunks;
+        agg_rr2_piece<VERT, DIVIDE, COSTIN>(src, dst, rec, W, H, Dp, L, fixed, line - fixed * chunks, m0, m1, rr2_lds, ci);
+        c += m1 - m0;
+    }
 }

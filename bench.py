@@ -4,30 +4,41 @@
 A "step" = one full `Match` (cost volume -> 4x cross aggregation -> 4 scanline passes -> L/R WTA -> multi-step
 refinement) of one 1920x1080, D=128 stereo pair whose images are already resident in HBM (adc_match_device); the
 disparity map stays in HBM.  The timed region is a FARM over a batch of DISTINCT pairs (BASELINE.json configs[4],
-SURVEY.md 8d config 5): batch = steps x ranks pairs, pair i = the seeded synthetic pair 12345 + i, rank r takes the
-pairs i = r (mod ranks) (adcensus_amd/farm.py), `--inflight` pipelines per GPU.  There is no data-path collective:
-RCCL is used for the barriers, the MAX over ranks of the elapsed time, the SUM of the done counter and an all-gather of
-one SHA-256 per pair.  After the timed region every rank recomputes the pairs of its neighbour rank (untimed), so each
-output of the batch is compared with the same pair computed on another GPU (N = 1: computed a second time), and with
-the committed table of 1-GPU outputs (tests/golden/farm_digests.json) when the size matches.
+SURVEY.md 8d config 5), pair i = the seeded synthetic pair 12345 + i:
+  default       weak scaling: batch = steps x ranks pairs, static partition (rank r takes the pairs i = r mod ranks),
+                every GPU does exactly `steps` pairs;
+  --batch B     strong scaling = configs[4] literally: a FIXED batch of B pairs (64), every rank holds all B pairs in its
+                HBM and PULLS the next pair index from one shared counter on the job's rendezvous store
+                (adcensus_amd/farm.py PullQueue; a failed Match is re-queued and the rank retires).  steps := B.
+`--inflight` pipelines (ADCensusStereo objects on separate streams) per GPU: default 1 for one GPU (clean per-kernel
+timings for the roofline), 2 for several.  There is no data-path collective: RCCL carries the barriers, the MAX over ranks
+of the elapsed time, the SUM of the done counter and an all-gather of one SHA-256 per pair.  After the timed region every
+output of the batch is recomputed on another GPU (N = 1: a second time) and the digests compared; they are also compared
+with the committed table of 1-GPU outputs of this product (tests/golden/farm_digests.json) when the size matches.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline       the aggregation kernel (K4).  achieved = ALGORITHMIC bytes per regular launch (one pass =
-                 2V + 4P arm records [+ 2P support counts on dividing passes], V = 4*W*H*D; a pass-pair launch does two
-                 passes of work) / average launch duration from HIP events on the handle's own stream inside the timed
-                 region.  hbm_achieved = the bytes that launch really moves (a pair launch reads V and writes V once) /
-                 the same duration; traffic = those bytes as measured by rocprofv3 PMC passes (profiles/, None when the
-                 committed measurement does not match this build); device_copy_GBps = a device-to-device copy of one
-                 volume measured after the timed region (the practical ceiling next to the 8 TB/s spec peak).
+  roofline       the aggregation kernel (K4): achieved = the bytes a regular launch really moves through HBM (read V +
+                 write V + records; a pass-pair launch does that once for two passes of work) / the average launch
+                 duration from HIP events on the handle's own stream inside the timed region; frac = achieved / 8 TB/s
+                 (<= 1 by construction).  algorithmic_achieved / algorithmic_frac = the SURVEY.md 8d numerator (every
+                 algorithmic pass counted with 2V + 4P [+ 2P]: exceeds the real traffic when launches fuse passes).
+                 traffic = PMC bytes per launch (profiles/r3_k4_pmc_traffic_<workload>.json; None unless that file was
+                 measured on exactly these kernel sources -- SHA-256 of k_aggregate*.{hip,h}).  device_copy_GBps = a
+                 device-to-device copy of one volume measured after the timed region (the practical ceiling).
+  stage_roofline HBM fractions of the scanline stage (4 x (2V + 3P)), the right-view WTA (V) and the whole Match
+                 (26 V = 27.6 GB) from the stage timings / ms_per_step.
   structured     (N = 1) the same measurement on the SURVEY 8d "structured" pair (natural-image-like arms / voting load).
-  host_inclusive (N = 1) the drop-in entry point adc_match(left, right, disp) with pageable host buffers: pinned staging
-                 copies + H2D + kernels + D2H + copy-out (ADCensusStereo.cpp:69-132 incl. the memcpy at :125).
+  host_inclusive (N = 1) the drop-in entry point adc_match(left, right, disp) with pageable host buffers.
+  host_farm      the persistent farm of the C ABI (adc_farm_*) fed from pageable host buffers (N > 1: every rank feeds its
+                 share of the batch that way in a second timed region -- what configs[4] describes; PCIe inclusive, never `value`).
   throughput_mode (N = 1) the same batch with 3 pipelines in flight per GPU.
+  scaling_reference (N > 1) rank 0 ALONE on its GPU with the same pairs per GPU and the same number of pipelines, measured
+                 after the farm (the other ranks idle at a barrier): the 1-GPU number this box gives for the N-GPU line.
   cpu_baseline   the reference CPU path (oracle/_ref, kind "reference"; the plain-C port if absent) timed on this host,
-                 1 thread, on a bounded row-strip sample of the same pair.
+                 1 thread, on the WHOLE pair 0 of the batch (--cpu-rows R: the top R rows, scaled).
 """
 import argparse
 import json
@@ -42,7 +53,18 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-K4_REV = "r2-rr1"  # bumped whenever the aggregation kernels change: a committed PMC measurement of another revision is stale
+K4_SOURCES = ("k_aggregate.hip", "k_aggregate_rr.h", "k_aggregate_rr2.h")
+
+
+def k4_source_hash():
+    """SHA-256 (first 16 hex digits) over the aggregation kernel sources: a committed PMC measurement is only reported
+    as `roofline.traffic` when it was taken on exactly these sources (tools/pmc_summary.py stores the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in K4_SOURCES:
+        with open(os.path.join(ROOT, "adcensus_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -55,8 +77,13 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--disp", type=int, default=128)
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ADC_BENCH_INFLIGHT", "1")),
-                    help="ADCensusStereo objects (streams) in flight per GPU in the timed region")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ADC_BENCH_INFLIGHT", "0")),
+                    help="ADCensusStereo objects (streams) in flight per GPU in the timed region (0 = 1 for one GPU, 2 for several)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="fixed batch of B distinct pairs farmed over all GPUs through the pull queue (strong scaling, "
+                         "BASELINE.json configs[4]: --batch 64); 0 = steps x ranks pairs, static partition (weak scaling)")
+    ap.add_argument("--queue", default="", choices=["", "static", "pull"], help="how the batch is handed out (default: pull with --batch, else static)")
+    ap.add_argument("--no-host-leg", action="store_true", help="N > 1: skip the second timed region fed from host buffers (adc_farm_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the structured / host-inclusive / throughput legs")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample strip (0 = the whole frame, ~20 s)")
@@ -89,6 +116,13 @@ class Matcher:
                 raise SystemExit("Initialize failed: " + A.last_error())
             self.handles.append(st)
         self.buf = {}  # pair id -> (d_left, d_right, d_disp)
+        self.soft_fail = False  # True: a failed Match raises farm.MatchFailed (pull queue: re-queue + retire) instead of aborting
+
+    def _fail(self, what):
+        if self.soft_fail:
+            from adcensus_amd import farm
+            raise farm.MatchFailed(what + ": " + self.A.last_error())
+        raise SystemExit(what + ": " + self.A.last_error())
 
     def upload(self, pid, left, right):
         lib, P = self.lib, self.P
@@ -100,11 +134,11 @@ class Matcher:
     def submit(self, slot, pid):
         dl, dr, dd = self.buf[pid]
         if not self.handles[slot].match_device(dl, dr, dd):
-            raise SystemExit("Match failed: " + self.A.last_error())
+            self._fail("Match failed")
 
     def wait(self, slot):
         if not self.handles[slot].wait():
-            raise SystemExit("Match failed: " + self.A.last_error())
+            self._fail("Match failed")
 
     def output(self, pid):
         out = np.empty((self.H, self.W), np.float32)
@@ -126,6 +160,28 @@ class Matcher:
             st.Release()
 
 
+class HostFedMatcher:
+    """The persistent farm of the C ABI (adc_farm_*: pinned staging ring, asynchronous submit, ordered delivery) fed with
+    pageable host images, delivering into pageable host maps -- the N > 1 runner of BASELINE.json configs[4]."""
+
+    def __init__(self, A, device, W, H, D, inflight, pairs):
+        self.A, self.W, self.H = A, W, H
+        self.farm = A.PairFarm(W, H, A.ADCensusOption(min_disparity=0, max_disparity=D), device=device, pipelines=max(1, inflight))
+        self.pairs = pairs  # pid -> (left, right) host arrays
+        self.out = {pid: np.empty((H, W), np.float32) for pid in pairs}
+        self.ticket = {}
+
+    def submit(self, slot, pid):
+        l, r = self.pairs[pid]
+        self.ticket[slot] = self.farm.submit(l, r, self.out[pid])
+
+    def wait(self, slot):
+        self.farm.wait(self.ticket.pop(slot))
+
+    def release(self):
+        self.farm.close()
+
+
 def make_pair(workload, W, H, D, pid):
     from adcensus_amd import workloads
     if workload == "noise":
@@ -133,7 +189,24 @@ def make_pair(workload, W, H, D, pid):
     return workloads.structured_pair(W, H, D, seed=777 + pid)
 
 
-def k4_roofline(prof, W, H, D, lib, workload):
+def device_copy_rate(lib, nbytes):
+    """Device-to-device copy of one volume (read nbytes + write nbytes), GB/s, or None."""
+    try:
+        ca, cb = lib.adc_device_malloc(nbytes), lib.adc_device_malloc(nbytes)
+        rate = None
+        if ca and cb:
+            t = lib.adc_device_copy_ms(cb, ca, nbytes, 5)
+            if t > 0:
+                rate = round(2.0 * nbytes / (t * 1e-3) / 1e9, 1)
+        for q in (ca, cb):
+            if q:
+                lib.adc_device_free(q)
+        return rate
+    except Exception:
+        return None
+
+
+def k4_roofline(prof, W, H, D, lib, workload, kernel=None, in_flight=1):
     """prof: list of aggregate_info() tuples of the profiled handle, one per timed Match."""
     P = float(W) * H
     V = 4.0 * P * D
@@ -142,70 +215,150 @@ def k4_roofline(prof, W, H, D, lib, workload):
         return None
     ms = float(np.mean([p[0] for p in prof]))
     launches, passes, fused = prof[-1][1], prof[-1][2], prof[-1][3]
-    # algorithmic bytes of the regular launches: every pass 2V + 4P; the dividing ones (4 of 8, all regular) + 2P
+    # algorithmic bytes of the regular launches (SURVEY.md 8d): every pass 2V + 4P; the dividing ones (4 of 8, all regular) + 2P
     alg_total = passes * (2.0 * V + 4.0 * P) + 4 * 2.0 * P
     hbm_total = launches * (2.0 * V + 4.0 * P) + 4 * 2.0 * P  # a pair launch still reads V and writes V once
     alg_per_launch, hbm_per_launch = alg_total / launches, hbm_total / launches
-    achieved = alg_per_launch / (ms * 1e-3) / 1e9
+    alg = alg_per_launch / (ms * 1e-3) / 1e9
     hbm = hbm_per_launch / (ms * 1e-3) / 1e9
-    copy_gbps = None
-    try:
-        nb = int(V)
-        ca, cb = lib.adc_device_malloc(nb), lib.adc_device_malloc(nb)
-        if ca and cb:
-            t = lib.adc_device_copy_ms(cb, ca, nb, 5)
-            if t > 0:
-                copy_gbps = round(2.0 * nb / (t * 1e-3) / 1e9, 1)
-        for q in (ca, cb):
-            if q:
-                lib.adc_device_free(q)
-    except Exception:
-        copy_gbps = None
+    copy_gbps = device_copy_rate(lib, int(V))
     pairs = passes > launches
-    kern = ("k_agg_march<.., PAIR> (LDS rings, short-arm image: a launch = dividing pass + next first pass)" if pairs and workload == "noise"
-            else ("k_agg_regring_pair" if pairs else "k_agg_regring (register ring, one pass per launch)"))
-    return {"kernel": kern, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic(workload, (W, H, D)),
-            "algorithmic_bytes_per_launch": alg_per_launch, "passes_per_launch": round(passes / float(launches), 3),
-            "regular_launches": launches, "first_pass_fused_with_cost": bool(fused),
-            "hbm_bytes_per_launch": hbm_per_launch, "hbm_achieved": round(hbm, 2), "hbm_frac": round(hbm / 8000.0, 4),
-            "avg_launch_ms": round(ms, 5), "device_copy_GBps": copy_gbps,
-            "hbm_frac_of_device_copy": round(hbm / copy_gbps, 4) if copy_gbps else None}
+    if not kernel:
+        kernel = "pass-pair launches" if pairs else "one pass per launch"
+    traffic = pmc_traffic(workload, (W, H, D))
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(hbm, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(hbm / 8000.0, 4), "traffic": traffic,
+            "bytes_per_launch": hbm_per_launch, "avg_launch_ms": round(ms, 5), "regular_launches": launches,
+            "passes_per_launch": round(passes / float(launches), 3), "first_pass_fused_with_cost": bool(fused),
+            "algorithmic_bytes_per_launch": alg_per_launch, "algorithmic_achieved": round(alg, 2),
+            "algorithmic_frac": round(alg / 8000.0, 4),
+            "traffic_over_bytes": round(traffic / hbm_per_launch, 4) if traffic else None,
+            "device_copy_GBps": copy_gbps, "frac_of_device_copy": round(hbm / copy_gbps, 4) if copy_gbps else None,
+            "in_flight_while_measured": in_flight,
+            "note": "achieved = HBM bytes a regular launch moves (read V + write V + records) / HIP-event launch-to-launch time; "
+                    "algorithmic_* = SURVEY 8d numerator (2V+4P[+2P] per algorithmic pass; a pass-pair launch covers two)"}
 
 
-def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair_ids, dist=None, tensor_device="cpu"):
-    """Uploads the pairs, runs warm-up + the timed farm region; returns (matcher, elapsed, total, stage_ms, roofline-prof)."""
+def stage_roofline(stage, ms_per_step, W, H, D):
+    """HBM fractions of the other volume stages from the stage timings (events on the handle's stream) and of the whole Match."""
+    P = float(W) * H
+    V = 4.0 * P * D
+    out = {}
+
+    def frac(nbytes, ms):
+        return {"bytes": nbytes, "ms": round(ms, 4), "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac": round(nbytes / (ms * 1e-3) / 8e12, 4)}
+    if stage.get("scanline", 0) > 0:
+        out["scanline_K5"] = dict(frac(4 * (2.0 * V + 3.0 * P), stage["scanline"]), what="4 chained DP passes, each reads V + writes V + 3P of penalty inputs")
+    if stage.get("wta", 0) > 0:
+        out["wta_right_K6"] = dict(frac(V, stage["wta"]), what="right-view winner-takes-all: one read of V (the left view rides on the last scanline pass)")
+    if stage.get("aggregate", 0) > 0:
+        out["aggregate_K4_stage_algorithmic"] = dict(frac(16.0 * V + 40.0 * P, stage["aggregate"]),
+                                                     what="SURVEY 8d stage figure: 8 passes x (2V + 4P) + 8P = 17.07 GB at 1080p / stage time (target >= 0.60)")
+    if ms_per_step and ms_per_step > 0:
+        out["whole_match"] = dict(frac(26.0 * V, ms_per_step), what="SURVEY 8d whole-pipeline model 26 V (27.6 GB at 1080p/128) / ms_per_step")
+    return out
+
+
+def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair_ids, dist=None, tensor_device="cpu",
+                     queue_factory=None, host_pairs=None):
+    """Uploads the pairs, runs warm-up + the timed farm region; returns (matcher, elapsed, total, stage_ms, roofline-prof).
+    queue_factory: None = static list `pair_ids` repeated to `steps`; else a callable returning a farm.PullQueue for the
+    timed region (the batch = range(queue.n): every pair must be in `pair_ids`)."""
     from adcensus_amd import farm
-    m = Matcher(A, device, W, H, D, inflight)
-    for pid in pair_ids:
-        l, r = make_pair(workload, W, H, D, pid)
-        m.upload(pid, l, r)
-    m.handles[0].set_profiling(True)
+    if host_pairs is not None:
+        m = HostFedMatcher(A, device, W, H, D, inflight, host_pairs)
+    else:
+        m = Matcher(A, device, W, H, D, inflight)
+        for pid in pair_ids:
+            l, r = make_pair(workload, W, H, D, pid)
+            m.upload(pid, l, r)
+        m.handles[0].set_profiling(True)
     prof, stages = [], []
+    m.mine, m.retired = list(pair_ids), False
+
+    def on_collected(slot):
+        if slot == 0 and host_pairs is None:
+            prof.append(m.handles[0].aggregate_info())
+            stages.append(m.handles[0].stage_ms())
+
+    def wait(slot):
+        m.wait(slot)
+        on_collected(slot)
 
     def run(n):
+        if queue_factory is not None and run.timed:
+            m.soft_fail = True
+            m.mine, m.retired = farm.run_queue(queue_factory(), m.submit, wait, inflight)
+            m.soft_fail = False
+            return
         ids = [pair_ids[i % len(pair_ids)] for i in range(n)]
-
-        def wait(slot):
-            m.wait(slot)
-            if slot == 0:
-                prof.append(m.handles[0].aggregate_info())
-                stages.append(m.handles[0].stage_ms())
         farm.run_pairs(ids, m.submit, wait, inflight)
+    run.timed = False
 
-    elapsed, total = farm.timed_region(run, steps, warmup, dist=dist, device_sync=m.lib.adc_device_synchronize,
-                                       tensor_device=tensor_device)
+    def run_timed(n):
+        run.timed = True
+        run(n)
+    if warmup > 0:
+        run(warmup)
+    sync = m.lib.adc_device_synchronize if host_pairs is None else A.lib().adc_device_synchronize
+    elapsed, total = farm.timed_region(run_timed, steps, 0, dist=dist, device_sync=sync, tensor_device=tensor_device)
+    if queue_factory is not None:  # the units really processed: this rank's share of the batch, SUMmed over the ranks
+        total = farm.done_counter(len(m.mine), dist, tensor_device)
     keep = max(1, (steps + inflight - 1) // inflight)
-    # how often adc_wait had to complete an assumption of the asynchronous pipeline (warm-up + timed region, all pipelines)
     m.fallbacks = {"median_handoff": 0, "voting_continuations": 0, "aggregation_redos": 0, "matches": warmup + steps}
-    for st in m.handles:
-        for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2)):
-            m.fallbacks[key] += int(st.debug_counter(which))
+    if host_pairs is None:
+        # how often adc_wait had to complete an assumption of the asynchronous pipeline (warm-up + timed region, all pipelines)
+        for st in m.handles:
+            for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2)):
+                m.fallbacks[key] += int(st.debug_counter(which))
     return m, elapsed, total, stages[-keep:], prof[-keep:]
 
 
 def mean_stages(stages):
     return {k: round(float(np.mean([s[k] for s in stages])), 4) for k in stages[0]} if stages else {}
+
+
+def init_dist(world, local_rank):
+    """torch.distributed for world > 1 (or ADC_BENCH_FORCE_DIST=1).  Returns (dist, backend label, tensor device, local_rank,
+    what the communicator itself reports)."""
+    # torch first: its bundled HIP runtime (same SONAME) is then shared by the C-ABI library
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    backend = os.environ.get("ADC_BENCH_BACKEND", "nccl")  # "gloo": test hook (several ranks on one GPU)
+    tensor_device = "cpu"
+    seen = None
+    if backend == "nccl":
+        # RCCL carries a barrier, a few scalar all-reduces and one all-gather of digests: nothing of the data path.  If
+        # the communicator cannot be created on this node, the same calls run over gloo instead of failing the job
+        try:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            seen = int(probe.item())  # the number of ranks that took part in an RCCL all-reduce
+            assert seen == int(os.environ["WORLD_SIZE"])
+            tensor_device = "cuda"
+        except Exception as exc:  # noqa: BLE001
+            print("bench.py: RCCL initialisation failed (%s: %s); falling back to gloo" % (type(exc).__name__, exc), file=sys.stderr)
+            try:
+                dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+            backend = "gloo (RCCL failed)"
+            dist.init_process_group(backend="gloo")
+    else:
+        local_rank = int(os.environ.get("ADC_BENCH_DEVICE", local_rank))
+        dist.init_process_group(backend=backend)
+    if seen is None:
+        probe = torch.ones(1)
+        dist.all_reduce(probe)
+        seen = int(probe.item())
+    return dist, backend, tensor_device, local_rank, {"backend": backend, "world_size": dist.get_world_size(), "ranks_in_all_reduce": seen}
 
 
 def main():
@@ -220,58 +373,44 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    tensor_device = "cpu"
-    backend = None
+    dist, tensor_device, backend, comm = None, "cpu", None, None
     if world > 1 or os.environ.get("ADC_BENCH_FORCE_DIST") == "1":  # (FORCE_DIST: exercise the RCCL calls with one rank)
-        # torch first: its bundled HIP runtime (same SONAME) is then shared by the C-ABI library
-        import torch
-        import torch.distributed as _dist
-        dist = _dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("ADC_BENCH_BACKEND", "nccl")  # "gloo": test hook (several ranks on one GPU)
-        if backend == "nccl":
-            # RCCL carries a barrier, two scalar all-reduces and one all-gather of digests: nothing of the data path.  If
-            # the communicator cannot be created on this node, the same four calls run over gloo instead of failing the job
-            try:
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                probe = torch.ones(1, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                assert int(probe.item()) == int(os.environ["WORLD_SIZE"])
-                tensor_device = "cuda"
-            except Exception as exc:  # noqa: BLE001
-                print("bench.py: RCCL initialisation failed (%s: %s); falling back to gloo" % (type(exc).__name__, exc), file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                backend = "gloo (RCCL failed)"
-                dist.init_process_group(backend="gloo")
-        else:
-            local_rank = int(os.environ.get("ADC_BENCH_DEVICE", local_rank))
-            dist.init_process_group(backend=backend)
+        dist, backend, tensor_device, local_rank, comm = init_dist(world, local_rank)
     import adcensus_amd as A
     from adcensus_amd import farm
     lib = A.lib()
     if A.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible")
     W, H, D = a.width, a.height, a.disp
-    F = max(1, a.inflight)
+    F = a.inflight if a.inflight > 0 else (1 if world == 1 else 2)
+    strong = a.batch > 0
+    mode = a.queue or ("pull" if strong else "static")
 
-    # ---- the batch: steps x ranks distinct pairs, partitioned round-robin over the ranks (weak scaling)
-    batch = a.steps * world
-    mine = farm.partition(batch, world, rank)
-    m, elapsed, total, stages, prof = measure_workload(A, local_rank, W, H, D, a.workload, a.steps, a.warmup, F, mine,
-                                                       dist=dist, tensor_device=tensor_device)
-    # ---- verification (untimed): digests of this rank's outputs, recomputation of the neighbour rank's pairs
-    primary = {pid: farm.digest(m.output(pid).tobytes()) for pid in mine}
+    # ---- the batch
+    if strong:
+        batch, steps = a.batch, a.batch  # a step = one pair of the fixed batch (whole job)
+    else:
+        batch, steps = a.steps * world, a.steps
+    if mode == "pull":
+        mine = list(range(batch))  # every rank holds every pair: any rank may pull any index
+        qname = "timed"
+
+        def queue_factory():
+            store = farm.job_store(dist, qname) if dist is not None else queue_factory.local
+            return farm.PullQueue(store, batch, world=world)
+        queue_factory.local = farm.LocalStore()
+    else:
+        mine = farm.partition(batch, world, rank)
+        queue_factory = None
+    m, elapsed, total, stages, prof = measure_workload(A, local_rank, W, H, D, a.workload, steps if mode == "static" else batch, a.warmup, F, mine,
+                                                       dist=dist, tensor_device=tensor_device, queue_factory=queue_factory)
+    computed = list(m.mine) if mode == "pull" else mine
+    # ---- verification (untimed): digests of this rank's outputs, recomputation on another GPU
+    primary = {pid: farm.digest(m.output(pid).tobytes()) for pid in computed}
+    all_primary = farm.gather_digests(primary, dist)
+    todo = farm.recheck_assignment(all_primary, rank) if mode == "pull" else farm.neighbour_pairs(batch, world, rank)
     recheck = {}
-    for pid in farm.neighbour_pairs(batch, world, rank):
+    for pid in ([] if m.retired else todo):
         own = pid in m.buf
         if not own:
             l, r = make_pair(a.workload, W, H, D, pid)
@@ -284,8 +423,10 @@ def main():
         if not own:
             m.free(pid)
     done = farm.done_counter(len(primary), dist, tensor_device)
-    all_primary, all_recheck = farm.gather_digests(primary, dist), farm.gather_digests(recheck, dist)
+    all_recheck = farm.gather_digests(recheck, dist)
+    retired = farm.done_counter(1 if m.retired else 0, dist, tensor_device)
 
+    out = None
     if rank == 0:
         ref_table = None
         ref_path = os.path.join(ROOT, "tests", "golden", "farm_digests.json")
@@ -296,32 +437,67 @@ def main():
                 ref_table = t["digests"]
         check = farm.cross_check(all_primary, all_recheck, ref_table)
         check["done_counter"] = done
+        check["retired_ranks"] = retired
+        check["pairs_per_rank"] = [len(d) for d in all_primary]
         check["ok"] = (done == batch and check["pairs"] == batch and not check["duplicates"] and not check["mismatches"]
-                       and not check["reference_mismatches"])
+                       and not check["committed_1gpu_mismatches"])
         if a.write_digests and world == 1:
             with open(a.write_digests, "w") as f:
                 json.dump({"workload": a.workload, "size": [W, H, D], "generator": "python bench.py --steps %d --write-digests ... (1 GPU)" % a.steps,
                            "digests": {str(k): v for k, v in sorted(primary.items())}}, f, indent=1, sort_keys=True)
         value = total / elapsed
         stage = mean_stages(stages)
+        ms_per_step = 1000.0 * elapsed / steps
         sizes = {(1920, 1080, 128): " (BASELINE.json configs[3])" if a.workload == "noise" else " (size of BASELINE.json configs[3], SURVEY 8d structured pair)",
                  (1242, 375, 128): " (size of BASELINE.json configs[2])", (450, 375, 64): " (size of BASELINE.json configs[1])"}
         out = {
             "metric": "stereo pairs/s at %dx%d D=%d (ADCensusStereo::Match, images and disparity map resident in HBM)" % (W, H, D),
-            "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1000.0 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d D=%d%s" % (a.workload, W, H, D, sizes.get((W, H, D), "")),
-                       "batch": "%d distinct pairs (seeds 12345+i), %d per GPU" % (batch, a.steps),
-                       "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs, round-robin partition)" % world,
-                       "comm_backend": (backend if dist is not None else None)},
+                       "batch": ("fixed batch of %d distinct pairs (seeds 12345+i) over %d GPU(s) = BASELINE.json configs[4]; a step = one pair of the batch" % (batch, world)) if strong
+                                else "%d distinct pairs (seeds 12345+i), %d per GPU" % (batch, a.steps),
+                       "queue": "pull (shared counter on the rendezvous store, re-queue on failure)" if mode == "pull" else "static round-robin partition",
+                       "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs)" % world,
+                       "comm_backend": (backend if dist is not None else None), "comm": comm},
             "farm_check": check,
             "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
             "stage_ms": stage,
-            "roofline": k4_roofline(prof, W, H, D, lib, a.workload),
+            "roofline": k4_roofline(prof, W, H, D, lib, a.workload, m.handles[0].aggregate_kernel(), F),
+            # (per-GPU time per Match: weak scaling = ms_per_step, strong = ms_per_step x ranks)
+            "stage_roofline": dict(stage_roofline(stage, ms_per_step * (world if strong else 1), W, H, D),
+                                   **({} if F == 1 else {"note": "%d pipelines in flight: stage times include co-running kernels of other pairs; whole_match is a throughput figure" % F})),
             "async_fallbacks": m.fallbacks,
         }
+    host_pairs_all = None
     m.release()
+
+    # ---- N > 1: the same farm fed from pageable host buffers through adc_farm_* (PCIe inclusive; never `value`)
+    if world > 1 and not a.no_host_leg:
+        ids = list(range(batch)) if mode == "pull" else mine
+        host_pairs_all = {pid: make_pair(a.workload, W, H, D, pid) for pid in ids}
+        qf2 = None
+        if mode == "pull":
+            def qf2():
+                return farm.PullQueue(farm.job_store(dist, "hostfed"), batch, world=world)
+        mh, eh, th, _, _ = measure_workload(A, local_rank, W, H, D, a.workload, steps if mode == "static" else batch, min(a.warmup, 2), F, ids,
+                                            dist=dist, tensor_device=tensor_device, queue_factory=qf2, host_pairs=host_pairs_all)
+        mh.release()
+        if rank == 0:
+            out["host_farm"] = {"value": round(th / eh, 4), "unit": "pairs/s", "pipelines_per_gpu": F, "n_gpus": world,
+                                "entry_point": "adc_farm_submit / adc_farm_wait on every rank: pageable host images in, pageable host maps out "
+                                               "(pinned staging + H2D + kernels + D2H + copy-out inside the timed region)"}
+        host_pairs_all = None
+    # ---- N > 1: rank 0 alone with the same per-GPU load (the others wait at the barrier)
+    if world > 1:
+        if rank == 0:
+            n1 = steps if not strong else max(1, batch // world)
+            m1, e1, t1, _, _ = measure_workload(A, local_rank, W, H, D, a.workload, n1, min(a.warmup, 2), F, list(range(min(n1, 16))))
+            out["scaling_reference"] = {"n_gpus": 1, "in_flight_per_gpu": F, "pairs": n1, "value": round(t1 / e1, 4), "unit": "pairs/s",
+                                        "note": "rank 0 alone on its GPU, same pipelines and pairs per GPU, measured after the farm in the same process"}
+            m1.release()
+        dist.barrier()
 
     if rank == 0 and world == 1 and not a.no_extra_legs:
         other = "structured" if a.workload == "noise" else "noise"
@@ -331,7 +507,8 @@ def main():
         s2 = mean_stages(st2)
         out[other] = {"value": round(t2 / e2, 4), "unit": "pairs/s", "ms_per_step": round(1000.0 * e2 / n2, 4), "steps": n2,
                       "workload": "%s %dx%d D=%d (one pair repeated)" % (other, W, H, D), "stage_ms": s2,
-                      "roofline": k4_roofline(pf2, W, H, D, lib, other), "async_fallbacks": m2.fallbacks}
+                      "roofline": k4_roofline(pf2, W, H, D, lib, other, m2.handles[0].aggregate_kernel(), 1),
+                      "stage_roofline": stage_roofline(s2, 1000.0 * e2 / n2, W, H, D), "async_fallbacks": m2.fallbacks}
         m2.release()
         # ---- the drop-in entry point with pageable host buffers
         out["host_inclusive"] = host_inclusive_leg(A, local_rank, W, H, D, a.workload, max(5, min(10, a.steps)))
@@ -398,14 +575,14 @@ def host_farm_leg(A, device, W, H, D, workload, n):
 def pmc_traffic(workload, whd):
     """HBM bytes per aggregation launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
     separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md).  None when not collected for this workload / size
-    or when it was collected on another revision of the aggregation kernels (K4_REV)."""
+    or when it was collected on other aggregation kernel sources (k4_source_hash)."""
     if whd != (1920, 1080, 128):
         return None
-    p = os.path.join(ROOT, "profiles", "r2_k4_pmc_traffic_%s.json" % workload)
+    p = os.path.join(ROOT, "profiles", "r3_k4_pmc_traffic_%s.json" % workload)
     try:
         with open(p) as f:
             o = json.load(f)
-        if o.get("k4_rev") != K4_REV:
+        if o.get("k4_src_sha16") != k4_source_hash():
             return None
         return float(o["traffic_bytes_per_launch_avg"])
     except Exception:

@@ -141,6 +141,8 @@ int adc_get_aggregate_pass_ms(adc_handle* h, float* avg_ms, int* launches);
  * left out when it computed the matching cost itself: first_fused = 1, write-only), and the number of algorithmic
  * passes (cross_aggregator.cpp:100-118, two per iteration) those launches covered -- a pass-pair launch covers two. */
 int adc_get_aggregate_info(adc_handle* h, float* avg_launch_ms, int* launches, int* passes, int* first_fused);
+/* Name of the kernel family the last regular aggregation launch of the handle used (static string, "" before the first Match). */
+const char* adc_get_aggregate_kernel(adc_handle* h);
 
 /* Print the reference's six timing lines from Match (ADCensusStereo.cpp:88-129); default off. */
 void adc_set_verbose(adc_handle* h, int on);

@@ -70,7 +70,7 @@ extern "C" int emul_rr_pass(const float* src_hwd, float* dst_hwd, const uint8_t*
 // third generation (k_aggregate_rr2.h): two disparities per lane, ring slots = VGPR pairs, packed adds; optionally the
 // fused matching cost (COSTIN) from packed pixel records built exactly as k_cost_records builds them (k_cost.hip)
 template <bool VERT, bool DIVIDE, bool COSTIN>
-static void run_grid2(const float* src, float* dst, const uint2* rec, int W, int H, int Dp, int L, int seg_len, int nseg, int per_xcd,
+static void run_grid2(const float* src, float* dst, const uint2* rec, int W, int H, int Dp, int L, int chunk_len, int nwaves, int per_xcd,
                       const AggCostIn& ci)
 {
     const int armmax[2] = {L, L};
@@ -79,13 +79,13 @@ static void run_grid2(const float* src, float* dst, const uint2* rec, int W, int
             rr_emul.block = b;
             rr_emul.lane = lane;
             for (int i = 0; i < 256; i++) rr_emul.vgpr[i] = NAN;
-            agg_rr2_body<VERT, DIVIDE, COSTIN>(src, dst, rec, W, H, Dp, L, seg_len, nseg, per_xcd, armmax, -1, 0x7fffffff, ci);
+            agg_rr2_body<VERT, DIVIDE, COSTIN>(src, dst, rec, W, H, Dp, L, chunk_len, nwaves, per_xcd, armmax, -1, 0x7fffffff, ci);
         }
 }
 
 // costin != 0: src_hwd is ignored, the pass computes the cost from the images / census words (first pass: H, non-dividing)
 extern "C" int emul_rr2_pass(const float* src_hwd, float* dst_hwd, const uint8_t* arms, const uint16_t* sup, int W, int H, int D,
-                             int vert, int divide, int L, int nseg, int costin, const uint8_t* img_l, const uint8_t* img_r,
+                             int vert, int divide, int L, int chunk_len, int costin, const uint8_t* img_l, const uint8_t* img_r,
                              const uint64_t* cen_l, const uint64_t* cen_r, int dmin, int lambda_ad, int lambda_census)
 {
     if (2 * L + 1 > RR2_SLOTS || L < 1) return 1;
@@ -130,12 +130,13 @@ extern "C" int emul_rr2_pass(const float* src_hwd, float* dst_hwd, const uint8_t
         ci.rrec = rrec.data(); ci.lrec = lrec.data(); ci.lut_ad = nullptr; ci.lut_census = nullptr;
         ci.rpitch = pitch; ci.padl = padl; ci.dmin = dmin; ci.D = D;
     }
-    int seg_len = (N + nseg - 1) / nseg;
-    if (seg_len < 1) seg_len = 1;
-    nseg = (N + seg_len - 1) / seg_len;
+    // launch geometry as launch_pass computes it: a wave = chunk_len outputs of the line-major index space
     const long long nlines = (long long)(vert ? W : H) * (Dp / 128);
-    const int per_xcd = (int)((nlines * nseg + 7) / 8);
-#define RUN2(V, DV, CI) run_grid2<V, DV, CI>(a.data(), bvol.data(), rec.data(), W, H, Dp, L, seg_len, nseg, per_xcd, ci)
+    const long long total = nlines * N;
+    if (chunk_len < 1) chunk_len = N;
+    const int nwaves = (int)((total + chunk_len - 1) / chunk_len);
+    const int per_xcd = (nwaves + 7) / 8;
+#define RUN2(V, DV, CI) run_grid2<V, DV, CI>(a.data(), bvol.data(), rec.data(), W, H, Dp, L, chunk_len, nwaves, per_xcd, ci)
     if (costin) RUN2(false, false, true);
     else if (vert) { if (divide) RUN2(true, true, false); else RUN2(true, false, false); }
     else { if (divide) RUN2(false, true, false); else RUN2(false, false, false); }

@@ -123,11 +123,13 @@ RR2_CASES = RR_CASES + ["s2_320x180_d128", "s2_200x120_d200", "noise_160x90_d128
 
 
 @pytest.mark.parametrize("name", RR2_CASES)
-@pytest.mark.parametrize("hseg,vseg,fused", [(1, 1, True), (3, 2, True), (2, 5, False)])
-def test_register_ring_pairs_body(emul, dumps, name, hseg, vseg, fused):
+@pytest.mark.parametrize("hchunk,vchunk,fused", [(0, 0, True), (37, 23, True), (1000, 7, False), (13, 250, True)])
+def test_register_ring_pairs_body(emul, dumps, name, hchunk, vchunk, fused):
     """k_aggregate_rr2.h compiled for the CPU (RR_EMUL): two disparities per lane, ring slots = VGPR pairs addressed with
-    M0 = 2 * slot, packed 35-add blocks; 8 single passes == the reference's cost_aggr.  fused: the first pass computes the
-    matching cost itself from packed pixel records (two lane windows) instead of reading cost_init."""
+    M0 = 2 * slot, packed 35-add blocks; 8 single passes == the reference's cost_aggr.  A wave = one chunk of the line-major
+    output index space (0 = whole lines; chunks that straddle line ends, cover several lines, or are shorter than the
+    prefetch depth).  fused: the first pass computes the matching cost itself from packed pixel records (two lane
+    windows) instead of reading cost_init."""
     left, right, opt, o = dumps(name)
     h, w = left.shape[:2]
     D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
@@ -140,7 +142,7 @@ def test_register_ring_pairs_body(emul, dumps, name, hseg, vseg, fused):
             ci = 1 if (fused and first) else 0
             if ci:
                 a[:] = np.nan  # the fused pass must not read the cost volume
-            rc = emul.emul_rr2_pass(P(a), P(b), P(o["arms"]), P(sup), w, h, D, vert, div, L, vseg if vert else hseg, ci,
+            rc = emul.emul_rr2_pass(P(a), P(b), P(o["arms"]), P(sup), w, h, D, vert, div, L, vchunk if vert else hchunk, ci,
                                     P(left), P(right), P(o["census_left"]), P(o["census_right"]), dmin, opt.lambda_ad, opt.lambda_census)
             assert rc == 0
             first = False
