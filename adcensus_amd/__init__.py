@@ -149,6 +149,7 @@ class PairFarm:
 
     def __init__(self, width, height, option, device=-1, pipelines=3):
         self.width, self.height = int(width), int(height)
+        self.pipelines = int(pipelines)
         self._f = lib().adc_farm_create(self.width, self.height, C.byref(option), int(device), int(pipelines))
         if not self._f:
             raise RuntimeError("adc_farm_create failed: " + last_error())
@@ -160,10 +161,14 @@ class PairFarm:
         assert disp_left.dtype == np.float32 and disp_left.flags["C_CONTIGUOUS"] and disp_left.size == self.width * self.height
         t = C.c_uint64(0)
         rc = lib().adc_farm_submit(self._f, l.ctypes.data, r.ctypes.data, disp_left.ctypes.data, C.byref(t))
-        if rc != 0:
+        if rc not in (0, 3):
             raise RuntimeError("adc_farm_submit failed (%d): %s" % (rc, last_error()))
-        self._keep[int(t.value)] = disp_left  # the output array must stay alive until the pair is delivered
-        return int(t.value)
+        ticket = int(t.value)
+        self._keep[ticket] = disp_left  # the output array must stay alive until the pair is delivered
+        self._keep.pop(ticket - self.pipelines, None)  # submit() has just delivered the pair that held this pipeline before
+        if rc == 3:  # ADC_FARM_PREVIOUS_FAILED: the new pair IS in flight; the message names the ticket that failed
+            raise RuntimeError("adc_farm_submit: " + last_error())
+        return ticket
 
     def wait(self, ticket):
         if lib().adc_farm_wait(self._f, int(ticket)) != 0:
@@ -254,7 +259,8 @@ class ADCensusStereo:
 
     # -- additive API --------------------------------------------------------------------------
     def match_device(self, d_left, d_right, d_disp):
-        """Device pointers (ints); asynchronous; call wait()."""
+        """Device pointers (ints); asynchronous; call wait().  The two image buffers are BORROWED until wait() returns: do
+        not overwrite or free them before (the handle keeps no pointer to them afterwards)."""
         return lib().adc_match_device(self._h, d_left, d_right, d_disp) == 0
 
     def match_async(self, img_left, img_right, disp_left):

@@ -503,6 +503,13 @@ int adc_wait(adc_handle* h)
         h->async_dst = nullptr;
     }
     h->device_dst = nullptr;
+    // adc_match_device BORROWED the caller's device images until here: nothing of the handle may point at them any
+    // more (a later debug stage would otherwise read memory the caller has reused or freed)
+    if (h->img_l != h->img_l_own || h->img_r != h->img_r_own) {
+        h->img_l = h->img_l_own;
+        h->img_r = h->img_r_own;
+        h->bgrx_valid = 0;
+    }
     collect_timings(h);
     return 0;
 }
@@ -557,13 +564,20 @@ int adc_farm_submit(adc_farm* f, const uint8_t* left, const uint8_t* right, floa
     if (!f || !left || !right || !disp) return 1;
     const uint64_t t = f->next_ticket;
     const size_t slot = (size_t)((t - 1) % f->pipes.size());
-    int rc = farm_collect(f, slot); // the pipeline's previous pair (if any) must be delivered before its staging is reused
-    if (rc != 0) return rc;
-    rc = adc_match_async(f->pipes[slot], left, right, disp);
+    // the pipeline's previous pair (if any) must be delivered before its staging is reused.  When THAT pair failed, the new
+    // pair is still enqueued (the caller gets its ticket) and the failure is reported as ADC_FARM_PREVIOUS_FAILED with the
+    // failed ticket in adc_last_error(): the caller can tell which output is invalid
+    const uint64_t prev = f->in_flight[slot];
+    const int rc_prev = farm_collect(f, slot);
+    int rc = adc_match_async(f->pipes[slot], left, right, disp);
     if (rc != 0) return rc;
     f->in_flight[slot] = t;
     f->next_ticket++;
     if (ticket) *ticket = t;
+    if (rc_prev != 0) {
+        g_last_error = "adc_farm_submit: the pair with ticket " + std::to_string((unsigned long long)prev) + " failed (" + g_last_error + "); the new pair was enqueued";
+        return ADC_FARM_PREVIOUS_FAILED;
+    }
     return 0;
 }
 int adc_farm_wait(adc_farm* f, uint64_t ticket)

@@ -17,6 +17,7 @@
 //   * algorithmic bytes per pass: read V + write V (+4 B/pixel arms, +2 B/pixel counts), V = 4*W*H*Dp.
 #include "adc_internal.h"
 #include "adc_device_fn.h"
+#include <mutex>
 #include "k_aggregate_rr.h"
 #include "k_aggregate_rr2.h"
 
@@ -835,17 +836,22 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     // 3x slower.  The single pass itself now runs at the device copy rate.
     static const int pair_full = env_int("ADC_AGG_PAIR_FULL", 0);
     static const bool regring_on = env_int("ADC_AGG_REGRING", 1) != 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        // allow > 64 KiB dynamic LDS for the ring (large cross_L1)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    {   // allow > 64 KiB dynamic LDS for the ring (large cross_L1): a per-DEVICE function attribute -- set once for every
+        // device this process drives (a farm on device 1 after one on device 0), under a lock (handles on several threads)
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {false};
+        std::lock_guard<std::mutex> lk(attr_mu);
+        const int dv = (h->device >= 0 && h->device < 64) ? h->device : 0;
+        if (!attr_set[dv]) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set[dv] = true;
+        }
     }
     hipError_t e = hipSuccess;
     const int Lfull = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));

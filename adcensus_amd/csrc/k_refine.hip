@@ -12,8 +12,10 @@
 //                       with dirty-tile re-evaluation; converges to the sequential result
 //   K9  interpolation : Jacobi within a list => plain parallel launch per list
 //   K10 discontinuity : Sobel mask + one thread per row (in-row sequential dependency)
-//   K11 median        : level-synchronous wavefront t = x + 2y inside one workgroup
+//   K11 median        : wavefront t = x + 2y; bands of 64 rows, one wave per band, register-resident, band-to-band hand-off
+//                       rows (k_median_banded); single-workgroup wavefront kernel as the time-out fallback
 #include "adc_internal.h"
+#include <mutex>
 #include "adc_device_fn.h"
 
 #include <vector>
@@ -776,13 +778,18 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
 static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float* out)
 {
     const AdcParams& p = h->p;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    {   // per-DEVICE function attribute (see adc_launch_aggregate)
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {false};
+        std::lock_guard<std::mutex> lk(attr_mu);
+        const int dv = (h->device >= 0 && h->device < 64) ? h->device : 0;
+        if (!attr_set[dv]) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_median_wavefront<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set[dv] = true;
+        }
     }
     const size_t lds = (size_t)p.H * 4 * sizeof(float);
     if (p.H > 8192) return hipErrorInvalidValue; // LDS ring of H*16 B and <= 8 rows per thread

@@ -4,6 +4,8 @@
 #include "ADCensusStereo.h"
 #include "adcensus_c_api.h"
 
+#include <stdlib.h>
+
 static adc_option to_c(const ADCensusOption& o)
 {
     adc_option c;
@@ -20,7 +22,15 @@ static adc_option to_c(const ADCensusOption& o)
     return c;
 }
 
-ADCensusStereo::ADCensusStereo() : impl_(nullptr), device_(-1), verbose_(false), profiling_(false) {}
+// The reference's Match always prints its six stage-timing lines (ADCensusStereo.cpp:88-129): the look-alike facade does
+// too; ADC_VERBOSE=0 in the environment or SetVerbose(false) switches them off (the C ABI underneath, which
+// the benchmarks use, prints nothing unless asked).
+static bool default_verbose()
+{
+    const char* e = getenv("ADC_VERBOSE");
+    return e ? atoi(e) != 0 : true;
+}
+ADCensusStereo::ADCensusStereo() : impl_(nullptr), device_(-1), verbose_(default_verbose()), profiling_(false) {}
 ADCensusStereo::~ADCensusStereo() { Release(); }
 
 void ADCensusStereo::Release()

@@ -48,6 +48,7 @@ static bool decode_png(const std::vector<uint8>& file, std::vector<uint8>& bgr, 
         if (pos + 12 + len > file.size()) return false;
         const uint8* data = &file[pos + 8];
         if (!memcmp(type, "IHDR", 4)) {
+            if (len != 13) return false; // (a short header chunk would be read past its end)
             w = (int)be32(data); h = (int)be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12];
         } else if (!memcmp(type, "PLTE", 4)) {
             plte.assign(data, data + len);
@@ -62,6 +63,8 @@ static bool decode_png(const std::vector<uint8>& file, std::vector<uint8>& bgr, 
     const int ch = ctype == 0 ? 1 : (ctype == 2 ? 3 : (ctype == 3 ? 1 : (ctype == 4 ? 2 : (ctype == 6 ? 4 : 0))));
     if (!ch) return false;
     const size_t stride = (size_t)w * ch;
+    // a deflate stream expands at most ~1032x: bound the dimensions the header claims by what the IDAT data can hold
+    if (w > (1 << 20) || h > (1 << 20) || (stride + 1) * (size_t)h > idat.size() * 1040 + 65536) return false;
     std::vector<uint8> raw((stride + 1) * h);
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
@@ -257,7 +260,8 @@ int main(int argc, char** argv)
     std::vector<uint8> gray((size_t)w * h, 0), col((size_t)w * h * 3, 0);
     for (size_t i = 0; i < gray.size(); i++) {
         const float32 a = fabsf(disparity[i]);
-        gray[i] = a == Invalid_Float ? 0 : static_cast<uint8>((a - mn) / (mx - mn) * 255);
+        // (a constant map has max == min: the reference divides 0 by 0 there, main.cpp:196 -- written as 0 instead of casting a NaN)
+        gray[i] = (a == Invalid_Float || !(mx > mn)) ? 0 : static_cast<uint8>((a - mn) / (mx - mn) * 255);
         col[3 * i] = kJet[gray[i]][0]; col[3 * i + 1] = kJet[gray[i]][1]; col[3 * i + 2] = kJet[gray[i]][2];
     }
     if (!write_png(out + "-d.png", gray.data(), w, h, 1) || !write_png(out + "-c.png", col.data(), w, h, 3)) printf("cannot write %s-d.png / -c.png\n", out.c_str());

@@ -9,7 +9,7 @@
  * the C ABI of include/adcensus_c_api.h (HIP kernels for gfx950); there is no CPU path.
  *
  * Additive members (no reference counterpart): SetDevice, SetVerbose (prints the reference's six stage
- * timing lines, ADCensusStereo.cpp:88-129, off by default), StageMilliseconds, MatchAsync/Wait.
+ * timing lines, ADCensusStereo.cpp:88-129: ON by default like the reference, ADC_VERBOSE=0 or SetVerbose(false) turns them off), StageMilliseconds, MatchAsync/Wait.
  */
 #pragma once
 
@@ -25,7 +25,7 @@ public:
     ADCensusStereo& operator=(const ADCensusStereo&) = delete;
 
     /** Allocates all device buffers once. false: width/height <= 0, empty disparity range
-     *  (ADCensusStereo.cpp:31-40), range > 256, or a HIP failure. */
+     *  (ADCensusStereo.cpp:31-40), range > ADC_MAX_DISP_RANGE (1024), W*H > 2^30, or a HIP failure. */
     bool Initialize(const sint32& width, const sint32& height, const ADCensusOption& option);
 
     /** Left-view sub-pixel disparity map of the pair (uint8 [H][W][3] BGR each) into the caller's

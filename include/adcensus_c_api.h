@@ -88,7 +88,8 @@ int adc_match(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right, 
 
 /* Same pipeline, device-resident buffers (already in HBM); asynchronous on the handle's stream: the call only ENQUEUES
  * (no host synchronisation anywhere in the pipeline) and returns; call adc_wait() before reading d_disp_left.  The two
- * image buffers are borrowed until adc_wait returns (not copied).  Where the reference would decide something on the
+ * image buffers are BORROWED until adc_wait returns (not copied: the caller must not overwrite or free them before; after
+ * adc_wait the handle holds no pointer to them).  Where the reference would decide something on the
  * host in mid-pipeline, the device decides or verifies: the aggregation uses the ring depth of the previous Match of the
  * handle and checks it on the device; the region voting is a kernel chain driven by a device-side state machine with a
  * launch budget adapted from the previous Match.  adc_wait completes whatever such an assumption left open (redo with
@@ -113,7 +114,10 @@ int adc_wait(adc_handle* h);
 typedef struct adc_farm adc_farm;
 adc_farm* adc_farm_create(int32_t width, int32_t height, const adc_option* opt, int device, int pipelines);
 void adc_farm_destroy(adc_farm* f);
-/* Returns 0 and the ticket (1, 2, 3, ...) of the pair; 1 on bad arguments, 2 on a HIP failure. */
+/* Returns 0 and the ticket (1, 2, 3, ...) of the pair; 1 on bad arguments, 2 on a HIP failure (nothing enqueued);
+ * ADC_FARM_PREVIOUS_FAILED when the pair that occupied the pipeline before (ticket - pipelines) failed while it was
+ * collected: the NEW pair was enqueued all the same and *ticket is valid; adc_last_error() names the failed ticket. */
+#define ADC_FARM_PREVIOUS_FAILED 3
 int adc_farm_submit(adc_farm* f, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left, uint64_t* ticket);
 /* Blocks until the pair with this ticket (and every earlier pair of its pipeline) has been delivered. */
 int adc_farm_wait(adc_farm* f, uint64_t ticket);

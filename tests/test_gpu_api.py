@@ -211,10 +211,13 @@ def test_large_arm_limit_uses_fallback(hip, oracle):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def test_cpp_facade_cli_cone(hip, oracle, tmp_path):
+@pytest.mark.parametrize("case,ref,dmax,ident,within1", [("cone", "cone", 64, 0.8355, 0.9938), ("cloth3", "cloth", 128, 0.8994, 0.9849),
+                                                          ("piano", "piano", 64, 0.6349, 0.8480)])
+def test_cpp_facade_cli(hip, oracle, tmp_path, case, ref, dmax, ident, within1):
     """Drop-in check: a main.cpp-style C++ program (examples/adcensus_cli.cpp) written against include/ADCensusStereo.h
-    (Initialize / Match) reproduces the reference output on the Cone pair, from PNG inputs to the PNG / cloud outputs of
-    SaveDisparityMap / SaveDisparityCloud (main.cpp:120-128,180-230)."""
+    (Initialize / Match) reproduces the reference output on the pairs whose result images the reference ships
+    (doc/exp/res/{cone,cloth,piano}-{d,c}.png), from PNG inputs to the PNG / cloud outputs of SaveDisparityMap /
+    SaveDisparityCloud (main.cpp:120-128,180-230)."""
     import os
     import subprocess
     from PIL import Image
@@ -222,15 +225,15 @@ def test_cpp_facade_cli_cone(hip, oracle, tmp_path):
     cli = os.path.join(root, "adcensus_amd", "bin", "adcensus_cli")
     if not os.path.exists(cli):
         pytest.fail("adcensus_cli not built (python -c 'import __graft_entry__ as g; g.build()')")
-    left, right, opt = cases.make_case("cone")
+    left, right, opt = cases.make_case(case)
     h, w = left.shape[:2]
-    Image.fromarray(np.ascontiguousarray(left[:, :, ::-1])).save(tmp_path / "im2.png")
-    Image.fromarray(np.ascontiguousarray(right[:, :, ::-1])).save(tmp_path / "im6.png")
-    out = subprocess.run([cli, str(tmp_path / "im2.png"), str(tmp_path / "im6.png"), "0", "64", str(tmp_path / "cone")],
+    Image.fromarray(np.ascontiguousarray(left[:, :, ::-1])).save(tmp_path / "left.png")
+    Image.fromarray(np.ascontiguousarray(right[:, :, ::-1])).save(tmp_path / "right.png")
+    out = subprocess.run([cli, str(tmp_path / "left.png"), str(tmp_path / "right.png"), "0", str(dmax), str(tmp_path / "out")],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "cost aggregating! timing" in out.stdout  # the reference's stage lines (ADCensusStereo.cpp:88-129)
-    with open(tmp_path / "cone.pfm", "rb") as f:
+    assert "cost aggregating! timing" in out.stdout  # the reference's stage lines (ADCensusStereo.cpp:88-129): on by default in the facade
+    with open(tmp_path / "out.pfm", "rb") as f:
         assert f.readline().strip() == b"Pf"
         assert f.readline().split() == [str(w).encode(), str(h).encode()]
         f.readline()
@@ -241,20 +244,46 @@ def test_cpp_facade_cli_cone(hip, oracle, tmp_path):
     a = np.abs(want)
     mn, mx = np.float32(a.min()), np.float32(a.max())
     d_want = ((a - mn) / (mx - mn) * np.float32(255)).astype(np.uint8)
-    d_got = np.array(Image.open(tmp_path / "cone-d.png"))
+    d_got = np.array(Image.open(tmp_path / "out-d.png"))
     assert d_got.shape == (h, w) and np.array_equal(d_got, d_want)
-    # ... and as close to the AUTHOR's result image (doc/exp/res/cone-d.png, made with MSVC / Windows libm) as the
-    # reference compiled here is: 83.56 % of the pixels identical, 99.38 % within one grey level
-    ref = np.array(Image.open(os.path.join(cases.GOLDEN_DIR, "ref_cone-d.png")))
-    diff = np.abs(d_got.astype(int) - ref.astype(int))
-    assert (diff == 0).mean() >= 0.8355 and (diff <= 1).mean() >= 0.9938, ((diff == 0).mean(), (diff <= 1).mean())
-    c_got = np.array(Image.open(tmp_path / "cone-c.png"))
-    c_ref = np.array(Image.open(os.path.join(cases.GOLDEN_DIR, "ref_cone-c.png")).convert("RGB"))
-    assert c_got.shape == c_ref.shape and (np.abs(c_got.astype(int) - c_ref.astype(int)).max(axis=2) == 0).mean() >= 0.8355
+    # ... and as close to the AUTHOR's result image (doc/exp/res/<ref>-d.png, made with MSVC / Windows libm) as the
+    # reference compiled here is (cone: 83.56 % of the pixels identical, 99.38 % within one grey level; cloth: 89.95 % /
+    # 98.50 %; piano: 63.50 % / 84.81 % -- SURVEY.md section 4; the thresholds are those figures)
+    refd = np.array(Image.open(os.path.join(cases.GOLDEN_DIR, "ref_%s-d.png" % ref)))
+    diff = np.abs(d_got.astype(int) - refd.astype(int))
+    assert (diff == 0).mean() >= ident and (diff <= 1).mean() >= within1, ((diff == 0).mean(), (diff <= 1).mean())
+    c_got = np.array(Image.open(tmp_path / "out-c.png"))
+    c_ref = np.array(Image.open(os.path.join(cases.GOLDEN_DIR, "ref_%s-c.png" % ref)).convert("RGB"))
+    assert c_got.shape == c_ref.shape and (np.abs(c_got.astype(int) - c_ref.astype(int)).max(axis=2) == 0).mean() >= ident - 0.001
     # <out>-cloud.txt: "x y |d| r g b" per valid pixel, colours of the left image (main.cpp:224-225)
-    rows = [l.split() for l in open(tmp_path / "cone-cloud.txt").read().splitlines()]
+    rows = [l.split() for l in open(tmp_path / "out-cloud.txt").read().splitlines()]
     assert len(rows) == int(np.isfinite(want).sum()) and all(len(r) == 6 for r in rows[:1000])
     x, y, d, r, g, b = rows[12345]
     xi, yi = int(float(x)), int(float(y))
     assert abs(float(d) - abs(float(want[yi, xi]))) < 1e-5 * max(1.0, abs(float(d)))
     assert (int(r), int(g), int(b)) == tuple(int(v) for v in left[yi, xi, ::-1])
+
+@pytest.mark.parametrize("env", [{"ADC_AGG_RR2": "0"}, {"ADC_AGG_RR2": "0", "ADC_AGG_PAIR_FULL": "1"}, {"ADC_AGG_REGRING": "0"},
+                                 {"ADC_AGG_HCHUNK": "37", "ADC_AGG_VCHUNK": "23"}])
+def test_aggregation_kernel_families_ab(hip, env):
+    """The aggregation kernels that are NOT the default for a 128-wide range stay bit-exact on hardware: the one-float
+    register ring (ADC_AGG_RR2=0), its pass pairs on two register rings (ADC_AGG_PAIR_FULL=1), the LDS full ring
+    (ADC_AGG_REGRING=0), and the pair-register ring with chunks that straddle line ends.  The switches are read once per
+    process, so every variant runs in its own interpreter (stage-isolated aggregation + whole Match against the oracle)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests import cases, gpu_harness\n"
+            "from oracle import pyoracle\n"
+            "bad = {}\n"
+            "for name in ('s2_320x180_d128', 'noise_160x90_d128'):\n"
+            "    l, r, opt = cases.make_case(name)\n"
+            "    o = pyoracle.load('auto').run(l, r, opt)\n"
+            "    rep = gpu_harness.stage_report(l, r, opt, o)\n"
+            "    bad.update({name + ':' + k: v['bad'] for k, v in gpu_harness.failing(rep).items()})\n"
+            "print('FAILING', bad)\n"
+            "sys.exit(1 if bad else 0)\n") % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
