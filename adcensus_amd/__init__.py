@@ -23,6 +23,7 @@ STAGES = ["cost", "arms", "aggregate", "scanline", "wta", "refine"]
 (RUN_GRAY_CENSUS, RUN_COST, RUN_ARMS, RUN_AGGREGATE, RUN_SCANLINE, RUN_WTA, RUN_LRCHECK, RUN_REGION_VOTING,
  RUN_INTERPOLATION, RUN_DISCONTINUITY, RUN_MEDIAN) = range(11)
 MAX_DISP_RANGE = 1024
+PAPER_CENSUS5X5, PAPER_SO_SUM, PAPER_RIGHT_ARMS = 1, 2, 4  # adc_set_paper_modes (opt-in, not the reference's behaviour)
 
 
 class ADCensusOption(C.Structure):
@@ -91,6 +92,8 @@ def lib():
     L.adc_get_aggregate_info.restype = C.c_int
     L.adc_get_aggregate_kernel.argtypes = [vp]
     L.adc_get_aggregate_kernel.restype = C.c_char_p
+    L.adc_set_paper_modes.argtypes = [vp, C.c_uint32]
+    L.adc_set_paper_modes.restype = C.c_int
     L.adc_get_stream.argtypes = [vp]
     L.adc_get_stream.restype = vp
     L.adc_device_synchronize.restype = C.c_int
@@ -292,6 +295,11 @@ class ADCensusStereo:
         ms, n, p, f = C.c_float(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib().adc_get_aggregate_info(self._h, C.byref(ms), C.byref(n), C.byref(p), C.byref(f))
         return float(ms.value), int(n.value), int(p.value), bool(f.value)
+
+    def set_paper_modes(self, modes):
+        """Opt-in paper features (PAPER_CENSUS5X5 | PAPER_SO_SUM | PAPER_RIGHT_ARMS); 0 = the reference's behaviour."""
+        if lib().adc_set_paper_modes(self._h, int(modes)) != 0:
+            raise RuntimeError("adc_set_paper_modes failed: " + last_error())
 
     def aggregate_kernel(self):
         return lib().adc_get_aggregate_kernel(self._h).decode()

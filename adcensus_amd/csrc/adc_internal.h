@@ -121,6 +121,12 @@ struct adc_handle {
     int agg_launches;
     int agg_passes;    // algorithmic passes those launches covered (a pair launch covers two)
     const char* agg_kernel; // kernel family of the last regular aggregation launch (static string)
+    // opt-in paper modes (k_paper.hip; 0 = the reference's behaviour)
+    uint32_t paper;
+    uint8_t* arms_r;      // arms built on the RIGHT image (ADC_PAPER_RIGHT_ARMS), with its packed pixels and a scratch armmax
+    uint32_t* bgrx_r;
+    int* armmax_r;
+    float* vol_c;         // third volume: accumulator of the averaged scanline paths (ADC_PAPER_SO_SUM)
     bool timings_pending;
     // region voting statistics of the last run
     int64_t vote_rounds, vote_evals;
@@ -140,6 +146,9 @@ hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream);
 size_t adc_so_cls_bytes(int W, int H);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
+hipError_t adc_launch_wta_left(adc_handle* h);                  // vol_a -> disp_l only (debug form of the left view)
+hipError_t adc_paper_aggregate(adc_handle* h, int iterations);  // k_paper.hip: aggregation limited by both images' arms
+hipError_t adc_paper_accumulate(adc_handle* h, float* acc, const float* src, int first, int last);
 hipError_t adc_launch_lrcheck(adc_handle* h);
 size_t adc_itp_cell_bytes(int W, int H);       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
 int adc_irv_grid(size_t pixels);                // workgroups of the voting chain for an image of this size

@@ -251,7 +251,7 @@ void adc_destroy(adc_handle* h)
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
-                    h->chg_a, h->edge};
+                    h->chg_a, h->edge, h->arms_r, h->bgrx_r, h->armmax_r, h->vol_c};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
     if (h->pin_out) hipHostFree(h->pin_out);
@@ -318,7 +318,8 @@ static hipError_t run_heavy(adc_handle* h)
     // ADC_FUSE_COST (default on): the cost volume is never written -- the first aggregation pass computes each cost
     // in registers from packed pixel records (k_agg_march<.., COSTIN>); otherwise K2 writes it and pass 1 reads it back
     static const bool fuse_cost = [] { const char* e = getenv("ADC_FUSE_COST"); return e ? atoi(e) != 0 : true; }();
-    if (fuse_cost) HIP_OK(adc_launch_cost_records(h));
+    const bool fuse_cost_now = fuse_cost && !(h->paper & ADC_PAPER_RIGHT_ARMS); // (paper mode: plain kernels on a stored cost volume)
+    if (fuse_cost_now) HIP_OK(adc_launch_cost_records(h));
     else HIP_OK(adc_launch_cost(h, h->vol_a));
     MARK(1, h->heavy);
     HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
@@ -341,7 +342,7 @@ static hipError_t run_heavy(adc_handle* h)
         }
     }
     HIP_OK(adc_launch_records(h));
-    h->fuse_cost = fuse_cost ? 1 : 0;
+    h->fuse_cost = fuse_cost_now ? 1 : 0;
     {
         const hipError_t e_ = adc_launch_aggregate(h, 4); // aggregator_.Aggregate(4), :164
         h->fuse_cost = 0;
@@ -607,6 +608,21 @@ const char* adc_stage_name(int s)
     static const char* names[ADC_STAGE_COUNT] = {"cost", "arms", "aggregate", "scanline", "wta", "refine"};
     return (s >= 0 && s < ADC_STAGE_COUNT) ? names[s] : "";
 }
+int adc_set_paper_modes(adc_handle* h, uint32_t modes)
+{
+    if (!h || (modes & ~(ADC_PAPER_CENSUS5X5 | ADC_PAPER_SO_SUM | ADC_PAPER_RIGHT_ARMS))) return 1;
+    hipSetDevice(h->device);
+    const size_t P = (size_t)h->p.W * h->p.H;
+    if ((modes & ADC_PAPER_RIGHT_ARMS) && !h->arms_r) {
+        if (hipMalloc(&h->arms_r, P * 4) != hipSuccess || hipMalloc(&h->bgrx_r, P * 4) != hipSuccess ||
+            hipMalloc(&h->armmax_r, 4 * sizeof(int)) != hipSuccess) { g_last_error = "adc_set_paper_modes: allocation failed"; return 2; }
+    }
+    if ((modes & ADC_PAPER_SO_SUM) && !h->vol_c) {
+        if (hipMalloc(&h->vol_c, P * h->p.Dp * sizeof(float)) != hipSuccess) { g_last_error = "adc_set_paper_modes: allocation failed"; return 2; }
+    }
+    h->paper = modes;
+    return 0;
+}
 void adc_set_profiling(adc_handle* h, int on) { if (h) h->profiling = on; }
 void adc_set_verbose(adc_handle* h, int on) { if (h) { h->verbose = on; if (on) h->profiling = 1; } }
 int adc_get_stage_ms(adc_handle* h, float* ms, int n)
@@ -737,8 +753,8 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
             arg -= 200;
         }
         if (e == hipSuccess && arg >= 100) {
-            e = adc_launch_cost_records(h);
-            h->fuse_cost = 1;
+            if (h->paper & ADC_PAPER_RIGHT_ARMS) e = adc_launch_cost(h, h->vol_a); // (no fused form in this mode: recompute the volume)
+            else { e = adc_launch_cost_records(h); h->fuse_cost = 1; }
             arg -= 100;
         }
         if (e == hipSuccess) e = adc_launch_aggregate(h, arg > 0 ? arg : 4);

@@ -826,6 +826,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
 // vol_a -> (H,V | V,H alternating) -> vol_a.  Every iteration is two launches: a -> b -> a.
 hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
 {
+    if ((h->paper & ADC_PAPER_RIGHT_ARMS) && h->arms_r) return adc_paper_aggregate(h, iterations); // opt-in paper mode (k_paper.hip)
     static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
     static const bool pair_env = env_int("ADC_AGG_PAIR", 1) != 0;
     // pairs with the full ring: 0 (default) = never, 1 = when both rings fit into registers (k_agg_regring_pair), 2 = also

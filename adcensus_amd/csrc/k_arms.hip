@@ -160,6 +160,11 @@ hipError_t adc_launch_arms(adc_handle* h)
                        p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2, h->armmax);
     hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
                        p.W, p.H);
+    if ((h->paper & ADC_PAPER_RIGHT_ARMS) && h->arms_r) { // opt-in paper mode (k_paper.hip): the same arms on the RIGHT image
+        hipLaunchKernelGGL(k_pack_bgr, dim3((p.W * p.H + 255) / 256), dim3(256), 0, h->heavy, h->img_r, h->bgrx_r, p.W * p.H);
+        hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->bgrx_r, reinterpret_cast<uchar4*>(h->arms_r), p.W, p.H,
+                           p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2, h->armmax_r);
+    }
     dim3 grid2(grid.x, grid.y, 2);
     hipLaunchKernelGGL(k_color_diffs, grid2, block, 0, h->heavy, h->img_l, h->img_r, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh,
                        h->cdiff_rv, p.W, p.H);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(CT_W* CT_H) void k_gray_census(const uint8_t* __res
                                                              const uint8_t* __restrict__ img_r,
                                                              uint8_t* __restrict__ gray_l, uint8_t* __restrict__ gray_r,
                                                              uint64_t* __restrict__ census_l,
-                                                             uint64_t* __restrict__ census_r, int W, int H)
+                                                             uint64_t* __restrict__ census_r, int W, int H, int census5)
 {
     __shared__ uint8_t tile[CT_LH][CT_LW + 2];
     const uint8_t* img = blockIdx.z == 0 ? img_l : img_r;
@@ -47,7 +47,17 @@ __global__ __launch_bounds__(CT_W* CT_H) void k_gray_census(const uint8_t* __res
     gray[(size_t)y * W + x] = c;
     uint64_t v = 0;
     // interior only, whole transform skipped for tiny images (adcensus_util.cpp:12,17-18); others stay 0
-    if (W > 9 && H > 7 && y >= 4 && y < H - 4 && x >= 3 && x < W - 3) {
+    if (census5) { // opt-in paper mode (k_paper.hip): 5x5 window, same conventions -- 25 bits, MSB first, interior only
+        if (W > 5 && H > 5 && y >= 2 && y < H - 2 && x >= 2 && x < W - 2) {
+#pragma unroll
+            for (int r = -2; r <= 2; r++)
+#pragma unroll
+                for (int cc = -2; cc <= 2; cc++) {
+                    v <<= 1;
+                    v += (tile[ly + r][lx + cc] < c) ? 1u : 0u;
+                }
+        }
+    } else if (W > 9 && H > 7 && y >= 4 && y < H - 4 && x >= 3 && x < W - 3) {
 #pragma unroll
         for (int r = -4; r <= 4; r++)
 #pragma unroll
@@ -64,7 +74,7 @@ hipError_t adc_launch_gray_census(adc_handle* h)
     const AdcParams& p = h->p;
     dim3 grid((p.W + CT_W - 1) / CT_W, (p.H + CT_H - 1) / CT_H, 2), block(CT_W, CT_H, 1);
     hipLaunchKernelGGL(k_gray_census, grid, block, 0, h->heavy, h->img_l, h->img_r, h->gray_l, h->gray_r, h->census_l,
-                       h->census_r, p.W, p.H);
+                       h->census_r, p.W, p.H, (h->paper & ADC_PAPER_CENSUS5X5) ? 1 : 0);
     return hipGetLastError();
 }
 

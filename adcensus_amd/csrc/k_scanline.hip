@@ -605,6 +605,21 @@ static hipError_t run_so(adc_handle* h, int passes)
 {
     // scanline_optimizer.cpp:54-60 (cost_aggr_ == vol_a, cost_init_ == vol_b)
     hipError_t e = adc_launch_so_classes(h, h->heavy); // the path-ordered d1 words (tiny)
+    if ((h->paper & ADC_PAPER_SO_SUM) && h->vol_c && passes == 4) {
+        // opt-in paper mode (k_paper.hip): every path from the SAME aggregated volume, averaged -- vol_a -> vol_b per path,
+        // accumulated in vol_c, which then becomes vol_a
+        for (int r = 0; r < 4 && e == hipSuccess; r++) {
+            e = launch_so<VPL>(h, h->vol_a, h->vol_b, r >= 2, (r & 1) ? -1 : +1);
+            if (e == hipSuccess) e = adc_paper_accumulate(h, h->vol_c, h->vol_b, r == 0, r == 3);
+        }
+        { float* t = h->vol_a; h->vol_a = h->vol_c; h->vol_c = t; }
+        h->wta_left_done = 0;
+        if (e == hipSuccess && h->fuse_wta) { // (the left view cannot ride on a pass here: computed from the averaged volume)
+            e = adc_launch_wta_left(h);
+            h->wta_left_done = 1;
+        }
+        return e;
+    }
     if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1);
     if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1);
     if (e == hipSuccess && passes >= 3) e = launch_so<VPL>(h, h->vol_a, h->vol_b, true, +1);

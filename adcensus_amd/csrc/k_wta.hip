@@ -147,6 +147,22 @@ __global__ __launch_bounds__(256) void k_wta_right_band(const float* __restrict_
     disp[(size_t)y * W + x] = out;
 }
 
+hipError_t adc_launch_wta_left(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    const long long P = (long long)p.W * p.H;
+    const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : 2); // == k_wta's WTA_PPW
+    const unsigned blocks = (unsigned)((P + 4 * wta_ppw - 1) / (4 * wta_ppw));
+#define LAUNCHL(V) hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D)
+    if (p.VPL == 1) LAUNCHL(1);
+    else if (p.VPL == 2) LAUNCHL(2);
+    else if (p.VPL == 4) LAUNCHL(4);
+    else if (p.VPL == 8) LAUNCHL(8);
+    else LAUNCHL(16);
+#undef LAUNCHL
+    return hipGetLastError();
+}
+
 hipError_t adc_launch_wta(adc_handle* h)
 {
     const AdcParams& p = h->p;

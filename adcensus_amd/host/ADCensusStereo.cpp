@@ -30,7 +30,7 @@ static bool default_verbose()
     const char* e = getenv("ADC_VERBOSE");
     return e ? atoi(e) != 0 : true;
 }
-ADCensusStereo::ADCensusStereo() : impl_(nullptr), device_(-1), verbose_(default_verbose()), profiling_(false) {}
+ADCensusStereo::ADCensusStereo() : impl_(nullptr), device_(-1), verbose_(default_verbose()), profiling_(false), paper_(0) {}
 ADCensusStereo::~ADCensusStereo() { Release(); }
 
 void ADCensusStereo::Release()
@@ -47,6 +47,7 @@ bool ADCensusStereo::Initialize(const sint32& width, const sint32& height, const
     if (!impl_) return false;
     if (profiling_) adc_set_profiling(impl_, 1);
     if (verbose_) adc_set_verbose(impl_, 1);
+    if (paper_ && adc_set_paper_modes(impl_, paper_) != 0) return false;
     return true;
 }
 
@@ -80,4 +81,9 @@ bool ADCensusStereo::MatchAsync(const uint8* l, const uint8* r, float32* d)
     return adc_match_async(impl_, l, r, d) == 0;
 }
 bool ADCensusStereo::Wait() { return impl_ && adc_wait(impl_) == 0; }
+bool ADCensusStereo::SetPaperModes(unsigned modes)
+{
+    paper_ = modes;
+    return impl_ ? adc_set_paper_modes(impl_, modes) == 0 : true; // (before Initialize: applied there)
+}
 const char* ADCensusStereo::LastError() const { return adc_last_error(); }

@@ -43,6 +43,10 @@ public:
     bool StageMilliseconds(float ms[6]) const;
     bool MatchAsync(const uint8* img_left, const uint8* img_right, float32* disp_left);
     bool Wait();
+    /** Opt-in paper features the reference declares / stores but does not implement (bit 0: 5x5 census, adcensus_types.h:39-42;
+     *  bit 1: averaged instead of chained scanline paths; bit 2: right-image arms, cross_aggregator.h:91).  0 (default) = the
+     *  reference's behaviour; anything else changes the results by definition.  Call after Initialize. */
+    bool SetPaperModes(unsigned modes);
     const char* LastError() const;
 
 private:
@@ -50,4 +54,5 @@ private:
     adc_handle* impl_;
     int device_;
     bool verbose_, profiling_;
+    unsigned paper_;
 };

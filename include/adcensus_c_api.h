@@ -148,6 +148,19 @@ int adc_get_aggregate_info(adc_handle* h, float* avg_launch_ms, int* launches, i
 /* Name of the kernel family the last regular aggregation launch of the handle used (static string, "" before the first Match). */
 const char* adc_get_aggregate_kernel(adc_handle* h);
 
+/* OPT-IN paper modes: features of the AD-Census paper the reference declares or stores but does not
+ * implement.  Default 0 = exactly the reference.  Any other value changes the results BY DEFINITION (no parity with the
+ * reference; checked against oracle/adcensus_port.c's own restatement of the same definitions).  Functional, not tuned.
+ *   ADC_PAPER_CENSUS5X5   5x5 census window (adcensus_types.h:39-42, CensusSize::Census5x5, declared / unimplemented)
+ *   ADC_PAPER_SO_SUM      the four scanline paths computed independently and averaged (paper eq. 10) instead of chained
+ *                         (scanline_optimizer.cpp:54-60)
+ *   ADC_PAPER_RIGHT_ARMS  support regions limited by the arms of BOTH images (cross_aggregator.h:91 stores img_right_, unused)
+ * Call between matches (not while one is in flight).  Returns 0, 1 on bad arguments, 2 on an allocation failure. */
+#define ADC_PAPER_CENSUS5X5 1u
+#define ADC_PAPER_SO_SUM 2u
+#define ADC_PAPER_RIGHT_ARMS 4u
+int adc_set_paper_modes(adc_handle* h, uint32_t modes);
+
 /* Print the reference's six timing lines from Match (ADCensusStereo.cpp:88-129); default off. */
 void adc_set_verbose(adc_handle* h, int on);
 

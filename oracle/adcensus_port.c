@@ -40,6 +40,10 @@ typedef struct {
     uint8_t* label;  /* 0 valid, 1 mismatch, 2 occlusion */
     int32_t *mis, *occ; /* raster-ordered pixel indices */
     size_t n_mis, n_occ;
+    /* opt-in PAPER modes (features of the AD-Census paper the reference declares or stores but does not implement; NOT
+     * the reference's behaviour -- oracle of the product's adc_set_paper_modes only): see adc_oracle_run_paper below */
+    uint32_t paper;
+    uint8_t* arms_r; /* [P][4] arms built on the RIGHT image (ADC_PAPER_RIGHT_ARMS) */
 } port_ctx;
 
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -69,6 +73,25 @@ static void port_census(const uint8_t* gray, uint64_t* census, int w, int h)
             uint64_t v = 0;
             for (int r = -4; r <= 4; r++)
                 for (int cc = -3; cc <= 3; cc++) {
+                    v <<= 1;
+                    if (gray[(size_t)(i + r) * w + j + cc] < c) v += 1;
+                }
+            census[(size_t)i * w + j] = v;
+        }
+}
+
+/* PAPER mode: 5x5 census (adcensus_types.h:39-42 declares CensusSize::Census5x5, nothing implements it): the 9x7 transform
+ * restated for a 5x5 window -- 25 bits, MSB first, centre bit included (= 0), interior pixels only, whole transform
+ * skipped for images not larger than the window (same conventions as adcensus_util.cpp:10-39). */
+static void port_census5x5(const uint8_t* gray, uint64_t* census, int w, int h)
+{
+    if (w <= 5 || h <= 5) return;
+    for (int i = 2; i < h - 2; i++)
+        for (int j = 2; j < w - 2; j++) {
+            const uint8_t c = gray[(size_t)i * w + j];
+            uint64_t v = 0;
+            for (int r = -2; r <= 2; r++)
+                for (int cc = -2; cc <= 2; cc++) {
                     v <<= 1;
                     if (gray[(size_t)(i + r) * w + j + cc] < c) v += 1;
                 }
@@ -122,17 +145,19 @@ static int color_dist_max(const uint8_t* a, const uint8_t* b)
 }
 
 /* One arm: walk from (x,y) in direction (dx,dy); returns its length. */
-static uint8_t port_arm(const port_ctx* c, int x, int y, int dx, int dy)
+static uint8_t port_arm_img(const port_ctx* c, const uint8_t* img, int x, int y, int dx, int dy);
+static uint8_t port_arm(const port_ctx* c, int x, int y, int dx, int dy) { return port_arm_img(c, c->left, x, y, dx, dy); }
+static uint8_t port_arm_img(const port_ctx* c, const uint8_t* img, int x, int y, int dx, int dy)
 {
     const int w = c->w, h = c->h;
     const int L1 = c->opt.cross_L1, L2 = c->opt.cross_L2, t1 = c->opt.cross_t1, t2 = c->opt.cross_t2;
-    const uint8_t* p0 = c->left + ((size_t)y * w + x) * 3;
+    const uint8_t* p0 = img + ((size_t)y * w + x) * 3;
     const uint8_t* last = p0;
     uint8_t len = 0;
     int xn = x + dx, yn = y + dy;
     for (int n = 0; n < imin(L1, 255); n++) { /* MAX_ARM_LENGTH 255, cross_aggregator.h:22 */
         if (xn < 0 || xn >= w || yn < 0 || yn >= h) break; /* :154-163 */
-        const uint8_t* p = c->left + ((size_t)yn * w + xn) * 3;
+        const uint8_t* p = img + ((size_t)yn * w + xn) * 3;
         const int d1 = color_dist_max(p, p0);
         if (d1 >= t1) break;                                  /* :169-172 */
         if (n > 0 && color_dist_max(p, last) >= t1) break;    /* :175-180 */
@@ -202,15 +227,72 @@ static void port_aggregate_plane(port_ctx* c, int di, int horizontal_first)
             }
 }
 
+/* PAPER mode: the support region of (p, d) is limited by BOTH images (the reference stores img_right_ for this,
+ * cross_aggregator.h:91, and never reads it): arm(p, d) = min(left arm at p, right arm at (x - d, y)) per direction when
+ * the right pixel lies in the image, else the left arm.  Same two-pass ordered sums; the divisor is the number of cost
+ * values that contributed = sum over the second pass's span of the first pass's span lengths (as float). */
+static void port_arms_at(const port_ctx* c, int x, int y, int d, int a[4])
+{
+    const uint8_t* al = c->arms + ((size_t)y * c->w + x) * 4;
+    const int xr = x - d;
+    for (int k = 0; k < 4; k++) a[k] = al[k];
+    if (xr >= 0 && xr < c->w) {
+        const uint8_t* ar = c->arms_r + ((size_t)y * c->w + xr) * 4;
+        for (int k = 0; k < 4; k++) a[k] = imin(a[k], ar[k]);
+    }
+}
+static void port_aggregate_plane_rarms(port_ctx* c, int di, int horizontal_first)
+{
+    const int w = c->w, h = c->h, D = c->D, d = di + c->dmin;
+    const size_t P = (size_t)w * h;
+    for (size_t p = 0; p < P; p++) c->tmp0[p] = c->cost_aggr[p * D + di];
+    for (int k = 0; k < 2; k++)
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int a[4];
+                port_arms_at(c, x, y, d, a);
+                const float* src = k == 0 ? c->tmp0 : c->tmp1;
+                const int horizontal = horizontal_first ? (k == 0) : (k == 1);
+                float cost = 0.0f;
+                int cnt = 0;
+                if (horizontal) {
+                    for (int t = -a[0]; t <= a[1]; t++) {
+                        cost += src[(size_t)y * w + x + t];
+                        if (k == 1) { int b[4]; port_arms_at(c, x + t, y, d, b); cnt += b[2] + b[3] + 1; }
+                    }
+                } else {
+                    for (int t = -a[2]; t <= a[3]; t++) {
+                        cost += src[(size_t)(y + t) * w + x];
+                        if (k == 1) { int b[4]; port_arms_at(c, x, y + t, d, b); cnt += b[0] + b[1] + 1; }
+                    }
+                }
+                if (k == 0) c->tmp1[(size_t)y * w + x] = cost;
+                else c->cost_aggr[((size_t)y * w + x) * D + di] = cost / (float)cnt;
+            }
+}
+
 static void port_aggregate(port_ctx* c, int iters)
 {
     const size_t n = (size_t)c->w * c->h * c->D;
     port_build_arms(c);
     port_sup_counts(c);
+    if (c->paper & 4u) {
+        for (int y = 0; y < c->h; y++)
+            for (int x = 0; x < c->w; x++) {
+                uint8_t* a = c->arms_r + ((size_t)y * c->w + x) * 4;
+                a[0] = port_arm_img(c, c->right, x, y, -1, 0);
+                a[1] = port_arm_img(c, c->right, x, y, +1, 0);
+                a[2] = port_arm_img(c, c->right, x, y, 0, -1);
+                a[3] = port_arm_img(c, c->right, x, y, 0, +1);
+            }
+    }
     memcpy(c->cost_aggr, c->cost_init, n * sizeof(float)); /* :108 */
     int horizontal_first = 1;
     for (int k = 0; k < iters; k++) {
-        for (int di = 0; di < c->D; di++) port_aggregate_plane(c, di, horizontal_first);
+        for (int di = 0; di < c->D; di++) {
+            if (c->paper & 4u) port_aggregate_plane_rarms(c, di, horizontal_first);
+            else port_aggregate_plane(c, di, horizontal_first);
+        }
         horizontal_first = !horizontal_first;
     }
 }
@@ -278,8 +360,24 @@ static void port_so_pass(port_ctx* c, const float* src, float* dst, int vertical
     free(last);
 }
 
+/* PAPER mode: the four path costs are computed INDEPENDENTLY from the aggregated volume and averaged (AD-Census paper,
+ * eq. 10: C2 = 1/4 sum_r C_r), where the reference chains them (scanline_optimizer.cpp:54-60).  Each path keeps the
+ * reference's recurrence (incl. its division by 2); sum order L->R, R->L, T->B, B->T, then * 0.25f. */
+static void port_scanline_sum(port_ctx* c)
+{
+    const size_t n = (size_t)c->w * c->h * c->D;
+    float* acc = (float*)malloc(n * sizeof(float));
+    for (int r = 0; r < 4; r++) {
+        port_so_pass(c, c->cost_aggr, c->cost_init, r >= 2, (r & 1) == 0);
+        for (size_t i = 0; i < n; i++) acc[i] = r == 0 ? c->cost_init[i] : acc[i] + c->cost_init[i];
+    }
+    for (size_t i = 0; i < n; i++) c->cost_aggr[i] = acc[i] * 0.25f;
+    free(acc);
+}
+
 static void port_scanline(port_ctx* c) /* scanline_optimizer.cpp:40-61: chained, ping-pong */
 {
+    if (c->paper & 2u) { port_scanline_sum(c); return; }
     port_so_pass(c, c->cost_aggr, c->cost_init, 0, 1);
     port_so_pass(c, c->cost_init, c->cost_aggr, 0, 0);
     port_so_pass(c, c->cost_aggr, c->cost_init, 1, 1);
@@ -527,7 +625,7 @@ static void port_free(port_ctx* c)
     free(c->gray_l); free(c->gray_r); free(c->census_l); free(c->census_r);
     free(c->cost_init); free(c->cost_aggr); free(c->arms);
     free(c->sup_h); free(c->sup_v); free(c->sup_tmp); free(c->tmp0); free(c->tmp1);
-    free(c->disp_l); free(c->disp_r); free(c->label); free(c->mis); free(c->occ);
+    free(c->disp_l); free(c->disp_r); free(c->label); free(c->mis); free(c->occ); free(c->arms_r);
 }
 
 static int port_init(port_ctx* c, int w, int h, const adc_option* opt)
@@ -541,7 +639,7 @@ static int port_init(port_ctx* c, int w, int h, const adc_option* opt)
     c->gray_l = calloc(P, 1); c->gray_r = calloc(P, 1);
     c->census_l = calloc(P, 8); c->census_r = calloc(P, 8); /* zero-filled once (cost_computor.cpp:37-38) */
     c->cost_init = calloc(P * c->D, 4); c->cost_aggr = calloc(P * c->D, 4);
-    c->arms = calloc(P, 4);
+    c->arms = calloc(P, 4); c->arms_r = calloc(P, 4);
     c->sup_h = calloc(P, 2); c->sup_v = calloc(P, 2); c->sup_tmp = calloc(P, 2);
     c->tmp0 = calloc(P, 4); c->tmp1 = calloc(P, 4);
     c->disp_l = calloc(P, 4); c->disp_r = calloc(P, 4);
@@ -558,8 +656,13 @@ static void port_pipeline(port_ctx* c, const uint8_t* left, const uint8_t* right
     /* ComputeCost (ADCensusStereo.cpp:147-155; cost_computor.cpp:123-137) */
     port_gray(left, c->gray_l, c->w, c->h);
     port_gray(right, c->gray_r, c->w, c->h);
-    port_census(c->gray_l, c->census_l, c->w, c->h);
-    port_census(c->gray_r, c->census_r, c->w, c->h);
+    if (c->paper & 1u) {
+        port_census5x5(c->gray_l, c->census_l, c->w, c->h);
+        port_census5x5(c->gray_r, c->census_r, c->w, c->h);
+    } else {
+        port_census(c->gray_l, c->census_l, c->w, c->h);
+        port_census(c->gray_r, c->census_r, c->w, c->h);
+    }
     port_cost(c);
     if (out) {
         DUMP(out->gray_left, c->gray_l, P); DUMP(out->gray_right, c->gray_r, P);
@@ -606,6 +709,20 @@ int adc_oracle_run(int32_t width, int32_t height, const adc_option* opt, const u
     port_ctx c;
     if (port_init(&c, width, height, opt)) return 1;
     if (!bgr_left || !bgr_right) { port_free(&c); return 2; }
+    port_pipeline(&c, bgr_left, bgr_right, dump);
+    port_free(&c);
+    return 0;
+}
+
+/* PORT ONLY (the reference has no such modes): the pipeline with the opt-in paper features of adc_set_paper_modes
+ * (bit 0: 5x5 census, bit 1: averaged instead of chained scanline paths, bit 2: right-image arms in the aggregation). */
+int adc_oracle_run_paper(int32_t width, int32_t height, const adc_option* opt, uint32_t paper_modes, const uint8_t* bgr_left,
+                         const uint8_t* bgr_right, adc_oracle_dump* dump)
+{
+    port_ctx c;
+    if (port_init(&c, width, height, opt)) return 1;
+    if (!bgr_left || !bgr_right) { port_free(&c); return 2; }
+    c.paper = paper_modes;
     port_pipeline(&c, bgr_left, bgr_right, dump);
     port_free(&c);
     return 0;

@@ -94,9 +94,10 @@ class Oracle:
         assert left.ndim == 3 and left.shape[2] == 3 and left.shape == right.shape
         return left, right
 
-    def run(self, left, right, opt=None, stages=None):
+    def run(self, left, right, opt=None, stages=None, paper_modes=0):
         """Runs the whole pipeline stage by stage; returns {stage name: ndarray}.
-        `stages`: iterable of names from DUMP_NAMES (default: all)."""
+        `stages`: iterable of names from DUMP_NAMES (default: all).  paper_modes != 0: the opt-in paper features of the
+        product's adc_set_paper_modes (port oracle only -- the reference does not implement them)."""
         opt = opt or Option()
         left, right = self._check_images(left, right)
         h, w = left.shape[:2]
@@ -111,7 +112,15 @@ class Oracle:
                     shape = (h, w) + tuple(d if s == "D" else s for s in shp)
                     out[name] = np.zeros(shape, dtype=dt)
                     setattr(dump, name, out[name].ctypes.data)
-        rc = self.lib.adc_oracle_run(w, h, C.byref(opt), left.ctypes.data, right.ctypes.data, C.byref(dump))
+        if paper_modes:
+            if self.kind != "port":
+                raise RuntimeError("paper modes exist in the port oracle only (the reference has no such code)")
+            self.lib.adc_oracle_run_paper.restype = C.c_int
+            self.lib.adc_oracle_run_paper.argtypes = [C.c_int32, C.c_int32, C.POINTER(Option), C.c_uint32, C.c_void_p, C.c_void_p,
+                                                      C.POINTER(_Dump)]
+            rc = self.lib.adc_oracle_run_paper(w, h, C.byref(opt), int(paper_modes), left.ctypes.data, right.ctypes.data, C.byref(dump))
+        else:
+            rc = self.lib.adc_oracle_run(w, h, C.byref(opt), left.ctypes.data, right.ctypes.data, C.byref(dump))
         if rc != 0:
             raise RuntimeError("oracle Initialize failed (rc=%d)" % rc)
         return out

@@ -25,13 +25,16 @@ def diff(got, want):
     return n, first
 
 
-def stage_report(left, right, opt, o, device=0):
-    """o = oracle dump dict (all stages). Returns {stage: {"bad": n, "total": N, "first": ...}}."""
+def stage_report(left, right, opt, o, device=0, paper_modes=0):
+    """o = oracle dump dict (all stages). Returns {stage: {"bad": n, "total": N, "first": ...}}.
+    paper_modes: opt-in paper features set on the handle (then `o` must come from the port oracle run with the same modes)."""
     h, w = left.shape[:2]
     st = A.ADCensusStereo(device=device)
     popt = cases.to_product_option(opt)
     if not st.Initialize(w, h, popt):
         raise RuntimeError("Initialize failed: " + A.last_error())
+    if paper_modes:
+        st.set_paper_modes(paper_modes)
     rep = {}
 
     def rec(name, got, want):
