@@ -1,6 +1,6 @@
 // k_paper.hip -- OPT-IN "paper" modes: features of the AD-Census paper that the reference declares or
 // stores but does not implement.  They are NOT the reference's behaviour (adc_set_paper_modes, default 0 = off) and have
-// their own oracle in oracle/adcensus_port.c (adc_oracle_run_paper), against which tests/test_gpu_paper.py compares them
+// their own checker -- the test suite's plain-C restatement of the same definitions -- against which tests/test_gpu_paper.py compares them
 // bit for bit.  Functional kernels, not tuned: one thread per volume element.
 //   ADC_PAPER_CENSUS5X5    5x5 census window (adcensus_types.h:39-42 declares CensusSize::Census5x5): in k_cost.hip
 //   ADC_PAPER_SO_SUM       the four scanline paths are computed independently from the aggregated volume and averaged

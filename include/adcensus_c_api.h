@@ -150,7 +150,7 @@ const char* adc_get_aggregate_kernel(adc_handle* h);
 
 /* OPT-IN paper modes: features of the AD-Census paper the reference declares or stores but does not
  * implement.  Default 0 = exactly the reference.  Any other value changes the results BY DEFINITION (no parity with the
- * reference; checked against oracle/adcensus_port.c's own restatement of the same definitions).  Functional, not tuned.
+ * reference; checked against the test suite's own plain-C restatement of the same definitions).  Functional, not tuned.
  *   ADC_PAPER_CENSUS5X5   5x5 census window (adcensus_types.h:39-42, CensusSize::Census5x5, declared / unimplemented)
  *   ADC_PAPER_SO_SUM      the four scanline paths computed independently and averaged (paper eq. 10) instead of chained
  *                         (scanline_optimizer.cpp:54-60)
