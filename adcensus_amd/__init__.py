@@ -92,6 +92,10 @@ def lib():
     L.adc_get_aggregate_info.restype = C.c_int
     L.adc_get_aggregate_kernel.argtypes = [vp]
     L.adc_get_aggregate_kernel.restype = C.c_char_p
+    L.adc_host_register.argtypes = [vp, C.c_size_t]
+    L.adc_host_register.restype = C.c_int
+    L.adc_host_unregister.argtypes = [vp]
+    L.adc_host_unregister.restype = C.c_int
     L.adc_set_paper_modes.argtypes = [vp, C.c_uint32]
     L.adc_set_paper_modes.restype = C.c_int
     L.adc_get_stream.argtypes = [vp]
@@ -139,6 +143,16 @@ def device_count():
 
 def last_error():
     return lib().adc_last_error().decode()
+
+
+def host_register(arr):
+    """Page-locks a numpy array for DMA straight from / to it (adc_host_register); call host_unregister before it dies."""
+    if lib().adc_host_register(arr.ctypes.data, arr.nbytes) != 0:
+        raise RuntimeError("adc_host_register failed: " + last_error())
+
+
+def host_unregister(arr):
+    lib().adc_host_unregister(arr.ctypes.data)
 
 
 def _img(a):

@@ -111,6 +111,7 @@ struct adc_handle {
     uint8_t* pin_in;  // 2 * 3*W*H
     float* pin_out;   // W*H
     float* async_dst;
+    int async_dst_direct; // 0 = via pin_out + host copy, 1 = DMA into the caller's page-locked map, 2 = pageable copy by adc_wait (ADC_HOST_DIRECT)
     void* device_dst;  // adc_match_device: the caller's device buffer (re-filled by the median fallback)
     // profiling
     int profiling, verbose;

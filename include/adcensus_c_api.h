@@ -103,6 +103,14 @@ int adc_match_device(adc_handle* h, const void* d_bgr_left, const void* d_bgr_ri
 int adc_match_async(adc_handle* h, const uint8_t* bgr_left, const uint8_t* bgr_right, float* disp_left);
 int adc_wait(adc_handle* h);
 
+/* Opt-in for host callers that keep their buffers alive: page-lock a host range (hipHostRegister) and tell the library.
+ * Images / disparity maps passed to adc_match / adc_match_async / adc_farm_submit that lie inside a registered range are
+ * then transferred by DMA straight from / to the caller's memory -- no pinned staging copies (2 x 6.2 MB in, 8.3 MB out
+ * per 1080p pair).  The caller must adc_host_unregister(ptr) BEFORE freeing the memory.  Process-wide, thread-safe.
+ * 0 ok, 1 bad argument / unknown pointer, 2 HIP failure. */
+int adc_host_register(void* ptr, size_t bytes);
+int adc_host_unregister(void* ptr);
+
 /* -------------------------------------------------------------------------------------------
  * Pair farm: a persistent set of `pipelines` matcher objects of one geometry on one device, each
  * with its own stream and pinned staging buffers (the ring), fed round-robin.  adc_farm_submit copies the pair into the

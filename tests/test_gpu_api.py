@@ -287,3 +287,26 @@ def test_aggregation_kernel_families_ab(hip, env):
             "sys.exit(1 if bad else 0)\n") % root
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_registered_host_buffers(hip, oracle):
+    """adc_host_register: images / map inside a page-locked range go by DMA straight from / to the caller's memory (no staging);
+    same result, also when only some of the three buffers are registered, and the plain path works again after unregister."""
+    A = hip
+    left, right, opt = cases.make_case("s2_96x64_d32")
+    want = oracle.run(left, right, opt, stages=["disp_final"])["disp_final"]
+    h, w = left.shape[:2]
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(w, h, cases.to_product_option(opt))
+    l, r, d = np.ascontiguousarray(left), np.ascontiguousarray(right), np.zeros((h, w), np.float32)
+    for regs in ((l, r, d), (l,), (d,), ()):
+        for arr in regs:
+            A.host_register(arr)
+        d[:] = -1
+        assert st.Match(l, r, d) and np.array_equal(d.view(np.uint32), want.view(np.uint32)), len(regs)
+        d[:] = -1
+        assert st.match_async(l, r, d) and st.wait() and np.array_equal(d.view(np.uint32), want.view(np.uint32))
+        for arr in regs:
+            A.host_unregister(arr)
+    assert A.lib().adc_host_unregister(l.ctypes.data) == 1  # unknown pointer
+    st.Release()
