@@ -450,16 +450,19 @@ int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, voi
     return 0;
 }
 
-int adc_match_async(adc_handle* h, const uint8_t* left, const uint8_t* right, float* disp)
+static int match_async_impl(adc_handle* h, const uint8_t* left, const uint8_t* right, float* disp, bool sync_call)
 {
     if (!h || !left || !right || !disp) return 1;
     hipSetDevice(h->device);
     const size_t P = (size_t)h->p.W * h->p.H;
     h->img_l = h->img_l_own;
     h->img_r = h->img_r_own;
-    // default: hand the caller's pageable pointers to the runtime (its own chunked staging: measured 145 vs 140 pairs/s for
-    // the synchronous adc_match at 1080p); ADC_HOST_DIRECT=0: stage through the handle's pinned buffers here
-    static const bool direct = [] { const char* e = getenv("ADC_HOST_DIRECT"); return e ? atoi(e) != 0 : true; }();
+    // Synchronous adc_match only (the caller cannot touch its buffers before the call returns): hand the pageable pointers to
+    // the runtime (its own chunked staging / pin-in-place: measured 145 vs 140 pairs/s at 1080p; ADC_HOST_DIRECT=0 switches it
+    // off).  The asynchronous entry points promise "the images may be reused as soon as the call returns", so they always
+    // stage through the handle's pinned buffers (complete on return) unless the caller registered its memory.
+    static const bool direct_env = [] { const char* e = getenv("ADC_HOST_DIRECT"); return e ? atoi(e) != 0 : true; }();
+    const bool direct = direct_env && sync_call;
     const bool reg_in = host_registered(left, P * 3) && host_registered(right, P * 3);
     if (reg_in || direct) { // DMA from the caller's memory (page-locked by the caller: asynchronous; pageable: the runtime stages)
         if (hipMemcpyAsync(h->img_l, left, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
@@ -476,6 +479,11 @@ int adc_match_async(adc_handle* h, const uint8_t* left, const uint8_t* right, fl
     h->device_dst = nullptr;
     if (enqueue_output(h) != hipSuccess) return 2;
     return 0;
+}
+
+int adc_match_async(adc_handle* h, const uint8_t* left, const uint8_t* right, float* disp)
+{
+    return match_async_impl(h, left, right, disp, false);
 }
 
 int adc_host_register(void* ptr, size_t bytes)
@@ -570,7 +578,7 @@ int adc_wait(adc_handle* h)
 
 int adc_match(adc_handle* h, const uint8_t* left, const uint8_t* right, float* disp)
 {
-    const int rc = adc_match_async(h, left, right, disp);
+    const int rc = match_async_impl(h, left, right, disp, true);
     if (rc != 0) return rc;
     return adc_wait(h);
 }
