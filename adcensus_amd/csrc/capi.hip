@@ -111,9 +111,12 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->lut_ad, 768 * sizeof(float)));
     HIP_OK(hipMalloc(&h->lut_census, 64 * sizeof(float)));
     HIP_OK(hipMalloc(&h->ray_sincos, 32 * sizeof(double)));
-    HIP_OK(hipMalloc(&h->disp_l, P * 4));
+    // (+ 1 KiB: the banded median prefetches a few columns past the last row's end without clamping, k_refine.hip)
+    HIP_OK(hipMalloc(&h->disp_l, P * 4 + 1024));
     HIP_OK(hipMalloc(&h->disp_r, P * 4));
-    HIP_OK(hipMalloc(&h->disp_tmp, P * 4));
+    HIP_OK(hipMalloc(&h->disp_tmp, P * 4 + 1024));
+    HIP_OK(hipMemset(h->disp_l + P, 0, 1024));
+    HIP_OK(hipMemset(h->disp_tmp + P, 0, 1024));
     HIP_OK(hipMalloc(&h->label, P));
     HIP_OK(hipMalloc(&h->elig, P));
     HIP_OK(hipMalloc(&h->irv_bbox, P * 4));

@@ -618,13 +618,29 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
 #define MEDB_ROWS 64
 #define MEDB_K 16 // levels per block (the asm take-over statements are written for 16)
 #define MEDB_HPAD 4 // hand[band][MEDB_HPAD + t]
+#ifndef MEDB_SLACK
+#define MEDB_SLACK 16 // levels of extra upstream progress a band waits for once it has to poll (32 measured 30 us slower at 1080p)
+#endif
 
 typedef float medb_v4f __attribute__((ext_vector_type(4)));
 template <int CTRL> __device__ __forceinline__ float medb_dpp(float src)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, 0xf, 0xf, false));
 }
+// ... with the value a lane WITHOUT a source lane keeps (lane 0 of wave_shr:1, lane 63 of wave_shl:1)
+template <int CTRL> __device__ __forceinline__ float medb_dpp_old(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, 0xf, false));
+}
 
+typedef float medb_v2f __attribute__((ext_vector_type(2)));
+// PAIRS (W even): a row's column has the parity of the level (x = t - 2y), so all lanes step from an even to an odd column
+// together: the window prefetch and the map stores move TWO columns per instruction (8-byte, aligned stores).  With one
+// lane per row every vector-memory instruction of this kernel touches 64 different cache lines; SQ counters of the
+// one-column form: 35 % of the wave's cycles in s_waitcnt although the data is prefetched a block ahead, and removing a
+// third of its vector instructions changed nothing -- it is bound by the rate at which the address coalescer takes those
+// 64-line instructions.  Half as many of them: see profiles/README.md.  Odd widths run the one-column form.
+template <bool PAIRS>
 __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* __restrict__ out, int W, int H,
                                                              int* progress, int* error_word, float* hand, int hpitch)
 {
@@ -632,6 +648,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     const int band = blockIdx.x;
     const int y = band * MEDB_ROWS + tid;
     const int nsteps = W + 2 * (H - 1);
+    const int yfirst = band * MEDB_ROWS, ylast = adc_imin(yfirst + MEDB_ROWS, H) - 1; // rows of this band (wave-uniform)
     const bool row_ok = y < H;
     const bool up = y > 0, dn = y + 1 < H;
     const bool first_row = tid == 0 && band > 0;                  // reads the upstream band's last row
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     const int ya = row_ok ? y : H - 1, yb = y + 1 < H ? y + 1 : H - 1;
     const float* rowA = in + (size_t)ya * W;
     // one auxiliary load stream serves two lanes: lane 0 of a band > 0 reads the upstream hand-off row (by level), the
-    // band's last lane reads the unfiltered row below (column x+1); every other lane reads dummy element 0 of `in`,
+    // band's last lane reads the unfiltered row below (column x+1); every other lane reads dummy elements of `in`,
     // so the loads are unconditional yet cost a single cache line per instruction
     const float* rowX = first_row ? hand + (size_t)(band - 1) * hpitch + MEDB_HPAD - 1 : in + (own_b ? (size_t)yb * W : 0);
     const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
@@ -652,46 +669,80 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     float Fm = 0.f, F0 = 0.f, Pv = 0.f;
     // Prefetch, one block of MEDB_K levels ahead, with the loads issued from inline asm (the compiler's own model of
     // loop-carried outstanding loads forces near-complete drains of the memory counter, i.e. of the stores in
-    // flight).  Every block issues EXACTLY, in this order: 32 loads, 16 map stores (inactive lanes store to a sink
-    // word), 4 hand-off stores, 1 progress store; vector-memory operations complete in issue order, so counted waits
-    // are exact:
-    //   vmcnt(21) before a block    -> the 32 loads issued one block earlier have landed;
-    //   vmcnt(53) before publishing -> the hand-off stores of the PREVIOUS block have completed (only the previous
+    // flight).  Every block issues EXACTLY, in this order: NL loads, NS map stores (inactive lanes store to a sink
+    // word), 4 hand-off stores, 1 progress store (one column per instruction: NL = 32, NS = 16; PAIRS: 16 and 8);
+    // vector-memory operations complete in issue order, so counted waits are exact:
+    //   vmcnt(NS + 5) before a block         -> the loads issued one block earlier have landed;
+    //   vmcnt(NL + NS + 5) before publishing -> the hand-off stores of the PREVIOUS block have completed (only the previous
     //                                  progress store, this block's loads and stores may be outstanding): "levels
     //                                  completed" is published one block late, so no store drain sits on the
     //                                  critical path.
-    float ca[MEDB_K], cx[MEDB_K], ra[MEDB_K], rx[MEDB_K], hr[MEDB_K];
+    float ca[MEDB_K], cx[MEDB_K], hr[MEDB_K];
+    float ra[PAIRS ? 1 : MEDB_K], rx[PAIRS ? 1 : MEDB_K];
+    medb_v2f ra2a[PAIRS ? MEDB_K / 2 : 1], rx2a[PAIRS ? MEDB_K / 2 : 1];
+    medb_v2f ca2[PAIRS ? MEDB_K / 2 : 1], cx2[PAIRS ? MEDB_K / 2 : 1];
 // take over the prefetched values: wait + moves in ONE statement, nothing can be hoisted above the wait
-#define MEDB_TAKE8(DST, SRC, O, WAIT)                                                                                   \
-    asm volatile(WAIT "v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"               \
-                      "v_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"                 \
+#define MEDB_TAKE8(MOV, DST, SRC, O, WAIT)                                                                              \
+    asm volatile(WAIT MOV " %0, %8\n\t" MOV " %1, %9\n\t" MOV " %2, %10\n\t" MOV " %3, %11\n\t"                          \
+                      MOV " %4, %12\n\t" MOV " %5, %13\n\t" MOV " %6, %14\n\t" MOV " %7, %15"                            \
                  : "=&v"(DST[O]), "=&v"(DST[O + 1]), "=&v"(DST[O + 2]), "=&v"(DST[O + 3]), "=&v"(DST[O + 4]),           \
                    "=&v"(DST[O + 5]), "=&v"(DST[O + 6]), "=&v"(DST[O + 7])                                              \
                  : "v"(SRC[O]), "v"(SRC[O + 1]), "v"(SRC[O + 2]), "v"(SRC[O + 3]), "v"(SRC[O + 4]), "v"(SRC[O + 5]),    \
                    "v"(SRC[O + 6]), "v"(SRC[O + 7])                                                                     \
                  : "memory")
-#define MEDB_TAKE(WAIT)                                                                                                 \
+#define MEDB_TAKE(SET, WAIT1, WAIT2)                                                                                    \
     do {                                                                                                                \
-        MEDB_TAKE8(ca, ra, 0, WAIT);                                                                                    \
-        MEDB_TAKE8(ca, ra, 8, "");                                                                                      \
-        MEDB_TAKE8(cx, rx, 0, "");                                                                                      \
-        MEDB_TAKE8(cx, rx, 8, "");                                                                                      \
+        if constexpr (PAIRS) {                                                                                          \
+            MEDB_TAKE8("v_mov_b64", ca2, ra2##SET, 0, WAIT2);                                                           \
+            MEDB_TAKE8("v_mov_b64", cx2, rx2##SET, 0, "");                                                              \
+            _Pragma("unroll") for (int q_ = 0; q_ < MEDB_K / 2; q_++) {                                                 \
+                ca[2 * q_] = ca2[q_].x; ca[2 * q_ + 1] = ca2[q_].y;                                                     \
+                cx[2 * q_] = cx2[q_].x; cx[2 * q_ + 1] = cx2[q_].y;                                                     \
+            }                                                                                                           \
+        } else {                                                                                                        \
+            MEDB_TAKE8("v_mov_b32", ca, ra, 0, WAIT1);                                                                  \
+            MEDB_TAKE8("v_mov_b32", ca, ra, 8, "");                                                                     \
+            MEDB_TAKE8("v_mov_b32", cx, rx, 0, "");                                                                     \
+            MEDB_TAKE8("v_mov_b32", cx, rx, 8, "");                                                                     \
+        }                                                                                                               \
     } while (0)
-// the 32 loads of the block that starts at level T (this row is then at column XN)
-#define MEDB_ISSUE(T, XN)                                                                                               \
-    _Pragma("unroll") for (int k = 0; k < MEDB_K; k++) {                                                                \
-        const float* pa_ = rowA + clampc((XN) + 3 + k);                                                                 \
-        const int ix_ = first_row ? (T) + k : (own_b ? clampc((XN) + 1 + k) : 0);                                       \
-        const float* px_ = rowX + ix_;                                                                                  \
-        asm volatile("global_load_dword %0, %1, off" : "=v"(ra[k]) : "v"(pa_) : "memory");                              \
-        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(rx[k]) : "v"(px_) : "memory");                          \
-    }
+// The loads of the next block of MEDB_K levels: running per-lane pointers + immediate offsets, NO column clamps (a
+// clamp + 64-bit address per load was a fifth of the kernel's instructions).  Row y reads in[y][x+3 ..] with x = t - 2y:
+// for x < 0 that is data of earlier rows (the lane is idle then), beyond the row end the next row's head -- never
+// consumed (border substitutions / idle lanes), always inside the allocation: the lowest address is in + y*(W-2) + 3,
+// the highest in + W*H + 2*MEDB_K + 2 (the disparity maps are allocated with that much slack, capi.hip).  Lanes
+// without a row (y >= H) and the auxiliary stream of lanes that need none re-read in[0..15] (stride 0).
+#define MEDB_LD1(K)                                                                                                     \
+    asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(ra[PAIRS ? 0 : (K)]) : "v"(pA), "n"(4 * (K)) : "memory"); \
+    asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "=v"(rx[PAIRS ? 0 : (K)]) : "v"(pX), "n"(4 * (K)) : "memory");
+#define MEDB_LD2(SET, Q)                                                                                                \
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(ra2##SET[PAIRS ? (Q) : 0]) : "v"(pA), "n"(8 * (Q)) : "memory"); \
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2 sc1" : "=v"(rx2##SET[PAIRS ? (Q) : 0]) : "v"(pX), "n"(8 * (Q)) : "memory");
+#define MEDB_ISSUE(SET)                                                                                                 \
+    do {                                                                                                                \
+        if constexpr (PAIRS) {                                                                                          \
+            MEDB_LD2(SET, 0) MEDB_LD2(SET, 1) MEDB_LD2(SET, 2) MEDB_LD2(SET, 3) MEDB_LD2(SET, 4) MEDB_LD2(SET, 5)       \
+            MEDB_LD2(SET, 6) MEDB_LD2(SET, 7)                                                                           \
+        } else {                                                                                                        \
+            MEDB_LD1(0) MEDB_LD1(1) MEDB_LD1(2) MEDB_LD1(3) MEDB_LD1(4) MEDB_LD1(5) MEDB_LD1(6) MEDB_LD1(7)             \
+            MEDB_LD1(8) MEDB_LD1(9) MEDB_LD1(10) MEDB_LD1(11) MEDB_LD1(12) MEDB_LD1(13) MEDB_LD1(14) MEDB_LD1(15)       \
+        }                                                                                                               \
+        pA += strideA;                                                                                                  \
+        pX += strideX;                                                                                                  \
+    } while (0)
+    static_assert(MEDB_K == 16, "MEDB_ISSUE is written for 16 levels per block");
+    const int strideA = row_ok ? MEDB_K : 0, strideX = (first_row || (own_b && row_ok)) ? MEDB_K : 0;
+    const float* pA = row_ok ? rowA + (x + 3) : in;
+    // auxiliary stream: lane 0 of a band > 0 -> hand-off row of the upstream band by level (rowX[t + k] = its result of level
+    // t + k - 1; block 0 is idle there), the band's last lane -> unfiltered row below at column x + 1 + k
+    const float* pX = first_row ? rowX : ((own_b && row_ok) ? rowX + (x + 1) : in);
     // block 0: a band's first row is idle there (x < 0), whatever it reads from the hand-off row is never used
-    MEDB_ISSUE(1, x);
-    MEDB_TAKE("s_waitcnt vmcnt(0)\n\t");
+    MEDB_ISSUE(a);
+    MEDB_TAKE(a, "s_waitcnt vmcnt(0)\n\t", "s_waitcnt vmcnt(0)\n\t");
+
     // the compiler-issued window loads above are consumed here, so that no wait for them ends up inside the loop
     asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(Bm), "+v"(B0));
-    float* const sinkf = reinterpret_cast<float*>(error_word + 2);  // store target of inactive lanes
+    float* const sinkf = reinterpret_cast<float*>(error_word + 2);  // store target of inactive lanes (8 bytes, 8-byte aligned)
     float* const sink4 = reinterpret_cast<float*>(error_word + 4);  // 16-byte sink (hand-off stores of the other lanes)
     int* const pubp = last_row ? progress + band : error_word + 3;  // progress word of the band (sink for the other lanes)
     float* const hrow = hand + (size_t)band * hpitch + MEDB_HPAD;
@@ -699,78 +750,136 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     const int* upstream = progress + (band > 0 ? band - 1 : 0);
     float* const orow = out + (size_t)(row_ok ? y : 0) * W;
 
-    for (int t0 = 0;;) {
-        // band > 0 stays behind the upstream band: this block uses hand-off values of levels < t0+MEDB_K-1 and
-        // prefetches those of the next block (levels < t0 + 2*MEDB_K - 1).  The progress word is normally read one
-        // block ahead of its use (scalar load past the scalar cache, tracked by lgkmcnt: nothing on the critical
-        // path); only when that stale value is not enough the band polls, and then it waits for two extra blocks of
-        // slack so that the following stale reads succeed.
-        if (band > 0) {
-            const int need = t0 + 2 * MEDB_K < nsteps ? t0 + 2 * MEDB_K : nsteps;
-            int plv;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, %1" : "=&s"(plv) : "s"(pl) : "memory");
-            seen = plv > seen ? plv : seen;
-            if (seen < need) {
-                const int want = need + 2 * MEDB_K < nsteps ? need + 2 * MEDB_K : nsteps;
-                int spins = 0;
-                while (true) {
-                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(seen) : "s"(upstream) : "memory");
-                    if (seen >= want) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1 << 22)) { atomicExch(error_word, 1); return; }
-                }
-            }
-            asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(pl) : "s"(upstream) : "memory");
-        }
-        MEDB_ISSUE(t0 + MEDB_K, x + MEDB_K);
-#pragma unroll
-        for (int k = 0; k < MEDB_K; k++) {
-            const bool active = row_ok && (x >= 0) && (x < W);
-            // newest filtered value of the row above: out[y-1][x+1] was produced by lane-1 at the previous level
-            const float F1d = medb_dpp<0x138>(Pv);    // wave_shr:1
-            const float B1d = medb_dpp<0x130>(ca[k]); // wave_shl:1: lane+1's in[y+1][(x-2)+3]
-            const float F1 = first_row ? cx[k] : F1d;
-            const float B1 = own_b ? cx[k] : B1d;
-            const bool lf = x > 0, rt = x + 1 < W;
-            const float v0 = (up && lf) ? Fm : PINF, v1 = up ? F0 : NINF, v2 = (up && rt) ? F1 : PINF;
-            const float v3 = lf ? Pv : NINF, v5 = rt ? A1 : NINF;
-            const float v6 = (dn && lf) ? Bm : PINF, v7 = dn ? B0 : NINF, v8 = (dn && rt) ? B1 : PINF;
-            // the triple that holds the two late values (F1, Pv) goes last
-            const float res = adc_median9(v0, v1, v6, v5, v7, v8, v2, v3, A0);
-            float* dst = active ? orow + x : sinkf;
-            asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(res) : "memory");
-            hr[k] = res;
-            Pv = active ? res : Pv;
-            Fm = F0; F0 = F1;
-            A0 = A1; A1 = A2; A2 = ca[k];
-            Bm = B0; B0 = B1;
-            x++;
-        }
-        {
-            float* hp = last_row ? hrow + t0 : sink4;
-            const int hs = last_row ? 4 : 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const medb_v4f hv = {hr[4 * j], hr[4 * j + 1], hr[4 * j + 2], hr[4 * j + 3]};
-                float* hq = hp + hs * j;
-                // through to memory.  The s_nop covers the ">64-bit store data, then VALU write of those VGPRs" hazard
-                // the assembler cannot see inside an asm statement (the next tuple is assembled right behind).
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(hq), "v"(hv) : "memory");
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(53)\n\tglobal_store_dword %0, %1, off sc1" ::"v"(pubp), "v"(t0) : "memory");
-        t0 += MEDB_K;
-        if (t0 >= nsteps) break;
-        MEDB_TAKE("s_waitcnt vmcnt(21)\n\t");
+    // One block of MEDB_K levels (SI = register set the prefetch of this iteration goes into, ST = set taken over at its end).
+    // band > 0 stays behind the upstream band: the block uses hand-off values of levels < t0+MEDB_K-1 and prefetches those of
+    // the block(s) ahead.  The progress word is normally read one block ahead of its use (scalar load past the scalar cache,
+    // tracked by lgkmcnt: nothing on the critical path); only when that stale value is not enough the band polls, and then
+    // it waits for two extra blocks of slack so that the following stale reads succeed.
+    // Levels at which some row of the band stands on its first or last column (row y is at x = 0 on level 2y and at x = W-1
+    // on level W-1+2y) need the left / right border substitutions: wave-uniform 16-bit mask, one scalar bit test per level;
+    // every other level runs the short form of the body.  The newest filtered value of the row above (out[y-1][x+1],
+    // produced by lane-1 at the previous level) comes by DPP wave_shr:1; a band's first lane has no lane above and takes the
+    // upstream band's hand-off value instead -- the DPP's `old` operand, which lanes without a source keep.  Same for the
+    // unfiltered row below (lane+1's prefetch by wave_shl:1; the band's last lane loads that row itself).
+    // PAIRS: levels 2q, 2q+1 = columns x (even), x+1 of every row: one aligned 8-byte store (W even: a row is active on both
+    // levels or on neither).  The hand-off stores go through to memory (sc1); the s_nop covers the ">64-bit store data, then
+    // VALU write of those VGPRs" hazard the assembler cannot see inside an asm statement.
+#define MEDB_POLL(AHEAD)                                                                                                \
+    do {                                                                                                                \
+        if (band > 0 && t0 + (AHEAD) > 2 * yfirst - 2) {                                                               \
+            const int ahead = AHEAD;                                                                                    \
+            const int need = t0 + ahead < nsteps ? t0 + ahead : nsteps;                                                 \
+            int plv;                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, %1" : "=&s"(plv) : "s"(pl) : "memory");                 \
+            seen = plv > seen ? plv : seen;                                                                             \
+            if (seen < need) {                                                                                          \
+                const int want = need + MEDB_SLACK < nsteps ? need + MEDB_SLACK : nsteps;                               \
+                int spins = 0;                                                                                          \
+                while (true) {                                                                                          \
+                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(seen) : "s"(upstream) : "memory"); \
+                    if (seen >= want) break;                                                                            \
+                    __builtin_amdgcn_s_sleep(2);                                                                        \
+                    if (++spins > (1 << 22)) { atomicExch(error_word, 1); return; }                                     \
+                }                                                                                                       \
+            }                                                                                                           \
+            asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(pl) : "s"(upstream) : "memory");                         \
+        }                                                                                                               \
+    } while (0)
+// per block: [poll][loads for the next block][levels + map stores][4 hand-off stores][progress][take] -- vector-memory operations
+// per block: one column per instruction 32 + 16 + 4 + 1, PAIRS 16 + 8 + 4 + 1.  Wait before the progress store: only the previous
+// progress store and this block's loads and stores may be outstanding (53 / 29: the PREVIOUS block's hand-off stores are then
+// complete -- progress is published one block late); wait before the take-over: the stores of this block (21 / 13).
+#define MEDB_BLOCK()                                                                                                    \
+    do {                                                                                                                \
+        MEDB_POLL(2 * MEDB_K);                                                                                          \
+        MEDB_ISSUE(a);                                                                                                  \
+        uint32_t bmask;                                                                                                 \
+        {                                                                                                               \
+            const int lo_l = 2 * yfirst - t0, hi_l = 2 * ylast - t0;                                                    \
+            const int lo_r = lo_l + (W - 1), hi_r = hi_l + (W - 1);                                                     \
+            const uint32_t ml = (hi_l < 0 || lo_l > 15) ? 0u : ((((2u << adc_imin(hi_l, 15)) - 1u) & ~((1u << adc_imax(lo_l, 0)) - 1u)) & 0x5555u); \
+            const uint32_t mr = (hi_r < 0 || lo_r > 15) ? 0u : ((((2u << adc_imin(hi_r, 15)) - 1u) & ~((1u << adc_imax(lo_r, 0)) - 1u)) & (((W - 1) & 1) ? 0xAAAAu : 0x5555u)); \
+            bmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ml | mr));                                           \
+        }                                                                                                               \
+        float res_even = 0.f;                                                                                           \
+_Pragma("unroll")                                                                                                       \
+        for (int k = 0; k < MEDB_K; k++) {                                                                              \
+            const bool active = row_ok && (x >= 0) && (x < W);                                                          \
+            const float F1 = medb_dpp_old<0x138>(cx[k], Pv);                                                            \
+            const float B1 = medb_dpp_old<0x130>(cx[k], ca[k]);                                                         \
+            float res;                                                                                                  \
+            if (bmask & (1u << k)) {                                                                                    \
+                const bool lf = x > 0, rt = x + 1 < W;                                                                  \
+                const float v0 = (up && lf) ? Fm : PINF, v1 = up ? F0 : NINF, v2 = (up && rt) ? F1 : PINF;              \
+                const float v3 = lf ? Pv : NINF, v5 = rt ? A1 : NINF;                                                   \
+                const float v6 = (dn && lf) ? Bm : PINF, v7 = dn ? B0 : NINF, v8 = (dn && rt) ? B1 : PINF;              \
+                res = adc_median9(v0, v1, v6, v5, v7, v8, v2, v3, A0);                                                  \
+            } else {                                                                                                    \
+                const float v0 = up ? Fm : PINF, v1 = up ? F0 : NINF, v2 = up ? F1 : PINF;                              \
+                const float v6 = dn ? Bm : PINF, v7 = dn ? B0 : NINF, v8 = dn ? B1 : PINF;                              \
+                res = adc_median9(v0, v1, v6, A1, v7, v8, v2, Pv, A0);                                                  \
+            }                                                                                                           \
+            if constexpr (PAIRS) {                                                                                      \
+                if ((k & 1) == 0) res_even = res;                                                                       \
+                else {                                                                                                  \
+                    const medb_v2f pr = {res_even, res};                                                                \
+                    float* dst = (row_ok && x >= 1 && x < W) ? orow + (x - 1) : sinkf;                                  \
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pr) : "memory");                    \
+                }                                                                                                       \
+            } else {                                                                                                    \
+                float* dst = active ? orow + x : sinkf;                                                                 \
+                asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(res) : "memory");                         \
+            }                                                                                                           \
+            hr[k] = res;                                                                                                \
+            Pv = active ? res : Pv;                                                                                     \
+            Fm = F0; F0 = F1;                                                                                           \
+            A0 = A1; A1 = A2; A2 = ca[k];                                                                               \
+            Bm = B0; B0 = B1;                                                                                           \
+            x++;                                                                                                        \
+        }                                                                                                               \
+        {                                                                                                               \
+            float* hp = last_row ? hrow + t0 : sink4;                                                                   \
+            const int hs = last_row ? 4 : 0;                                                                            \
+_Pragma("unroll")                                                                                                       \
+            for (int j = 0; j < 4; j++) {                                                                               \
+                const medb_v4f hv = {hr[4 * j], hr[4 * j + 1], hr[4 * j + 2], hr[4 * j + 3]};                           \
+                float* hq = hp + hs * j;                                                                                \
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(hq), "v"(hv) : "memory");          \
+            }                                                                                                           \
+        }                                                                                                               \
+        if constexpr (PAIRS) asm volatile("s_waitcnt vmcnt(29)\n\tglobal_store_dword %0, %1, off sc1" ::"v"(pubp), "v"(t0) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(53)\n\tglobal_store_dword %0, %1, off sc1" ::"v"(pubp), "v"(t0) : "memory"); \
+        t0 += MEDB_K;                                                                                                   \
+        done = t0 >= nsteps;                                                                                            \
+        if (!done) MEDB_TAKE(a, "s_waitcnt vmcnt(21)\n\t", "s_waitcnt vmcnt(13)\n\t");                                 \
+    } while (0)
+    {
+        int t0 = 0;
+        bool done = false;
+        while (!done) MEDB_BLOCK();
     }
+#undef MEDB_BLOCK
+#undef MEDB_POLL
     // (the prefetch of the block past the end is never taken: its registers must stay reserved until it has landed)
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]),
-                 "v"(ra[7]), "v"(ra[8]), "v"(ra[9]), "v"(ra[10]), "v"(ra[11]), "v"(ra[12]), "v"(ra[13]), "v"(ra[14]),
-                 "v"(ra[15]) : "memory");
-    asm volatile("" ::"v"(rx[0]), "v"(rx[1]), "v"(rx[2]), "v"(rx[3]), "v"(rx[4]), "v"(rx[5]), "v"(rx[6]), "v"(rx[7]),
-                 "v"(rx[8]), "v"(rx[9]), "v"(rx[10]), "v"(rx[11]), "v"(rx[12]), "v"(rx[13]), "v"(rx[14]), "v"(rx[15]) : "memory");
+    if constexpr (PAIRS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(ra2a[0]), "v"(ra2a[1]), "v"(ra2a[2]), "v"(ra2a[3]), "v"(ra2a[4]), "v"(ra2a[5]), "v"(ra2a[6]),
+                     "v"(ra2a[7]) : "memory");
+        asm volatile("" ::"v"(rx2a[0]), "v"(rx2a[1]), "v"(rx2a[2]), "v"(rx2a[3]), "v"(rx2a[4]), "v"(rx2a[5]), "v"(rx2a[6]), "v"(rx2a[7]) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]), "v"(ra[4]), "v"(ra[5]), "v"(ra[6]),
+                     "v"(ra[7]), "v"(ra[8 % (PAIRS ? 1 : MEDB_K)]), "v"(ra[9 % (PAIRS ? 1 : MEDB_K)]), "v"(ra[10 % (PAIRS ? 1 : MEDB_K)]),
+                     "v"(ra[11 % (PAIRS ? 1 : MEDB_K)]), "v"(ra[12 % (PAIRS ? 1 : MEDB_K)]), "v"(ra[13 % (PAIRS ? 1 : MEDB_K)]),
+                     "v"(ra[14 % (PAIRS ? 1 : MEDB_K)]), "v"(ra[15 % (PAIRS ? 1 : MEDB_K)]) : "memory");
+        asm volatile("" ::"v"(rx[0]), "v"(rx[1 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[2 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[3 % (PAIRS ? 1 : MEDB_K)]),
+                     "v"(rx[4 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[5 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[6 % (PAIRS ? 1 : MEDB_K)]),
+                     "v"(rx[7 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[8 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[9 % (PAIRS ? 1 : MEDB_K)]),
+                     "v"(rx[10 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[11 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[12 % (PAIRS ? 1 : MEDB_K)]),
+                     "v"(rx[13 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[14 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[15 % (PAIRS ? 1 : MEDB_K)]) : "memory");
+    }
     if (last_row) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef MEDB_ISSUE
+#undef MEDB_LD1
+#undef MEDB_LD2
 #undef MEDB_TAKE
 #undef MEDB_TAKE8
 }
@@ -811,8 +920,14 @@ hipError_t adc_launch_median(adc_handle* h)
         int* prog = h->vote_counters + 160;
         // layout: prog[0..255] band progress, prog[260] error word, prog[262..267] store sinks of idle lanes
         hipMemsetAsync(prog, 0, 272 * sizeof(int32_t), h->stream);
-        hipLaunchKernelGGL(k_median_banded, dim3(nbands), dim3(MEDB_ROWS), 0, h->stream, h->disp_l, h->disp_tmp, p.W, p.H, prog,
-                           prog + 260, h->med_hand, h->med_hpitch);
+        // pairs of columns per instruction when the width is even (ADC_MEDIAN_PAIRS=0: always one column per instruction)
+        static const bool pairs_env = [] { const char* e = getenv("ADC_MEDIAN_PAIRS"); return e ? atoi(e) != 0 : true; }();
+        if (pairs_env && (p.W & 1) == 0)
+            hipLaunchKernelGGL(k_median_banded<true>, dim3(nbands), dim3(MEDB_ROWS), 0, h->stream, h->disp_l, h->disp_tmp, p.W, p.H, prog,
+                               prog + 260, h->med_hand, h->med_hpitch);
+        else
+            hipLaunchKernelGGL(k_median_banded<false>, dim3(nbands), dim3(MEDB_ROWS), 0, h->stream, h->disp_l, h->disp_tmp, p.W, p.H, prog,
+                               prog + 260, h->med_hand, h->med_hpitch);
         if (h->pin_flags) hipMemcpyAsync(h->pin_flags, prog + 260, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream); // checked by adc_wait
         float* t = h->disp_l;
         h->disp_l = h->disp_tmp;
