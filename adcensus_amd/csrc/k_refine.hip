@@ -618,9 +618,7 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
 #define MEDB_ROWS 64
 #define MEDB_K 16 // levels per block (the asm take-over statements are written for 16)
 #define MEDB_HPAD 4 // hand[band][MEDB_HPAD + t]
-#ifndef MEDB_SLACK
-#define MEDB_SLACK 16 // levels of extra upstream progress a band waits for once it has to poll (32 measured 30 us slower at 1080p)
-#endif
+
 
 typedef float medb_v4f __attribute__((ext_vector_type(4)));
 template <int CTRL> __device__ __forceinline__ float medb_dpp(float src)
@@ -744,10 +742,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(Bm), "+v"(B0));
     float* const sinkf = reinterpret_cast<float*>(error_word + 2);  // store target of inactive lanes (8 bytes, 8-byte aligned)
     float* const sink4 = reinterpret_cast<float*>(error_word + 4);  // 16-byte sink (hand-off stores of the other lanes)
-    int* const pubp = last_row ? progress + band : error_word + 3;  // progress word of the band (sink for the other lanes)
     float* const hrow = hand + (size_t)band * hpitch + MEDB_HPAD;
-    int seen = 0, pl = 0; // upstream progress: last value observed / value fetched asynchronously during the previous block
-    const int* upstream = progress + (band > 0 ? band - 1 : 0);
     float* const orow = out + (size_t)(row_ok ? y : 0) * W;
 
     // One block of MEDB_K levels (SI = register set the prefetch of this iteration goes into, ST = set taken over at its end).
@@ -764,34 +759,34 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     // PAIRS: levels 2q, 2q+1 = columns x (even), x+1 of every row: one aligned 8-byte store (W even: a row is active on both
     // levels or on neither).  The hand-off stores go through to memory (sc1); the s_nop covers the ">64-bit store data, then
     // VALU write of those VGPRs" hazard the assembler cannot see inside an asm statement.
-#define MEDB_POLL(AHEAD)                                                                                                \
+// Hand-off without progress words: the hand-off rows are filled with a sentinel (all ones: a NaN no disparity map contains)
+// before the launch, the upstream band overwrites them level by level (16-byte sc1 stores), and a band simply looks at the
+// values it has just taken over: a sentinel among the 16 values of the next block means "not written yet" -> read the block
+// again (bounded).  The data is its own flag: no publication one block late, no polling protocol, a band trails its upstream
+// band by the store latency + the prefetch distance only.  T1 = first level of the block just taken over; values of levels
+// before the band's first row becomes active are never consumed and are not waited for.
+#define MEDB_RECHECK(T1)                                                                                                \
     do {                                                                                                                \
-        if (band > 0 && t0 + (AHEAD) > 2 * yfirst - 2) {                                                               \
-            const int ahead = AHEAD;                                                                                    \
-            const int need = t0 + ahead < nsteps ? t0 + ahead : nsteps;                                                 \
-            int plv;                                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, %1" : "=&s"(plv) : "s"(pl) : "memory");                 \
-            seen = plv > seen ? plv : seen;                                                                             \
-            if (seen < need) {                                                                                          \
-                const int want = need + MEDB_SLACK < nsteps ? need + MEDB_SLACK : nsteps;                               \
-                int spins = 0;                                                                                          \
-                while (true) {                                                                                          \
-                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(seen) : "s"(upstream) : "memory"); \
-                    if (seen >= want) break;                                                                            \
-                    __builtin_amdgcn_s_sleep(2);                                                                        \
-                    if (++spins > (1 << 22)) { atomicExch(error_word, 1); return; }                                     \
-                }                                                                                                       \
+        if (band > 0 && (T1) + MEDB_K > 2 * yfirst - 2) {                                                               \
+            int spins = 0;                                                                                              \
+            while (true) {                                                                                              \
+                uint32_t mx = 0u;                                                                                       \
+                _Pragma("unroll") for (int q_ = 0; q_ < MEDB_K; q_++) mx = mx > __float_as_uint(cx[q_]) ? mx : __float_as_uint(cx[q_]); \
+                if (__ballot(first_row && mx == 0xFFFFFFFFu) == 0ull) break;                                            \
+                if (++spins > (1 << 20)) { atomicExch(error_word, 1); return; }                                         \
+                __builtin_amdgcn_s_sleep(1);                                                                            \
+                const float* pr_ = pX - strideX; /* the block just taken over (pX already stands on the next one) */     \
+                _Pragma("unroll") for (int q_ = 0; q_ < MEDB_K; q_++) /* device-scope loads: past the caches */           \
+                    cx[q_] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(pr_) + q_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); \
             }                                                                                                           \
-            asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(pl) : "s"(upstream) : "memory");                         \
         }                                                                                                               \
     } while (0)
-// per block: [poll][loads for the next block][levels + map stores][4 hand-off stores][progress][take] -- vector-memory operations
-// per block: one column per instruction 32 + 16 + 4 + 1, PAIRS 16 + 8 + 4 + 1.  Wait before the progress store: only the previous
-// progress store and this block's loads and stores may be outstanding (53 / 29: the PREVIOUS block's hand-off stores are then
-// complete -- progress is published one block late); wait before the take-over: the stores of this block (21 / 13).
+// per block: [loads for the next block][levels + map stores][4 hand-off stores][take + sentinel check] -- vector-memory operations
+// per block: one column per instruction 32 + 16 + 4, PAIRS 16 + 8 + 4; wait before the take-over: the stores of this block
+// (20 / 12) may stay outstanding.  (Hand-off stores issued every 4 levels instead of at the end of the block were measured:
+// 1.10 ms instead of 0.70 at 1080p -- a downstream band then finds blocks half written and pays a re-read per block.)
 #define MEDB_BLOCK()                                                                                                    \
     do {                                                                                                                \
-        MEDB_POLL(2 * MEDB_K);                                                                                          \
         MEDB_ISSUE(a);                                                                                                  \
         uint32_t bmask;                                                                                                 \
         {                                                                                                               \
@@ -847,11 +842,12 @@ _Pragma("unroll")                                                               
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(hq), "v"(hv) : "memory");          \
             }                                                                                                           \
         }                                                                                                               \
-        if constexpr (PAIRS) asm volatile("s_waitcnt vmcnt(29)\n\tglobal_store_dword %0, %1, off sc1" ::"v"(pubp), "v"(t0) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(53)\n\tglobal_store_dword %0, %1, off sc1" ::"v"(pubp), "v"(t0) : "memory"); \
         t0 += MEDB_K;                                                                                                   \
         done = t0 >= nsteps;                                                                                            \
-        if (!done) MEDB_TAKE(a, "s_waitcnt vmcnt(21)\n\t", "s_waitcnt vmcnt(13)\n\t");                                 \
+        if (!done) {                                                                                                    \
+            MEDB_TAKE(a, "s_waitcnt vmcnt(20)\n\t", "s_waitcnt vmcnt(12)\n\t");                                         \
+            MEDB_RECHECK(t0);                                                                                           \
+        }                                                                                                               \
     } while (0)
     {
         int t0 = 0;
@@ -859,7 +855,7 @@ _Pragma("unroll")                                                               
         while (!done) MEDB_BLOCK();
     }
 #undef MEDB_BLOCK
-#undef MEDB_POLL
+#undef MEDB_RECHECK
     // (the prefetch of the block past the end is never taken: its registers must stay reserved until it has landed)
     if constexpr (PAIRS) {
         asm volatile("s_waitcnt vmcnt(0)" ::"v"(ra2a[0]), "v"(ra2a[1]), "v"(ra2a[2]), "v"(ra2a[3]), "v"(ra2a[4]), "v"(ra2a[5]), "v"(ra2a[6]),
@@ -876,7 +872,6 @@ _Pragma("unroll")                                                               
                      "v"(rx[10 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[11 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[12 % (PAIRS ? 1 : MEDB_K)]),
                      "v"(rx[13 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[14 % (PAIRS ? 1 : MEDB_K)]), "v"(rx[15 % (PAIRS ? 1 : MEDB_K)]) : "memory");
     }
-    if (last_row) __hip_atomic_store(&progress[band], nsteps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #undef MEDB_ISSUE
 #undef MEDB_LD1
 #undef MEDB_LD2
@@ -916,10 +911,11 @@ hipError_t adc_launch_median(adc_handle* h)
     static const bool banded = [] { const char* e = getenv("ADC_MEDIAN_BANDED"); return e ? atoi(e) != 0 : true; }();
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
     if (banded && nbands > 1 && nbands <= 256 && p.W >= 2 && p.H >= 2 && h->med_hand) {
-        // progress counters + error word live in vote_counters[160..]; zeroed on the stream before every launch
+        // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
+        // the hand-off rows are reset to the "not written yet" sentinel (all ones) before every launch
         int* prog = h->vote_counters + 160;
-        // layout: prog[0..255] band progress, prog[260] error word, prog[262..267] store sinks of idle lanes
-        hipMemsetAsync(prog, 0, 272 * sizeof(int32_t), h->stream);
+        hipMemsetAsync(prog + 256, 0, 16 * sizeof(int32_t), h->stream);
+        hipMemsetAsync(h->med_hand, 0xFF, (size_t)(nbands + 1) * h->med_hpitch * sizeof(float), h->stream);
         // pairs of columns per instruction when the width is even (ADC_MEDIAN_PAIRS=0: always one column per instruction)
         static const bool pairs_env = [] { const char* e = getenv("ADC_MEDIAN_PAIRS"); return e ? atoi(e) != 0 : true; }();
         if (pairs_env && (p.W & 1) == 0)
