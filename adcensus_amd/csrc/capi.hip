@@ -132,7 +132,9 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin
     HIP_OK(hipMalloc(&h->disp_vote, P * 4));
     HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
-    h->irv_budget = 96;
+    // voting chain budget of the FIRST Match of a handle (later ones adapt: kernels used + 12 % + 4): a natural 1080p image needs
+    // ~350 kernels; kernels past the end of the chain are no-ops of ~2.5 us, an exhausted budget costs a synchronous continuation
+    h->irv_budget = 384;
     // change-tile map of the voting rounds: one BYTE per 8x8 tile, rows padded to a multiple of 4 (+16: a 16-byte load
     // may start at the last dword of a row)
     h->chg_pitch = (((p.W + 7) / 8 + 3) & ~3) + 16;

@@ -611,10 +611,10 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
 // filter -- hence the map itself is written with plain stores (made visible by the end of the kernel) and only the
 // band's LAST ROW is additionally written, 16 levels at a time, to a small hand-off buffer indexed by LEVEL
 // (hand[band][t] = result of the last row at level t) with four 16-byte sc1 stores per block.  The downstream band
-// reads hand[band-1][t-1] with sc1 loads one block ahead.  To keep the cross-XCD hand-off off the per-level
-// critical path band b runs >= 2*MEDB_K levels behind band b-1: "levels completed" is published once per block
-// and polled once per block.  Dependencies only point upstream, all bands are co-resident (<= 256 single-wave
-// workgroups), spins are bounded (error word + bail out, reported by adc_wait).
+// reads hand[band-1][t-1] with sc1 loads one block ahead; the rows are reset to a sentinel before the launch and a band
+// re-reads a block in which it still finds the sentinel (MEDB_RECHECK): the data is its own flag.  Dependencies only
+// point upstream, all bands are co-resident (<= 256 single-wave workgroups), the re-reads are bounded (error word +
+// bail out, reported by adc_wait, which then runs the single-workgroup kernel).
 #define MEDB_ROWS 64
 #define MEDB_K 16 // levels per block (the asm take-over statements are written for 16)
 #define MEDB_HPAD 4 // hand[band][MEDB_HPAD + t]
