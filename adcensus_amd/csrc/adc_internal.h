@@ -96,7 +96,9 @@ struct adc_handle {
     int st16_pitch;      // row pitch of st16 in elements (multiple of 8: rows start 16-byte aligned)
     float* disp_vote;    // the map the voting chain works on (copy of the LR-checked map, copied back when the chain ends)
     int irv_grid;        // workgroups of the voting chain (adc_irv_grid, fixed per handle: the work-list layout depends on it)
-    int irv_budget;      // kernels the next Match enqueues for the voting chain (adapted from the last Match)
+    int irv_budget;      // kernels the next Match enqueues for the voting chain (adapted from the last Matches)
+    int irv_used_hist[8]; // kernels the last 8 Matches needed
+    unsigned irv_used_pos;
     int irv_chain;       // kernels of the chain enqueued so far (continuation starts here)
     int irv_pending;     // a chain was enqueued and its final state has not been looked at yet
     int irv_overflows;   // how often adc_wait had to continue the chain (budget too small)

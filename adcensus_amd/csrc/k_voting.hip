@@ -28,7 +28,7 @@
 //            compaction kernel and a vote kernel per round; a round of the long tail is a chain of dependent memory round
 //            trips, and the second kernel boundary + plan + list round trip were 40 % of it.)
 //     FINAL  write the last pass's fills back
-// The chain length is a BUDGET (adc_handle::irv_budget, adapted from the kernels the previous Match of the handle needed);
+// The chain length is a BUDGET (adc_handle::irv_budget, adapted from the kernels the last Matches of the handle needed);
 // when it is exhausted before the state machine reaches DONE, adc_wait continues the same chain synchronously and redoes
 // the stages behind it -- a performance cliff, never a different result.
 #include "adc_internal.h"
@@ -502,6 +502,12 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     // nothing left to do) + 12 % + 4
     const int used = st[7] + 1;
     static const int fixed = [] { const char* ev = getenv("ADC_IRV_BUDGET"); return ev ? atoi(ev) : 0; }();
-    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, used + used / 8 + 4);
+    // (the longest chain of the last 8 Matches of the handle: the pairs of a stream differ -- at the KITTI size 3 of 23 distinct
+    // structured pairs overran a budget taken from their predecessor alone; a surplus kernel is a 2.5 us no-op, an overrun a
+    // synchronous continuation)
+    h->irv_used_hist[h->irv_used_pos++ & 7] = used;
+    int longest = 0;
+    for (int i = 0; i < 8; i++) longest = adc_imax(longest, h->irv_used_hist[i]);
+    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + longest / 8 + 4);
     return hipSuccess;
 }

@@ -83,6 +83,10 @@ def parse():
                     help="fixed batch of B distinct pairs farmed over all GPUs through the pull queue (strong scaling, "
                          "BASELINE.json configs[4]: --batch 64); 0 = steps x ranks pairs, static partition (weak scaling)")
     ap.add_argument("--queue", default="", choices=["", "static", "pull"], help="how the batch is handed out (default: pull with --batch, else static)")
+    ap.add_argument("--spinup-ms", type=float, default=float(os.environ.get("ADC_BENCH_SPINUP_MS", "400")),
+                    help="untimed device spin-up before the warm-up steps of the headline region: matches are run until this many ms have "
+                         "passed, so that the timed region starts at the clocks of a busy GPU (the first 20 ms of work after idle ran "
+                         "5 %% slower than the same work a second later)")
     ap.add_argument("--no-host-leg", action="store_true", help="N > 1: skip the second timed region fed from host buffers (adc_farm_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the structured / host-inclusive / throughput legs")
@@ -260,7 +264,7 @@ def stage_roofline(stage, ms_per_step, W, H, D):
 
 
 def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair_ids, dist=None, tensor_device="cpu",
-                     queue_factory=None, host_pairs=None):
+                     queue_factory=None, host_pairs=None, spinup_ms=0.0):
     """Uploads the pairs, runs warm-up + the timed farm region; returns (matcher, elapsed, total, stage_ms, roofline-prof).
     queue_factory: None = static list `pair_ids` repeated to `steps`; else a callable returning a farm.PullQueue for the
     timed region (the batch = range(queue.n): every pair must be in `pair_ids`)."""
@@ -298,6 +302,11 @@ def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair
     def run_timed(n):
         run.timed = True
         run(n)
+    if spinup_ms > 0:  # clock ramp (untimed): the same matches, until the time is up
+        t_end = time.perf_counter() + spinup_ms * 1e-3
+        while time.perf_counter() < t_end:
+            run(max(1, inflight))
+        del prof[:], stages[:]
     if warmup > 0:
         run(warmup)
     sync = m.lib.adc_device_synchronize if host_pairs is None else A.lib().adc_device_synchronize
@@ -403,7 +412,7 @@ def main():
         mine = farm.partition(batch, world, rank)
         queue_factory = None
     m, elapsed, total, stages, prof = measure_workload(A, local_rank, W, H, D, a.workload, steps if mode == "static" else batch, a.warmup, F, mine,
-                                                       dist=dist, tensor_device=tensor_device, queue_factory=queue_factory)
+                                                       dist=dist, tensor_device=tensor_device, queue_factory=queue_factory, spinup_ms=a.spinup_ms)
     computed = list(m.mine) if mode == "pull" else mine
     # ---- verification (untimed): digests of this rank's outputs, recomputation on another GPU
     primary = {pid: farm.digest(m.output(pid).tobytes()) for pid in computed}
@@ -460,6 +469,7 @@ def main():
                                 else "%d distinct pairs (seeds 12345+i), %d per GPU" % (batch, a.steps),
                        "queue": "pull (shared counter on the rendezvous store, re-queue on failure)" if mode == "pull" else "static round-robin partition",
                        "in_flight_per_gpu": F, "parallelism": "replicas x%d (independent pairs)" % world,
+                       "spinup_ms": a.spinup_ms,
                        "comm_backend": (backend if dist is not None else None), "comm": comm},
             "farm_check": check,
             "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
