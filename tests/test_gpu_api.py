@@ -104,8 +104,8 @@ def test_async_pipeline_assumptions_and_budgets(hip, oracle):
     """Match never waits for the device in mid-pipeline: the aggregation ASSUMES the arm maxima of the previous Match of the
     handle and the voting chain has a launch BUDGET adapted from the previous Match.  Both are verified / completed by
     adc_wait -- wrong assumptions cost time, never correctness.  Sequence on ONE handle: structured pair (long arms, many
-    voting rounds), noise pair (short arms, no rounds), structured again (assumed short arms: wrong -> redo; budget too
-    small -> continuation), every result bit-exact."""
+    voting rounds), noise pair (short arms, no rounds), structured again (assumed short arms: wrong -> redo; the budget still
+    covers it), eight noise pairs, structured again (budget too small -> continuation), every result bit-exact."""
     A = hip
     from oracle import pyoracle
     from adcensus_amd import workloads
@@ -126,13 +126,19 @@ def test_async_pipeline_assumptions_and_budgets(hip, oracle):
     assert st.debug_counter(2) == redo0 and st.debug_counter(1) == over0
     assert same(st.match(*n_pair), want_n)           # short arms after long arms: the full ring stays valid, no redo
     assert st.debug_counter(2) == redo0
-    small_budget = st.debug_counter(3)
+    kept_budget = st.debug_counter(3)
     assert same(st.match(*n_pair), want_n)           # now the small ring is assumed (and right)
     assert st.debug_counter(2) == redo0
     assert same(st.match(*s_pair), want_s)           # long arms while the small ring is assumed: detected on the device, redone
     assert st.debug_counter(2) == redo0 + 1
-    assert st.debug_counter(1) >= over0 + 1          # and the noise-sized voting budget was too small: continued
-    assert st.debug_counter(3) > small_budget
+    # the voting budget remembers the longest chain of the last 8 Matches: the structured pair after two noise pairs does NOT
+    # overrun it (it did while the budget followed the previous Match alone)
+    assert st.debug_counter(1) == over0 and st.debug_counter(3) == kept_budget
+    for _ in range(8):                               # eight short chains later the budget has shrunk to the noise pair's ...
+        assert same(st.match(*n_pair), want_n)
+    assert st.debug_counter(3) < kept_budget
+    assert same(st.match(*s_pair), want_s)           # ... the structured pair overruns it: continued by adc_wait, same result
+    assert st.debug_counter(1) >= over0 + 1 and st.debug_counter(3) >= kept_budget
     assert same(st.match(*s_pair), want_s)
     st.Release()
 
