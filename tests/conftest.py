@@ -67,3 +67,28 @@ def hip():
     if adcensus_amd.device_count() < 1:
         pytest.fail("no HIP device visible: GPU tests must run on a MI355X box")
     return adcensus_amd
+
+
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="session")
+def device_asm(tmp_path_factory):
+    """device_asm("k_scanline") -> path of the gfx950 assembly of adcensus_amd/csrc/k_scanline.hip, compiled once per session
+    with the product flags (csrc/Makefile) -- what the generated-code checks (register budgets, asynchronous loads) read."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out_dir = tmp_path_factory.mktemp("device_asm")
+    cache = {}
+
+    def get(stem):
+        if stem not in cache:
+            src = os.path.join(ROOT, "adcensus_amd", "csrc", stem + ".hip")
+            out = str(out_dir / (stem + ".s"))
+            cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                   "-Wno-inline-asm", "-Wno-unused-value", "-S", "--cuda-device-only", src, "-o", out]
+            subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+            cache[stem] = out
+        return cache[stem]
+
+    return get

@@ -5,8 +5,6 @@ operations per step the hand-counted s_waitcnt vmcnt values assume: this test co
 the product flags and checks every instruction outside the asm blocks, the kernel descriptors and the steady-state loop."""
 import os
 import re
-import shutil
-import subprocess
 
 import pytest
 
@@ -16,13 +14,8 @@ RING_V0 = 56
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_compiler_stays_below_the_ring_registers(tmp_path):
-    src = os.path.join(ROOT, "adcensus_amd", "csrc", "k_aggregate.hip")
-    out = str(tmp_path / "k_aggregate.s")
-    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-           "-Wno-inline-asm", "-S", "--cuda-device-only", src, "-o", out]
-    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
-    text = open(out).read()
+def test_compiler_stays_below_the_ring_registers(device_asm):
+    text = open(device_asm("k_aggregate")).read()
     names = re.findall(r"^(_Z\d+k_agg_regring\w*):", text, re.M)
     assert len(names) >= 7, names  # 4 plain passes + the fused-cost pass + 2 pass pairs
     for name in names:
@@ -81,4 +74,3 @@ def test_compiler_stays_below_the_ring_registers(tmp_path):
             # the steady-state wait vmcnt(14) assumes EXACTLY one compiler-issued vector-memory operation (the output store)
             # per step next to the asm-issued prefetch load; (9 such waits: the last step of the peeled block + the 8 of the loop body; the last interval runs into the drain code)
             assert len(steady) >= 8 and all(c == 1 for c in steady[:7]), "%s: vector-memory operations per steady-state step: %s" % (name, steady[:20])
-    shutil.rmtree(str(tmp_path), ignore_errors=True)
