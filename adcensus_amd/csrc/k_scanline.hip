@@ -246,12 +246,27 @@ __device__ __forceinline__ void so_rmap_load_words(const uint8_t* __restrict__ r
 #ifndef SO_INTERIOR
 #define SO_INTERIOR 1 // A/B switch: 0 = always the general class rule
 #endif
+#ifndef SO_FAST
+#define SO_FAST 1 // A/B switch: 0 = never the short form of a whole interior chunk
+#endif
+// Prefetch slots of the VPL <= 2 kernels: REGISTERS THE COMPILER CANNOT ALLOCATE (it is limited to v0 .. v[SO_V0-1] by
+// amdgpu_num_vgpr, like the ring of k_aggregate_rr2.h), named directly in the asm statements:
+//   data slot U   v[SO_V0 + 2U : SO_V0 + 2U + 1]   (VPL = 1 uses the low register)
+//   rmap slot U   v[SO_V0 + 32 + U]
+//   d1 word G     v[SO_V0 + 48 + G]
+// A load is in flight for 16 steps; in compiler-allocated registers nothing stops the register allocator from copying a slot
+// while its load has not landed (it did, as soon as the steady state had two forms: tools/check_async_loads.py).
+#define SO_V0 96
+#define SO_RC(U) (SO_V0 + 2 * (U))
+#define SO_RR(U) (SO_V0 + 32 + (U))
+#define SO_RW(G) (SO_V0 + 48 + (G))
+#define SO_CLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147"
 template <int VPL, bool VERT, bool DPP, bool WTA>
-__global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src, float* __restrict__ dst,
-                                                  const uint32_t* __restrict__ c1w, int ngr,
-                                                  const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso,
-                                                  int dir, float P1a, float P1b, float P1c, float P2a, float P2b, float P2c,
-                                                  float* __restrict__ disp)
+__device__ __forceinline__ void so_body(const float* __restrict__ src, float* __restrict__ dst,
+                                        const uint32_t* __restrict__ c1w, int ngr,
+                                        const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso,
+                                        int dir, float P1a, float P1b, float P1c, float P2a, float P2b, float P2c,
+                                        float* __restrict__ disp, int allow_fast)
 {
     static_assert(!WTA || DPP, "the fused winner-takes-all relies on the uniform (SGPR) path minimum of the DPP reduction");
     constexpr int Dp = 64 * VPL;
@@ -392,6 +407,43 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         vstore<VPL>(dpn, OUT);        \
         dpn += fstep;                 \
     } while (0)
+// The same step for a chunk of the path that is interior as a whole (see the steady-state loop below): interior class
+// rule without its per-step test, no padding lanes (D == 64 * VPL), the four-way minimum as v_min3 + v_min without the
+// canonicalising copies the compiler puts in front of fminf (costs are finite, never NaN: exact selections either way),
+// and the lane-edge sentinels of the d-1 / d+1 neighbours simply stay where they are (a DPP move leaves lanes without a
+// source untouched: lane 0 of upN / lane 63 of dnN have held Large_Float since the first element).
+#define SO_STEP_F(I, E)                                                                                    \
+    do {                                                                                                   \
+        int off_[VPL];                                                                                     \
+        adc_so_class_offsets_interior<VPL>((E).rb, (E).c1, tso, off_);                                     \
+        float out_[VPL];                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                    \
+        {                                                                                                  \
+            const float2 pp_ = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(so_tab) + off_[k]); \
+            const float lm1_ = k == 0 ? upN : Lp[k == 0 ? 0 : k - 1];                                      \
+            const float lp1_ = k == VPL - 1 ? dnN : Lp[k == VPL - 1 ? k : k + 1];                          \
+            const float l2_ = lm1_ + pp_.x;                                                                \
+            const float l3_ = lp1_ + pp_.x;                                                                \
+            const float l4_ = minLp + pp_.y;                                                               \
+            float t_, mm_;                                                                                 \
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t_) : "v"(Lp[k]), "v"(l2_), "v"(l3_));                  \
+            asm("v_min_f32 %0, %1, %2" : "=v"(mm_) : "v"(t_), "v"(l4_));                                   \
+            out_[k] = ((E).c[k] + mm_) * 0.5f;                                                             \
+        }                                                                                                  \
+        SO_STORE(I, out_);                                                                                 \
+        float omin_ = out_[0];                                                                             \
+        _Pragma("unroll") for (int k = 0; k < VPL; k++) Lp[k] = out_[k];                                   \
+        if constexpr (VPL == 2) asm("v_min_f32 %0, %1, %2" : "=v"(omin_) : "v"(out_[0]), "v"(out_[1]));    \
+        minLp = wave_min_f32<DPP>(omin_);                                                                  \
+        if constexpr (DPP) {                                                                               \
+            upN = dpp_mov<0x138>(upN, Lp[VPL - 1]);                                                        \
+            dnN = dpp_mov<0x130>(dnN, Lp[0]);                                                              \
+        } else {                                                                                           \
+            upN = lane_up<DPP>(Lp[VPL - 1], ADC_LARGE_FLOAT, lane);                                        \
+            dnN = lane_down<DPP>(Lp[0], ADC_LARGE_FLOAT, lane);                                            \
+        }                                                                                                  \
+        SO_WTA(I);                                                                                         \
+    } while (0)
 
     if constexpr (VPL <= 2) {
         // Prefetch ring with asm-issued loads and hand-counted vmcnt (same technique and the same reasons as
@@ -407,9 +459,7 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         // Loads past the end of the path are clamped to its last element / group (harmless duplicates).
         typedef typename VecT<VPL>::type vec_t;
         constexpr int PF = 16, NG = PF / 4;
-        vec_t pfc[PF];
-        uint32_t pfr[PF];
-        uint32_t pfw[NG];
+        asm volatile("" ::: SO_CLOBBERS); // the kernel's register count includes the slots (see SO_V0)
         const long long pstep = (long long)(VERT ? W : 1) * dir; // pixels per path step
         const long long fstep = pstep * Dp;
         const size_t px1 = so_pixel<VERT>(g, 1);
@@ -423,11 +473,11 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     do {                                                                                                       \
         const int ro_ = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last);                                          \
         if constexpr (VPL == 1) {                                                                              \
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory");                \
-            asm volatile("global_load_ubyte %0, %1, %2" : "=v"(pfr[U]) : "v"(ro_), "s"(rmap) : "memory");      \
+            asm volatile("global_load_dword v[%1], %0, off" ::"v"(spn), "n"(SO_RC(U)) : "memory");               \
+            asm volatile("global_load_ubyte v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory");     \
         } else {                                                                                               \
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[U]) : "v"(spn) : "memory");              \
-            asm volatile("global_load_ushort %0, %1, %2" : "=v"(pfr[U]) : "v"(ro_), "s"(rmap) : "memory");     \
+            asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
+            asm volatile("global_load_ushort v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory");    \
         }                                                                                                      \
         spn += ii < last ? fstep : 0;                                                                          \
         mpf += ii < last ? dir : 0;                                                                            \
@@ -435,8 +485,27 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
     } while (0)
 #define SO_ISSUE_C(G)                                                                                          \
     do {                                                                                                       \
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pfw[G]) : "v"(cwn) : "memory");                    \
+        asm volatile("global_load_dword v[%1], %0, off" ::"v"(cwn), "n"(SO_RW(G)) : "memory");                   \
         cwn += gi + 1 < ngr ? 1 : 0;                                                                           \
+        gi++;                                                                                                  \
+    } while (0)
+// clamp-free forms for a chunk whose prefetches all stay inside the path (running rmap offset `rof`)
+#define SO_ISSUE_DF(U)                                                                                         \
+    do {                                                                                                       \
+        if constexpr (VPL == 1) {                                                                              \
+            asm volatile("global_load_dword v[%1], %0, off" ::"v"(spn), "n"(SO_RC(U)) : "memory");               \
+            asm volatile("global_load_ubyte v[%2], %0, %1" ::"v"(rof), "s"(rmap), "n"(SO_RR(U)) : "memory");     \
+        } else {                                                                                               \
+            asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
+            asm volatile("global_load_ushort v[%2], %0, %1" ::"v"(rof), "s"(rmap), "n"(SO_RR(U)) : "memory");    \
+        }                                                                                                      \
+        spn += fstep;                                                                                          \
+        rof += rstep;                                                                                          \
+    } while (0)
+#define SO_ISSUE_CF(G)                                                                                         \
+    do {                                                                                                       \
+        asm volatile("global_load_dword v[%1], %0, off" ::"v"(cwn), "n"(SO_RW(G)) : "memory");                   \
+        cwn += 1;                                                                                              \
         gi++;                                                                                                  \
     } while (0)
 // take element U (and, on the first step of a group, the group's d1 word) after waiting for <= WAITN younger ops
@@ -446,20 +515,20 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         uint32_t tr_;                                                                                          \
         if constexpr (((U)&3) == 0) {                                                                          \
             if constexpr (VPL == 1)                                                                            \
-                asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" \
+                asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v[%4]\n\tv_mov_b32 %1, v[%5]\n\tv_mov_b32 %2, v[%6]" \
                              : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
-                             : "v"(pfc[U]), "v"(pfr[U]), "v"(pfw[(U) >> 2]), "n"(WAITN) : "memory");           \
+                             : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RR(U)), "n"(SO_RW((U) >> 2)) : "memory");     \
             else                                                                                               \
-                asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b64 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" \
+                asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b64 %0, v[%4:%5]\n\tv_mov_b32 %1, v[%6]\n\tv_mov_b32 %2, v[%7]" \
                              : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
-                             : "v"(pfc[U]), "v"(pfr[U]), "v"(pfw[(U) >> 2]), "n"(WAITN) : "memory");           \
+                             : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RC(U) + 1), "n"(SO_RR(U)), "n"(SO_RW((U) >> 2)) : "memory"); \
         } else {                                                                                               \
             if constexpr (VPL == 1)                                                                            \
-                asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                     \
-                             : "=&v"(tc_), "=&v"(tr_) : "v"(pfc[U]), "v"(pfr[U]), "n"(WAITN) : "memory");      \
+                asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, v[%3]\n\tv_mov_b32 %1, v[%4]"                 \
+                             : "=&v"(tc_), "=&v"(tr_) : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RR(U)) : "memory");  \
             else                                                                                               \
-                asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b32 %1, %3"                     \
-                             : "=&v"(tc_), "=&v"(tr_) : "v"(pfc[U]), "v"(pfr[U]), "n"(WAITN) : "memory");      \
+                asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b64 %0, v[%3:%4]\n\tv_mov_b32 %1, v[%5]"            \
+                             : "=&v"(tc_), "=&v"(tr_) : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RC(U) + 1), "n"(SO_RR(U)) : "memory"); \
         }                                                                                                      \
         if constexpr (VPL == 1) (E).c[0] = tc_;                                                                \
         else { (E).c[0] = tc_.x; (E).c[VPL - 1] = tc_.y; }                                                     \
@@ -475,6 +544,15 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         if constexpr (((U)&3) == 0) SO_ISSUE_C((U) >> 2);                                                      \
         SO_STEP(i + (U), cur_);                                                                                \
     } while (0)
+#define SO_PIPE_F(U, WAITN)                                                                                    \
+    do {                                                                                                       \
+        SoElem<VPL> cur_;                                                                                      \
+        SO_TAKE(U, WAITN, cur_);                                                                               \
+        SO_ISSUE_DF(U);                                                                                        \
+        if constexpr (((U)&3) == 0) SO_ISSUE_CF((U) >> 2);                                                     \
+        SO_STEP_F(i + (U), cur_);                                                                              \
+    } while (0)
+#define SO_FAST4(G) SO_PIPE_F(4 * (G), 49); SO_PIPE_F(4 * (G) + 1, 50); SO_PIPE_F(4 * (G) + 2, 50); SO_PIPE_F(4 * (G) + 3, 50)
 #define SO_FIRST4(G)                                                                                           \
     SO_PIPE(4 * (G), 33 + 4 * (G)); SO_PIPE(4 * (G) + 1, 35 + 4 * (G)); SO_PIPE(4 * (G) + 2, 36 + 4 * (G));     \
     SO_PIPE(4 * (G) + 3, 37 + 4 * (G))
@@ -501,23 +579,42 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         if (i + PF <= g.plen) {
             SO_FIRST4(0); SO_FIRST4(1); SO_FIRST4(2); SO_FIRST4(3);
             i += PF;
+            // Steady state.  A chunk of PF steps takes the short form when it is interior as a whole: no padding lanes,
+            // every element of the chunk AND every element it prefetches (the PF behind it, their d1 groups included)
+            // inside the path and inside the columns where the class rule is the interior one and the rmap gather needs
+            // no clamp (x - (dmin + Dp - 1) >= 1, x - dmin < W - 1).  Same vector-memory operations in the same order as
+            // the general form, so the two can alternate under the same wait counts; at 1080p 109 of the 120 chunks of a
+            // row qualify.  The general form keeps its per-step tests and clamps for the rest.
+            const int rstep = (VERT ? W : 1) * dir;
             for (; i + PF <= g.plen; i += PF) {
-                SO_STEADY4(0); SO_STEADY4(1); SO_STEADY4(2); SO_STEADY4(3);
+                bool fast = SO_INTERIOR && SO_FAST && allow_fast && D == Dp && W >= 3 && i + 2 * PF + 4 <= g.plen;
+                if (fast) {
+                    const int ea = i, eb = i + 2 * PF - 1; // path elements the chunk steps on or prefetches
+                    const int ma = dir > 0 ? ea : g.plen - 1 - ea, mb = dir > 0 ? eb : g.plen - 1 - eb;
+                    const int xlo = VERT ? g.path : (ma < mb ? ma : mb), xhi = VERT ? g.path : (ma < mb ? mb : ma);
+                    fast = xlo >= dmin + Dp && xhi - dmin < W - 1;
+                }
+                if (fast) {
+                    int rof = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last); // exact: no clamp is active in this chunk
+                    SO_FAST4(0); SO_FAST4(1); SO_FAST4(2); SO_FAST4(3);
+                    mcur += PF * dir;
+                    mpf += PF * dir;
+                    ii += PF;
+                } else {
+                    SO_STEADY4(0); SO_STEADY4(1); SO_STEADY4(2); SO_STEADY4(3);
+                }
             }
         }
         // final chunk: fewer than PF elements left, all of them in flight
         SO_LAST4(0) SO_LAST4(1) SO_LAST4(2) SO_LAST4(3)
-        // Slots past the end of the path were loaded (clamped) but never taken: keep their destination registers alive
-        // until those loads have landed, or the compiler may reuse them for the values of the steps above and a
-        // late-landing load overwrites them.
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(pfc[0]), "v"(pfc[1]), "v"(pfc[2]), "v"(pfc[3]), "v"(pfc[4]), "v"(pfc[5]),
-                     "v"(pfc[6]), "v"(pfc[7]), "v"(pfc[8]), "v"(pfc[9]), "v"(pfc[10]), "v"(pfc[11]), "v"(pfc[12]),
-                     "v"(pfc[13]), "v"(pfc[14]), "v"(pfc[15]) : "memory");
-        asm volatile("" ::"v"(pfr[0]), "v"(pfr[1]), "v"(pfr[2]), "v"(pfr[3]), "v"(pfr[4]), "v"(pfr[5]), "v"(pfr[6]),
-                     "v"(pfr[7]), "v"(pfr[8]), "v"(pfr[9]), "v"(pfr[10]), "v"(pfr[11]), "v"(pfr[12]), "v"(pfr[13]),
-                     "v"(pfr[14]), "v"(pfr[15]), "v"(pfw[0]), "v"(pfw[1]), "v"(pfw[2]), "v"(pfw[3]) : "memory");
+        // (slots past the end of the path were loaded, clamped, but never taken: harmless, their registers are reserved)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef SO_ISSUE_D
 #undef SO_ISSUE_C
+#undef SO_ISSUE_DF
+#undef SO_ISSUE_CF
+#undef SO_PIPE_F
+#undef SO_FAST4
 #undef SO_TAKE
 #undef SO_PIPE
 #undef SO_FIRST4
@@ -556,8 +653,30 @@ __global__ __launch_bounds__(256) void k_scanline(const float* __restrict__ src,
         }
     }
 #undef SO_STEP
+#undef SO_STEP_F
 #undef SO_STORE
 #undef SO_WTA
+}
+
+// VPL <= 2 (disparity ranges up to 128): asm prefetch into the reserved slot registers -- the compiler keeps to v0 .. v95
+template <int VPL, bool VERT, bool DPP, bool WTA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SO_V0))) void k_scanline(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
+    const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
+    float P2a, float P2b, float P2c, float* __restrict__ disp, int allow_fast)
+{
+    static_assert(VPL <= 2, "wider lanes use k_scanline_wide");
+    so_body<VPL, VERT, DPP, WTA>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, allow_fast);
+}
+// VPL >= 4: compiler-scheduled prefetch, no reserved registers
+template <int VPL, bool VERT, bool DPP, bool WTA>
+__global__ __launch_bounds__(256) void k_scanline_wide(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
+    const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
+    float P2a, float P2b, float P2c, float* __restrict__ disp, int allow_fast)
+{
+    static_assert(VPL >= 4, "VPL <= 2 uses k_scanline");
+    so_body<VPL, VERT, DPP, WTA>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, allow_fast);
 }
 
 static bool so_use_dpp()
@@ -584,10 +703,23 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
     const uint32_t* c1w = reinterpret_cast<const uint32_t*>(h->so_cls) + L.off[pass];
     const uint8_t* rmap = vert ? h->cdiff_rv : h->cdiff_rh;
 #define SO_LAUNCH(VERT_, DPP_, WTA_)                                                                                   \
-    hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, \
-                       L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1],         \
-                       h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2], disp)
+    do {                                                                                                               \
+        if constexpr (VPL <= 2)                                                                                        \
+            hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, \
+                               L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], \
+                               h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2], disp, so_fast);                             \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_scanline_wide<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, \
+                               L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], \
+                               h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2], disp, so_fast);                             \
+    } while (0)
     const bool dpp = so_use_dpp();
+    // Short form of whole interior chunks (SO_STEP_F): pays where a pass is a set of lone-wave chains, i.e. fewer paths than
+    // the 1024 SIMDs of the chip (KITTI-size row passes: 375 paths, scanline stage 0.873 -> 0.675 ms, same-box A/B); where
+    // every SIMD has a wave or two the pass is bound by its memory streams and the short form changes nothing (1080p:
+    // 1.97 vs 2.00 ms with it), so those passes keep the general form.  ADC_SO_FAST=0 / 1 forces it off / on everywhere.
+    static const int so_fast_env = [] { const char* e = getenv("ADC_SO_FAST"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    const int so_fast = so_fast_env >= 0 ? so_fast_env : (npaths < 1024 ? 1 : 0);
     if (vert) {
         if (dpp && disp) SO_LAUNCH(true, true, true);
         else if (dpp) SO_LAUNCH(true, true, false);

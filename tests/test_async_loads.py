@@ -44,7 +44,30 @@ def _check(path, want):
 def test_scanline_prefetch_slots(device_asm):
     res, seen = _check(device_asm("k_scanline"), ["k_scanlineILi1E", "k_scanlineILi2E"])
     assert seen["k_scanlineILi1E"] == 5 and seen["k_scanlineILi2E"] == 5, seen  # every asm-prefetch instantiation was analysed
-    assert all(r["asm_loads"] >= 100 for r in res.values())  # prologue + first block + steady state, 16 slots + d1 words
+    assert all(r["asm_loads"] >= 100 for r in res.values())  # prologue + first block + both steady-state forms, 16 slots + d1 words
+    # the slots are registers the compiler cannot allocate (amdgpu_num_vgpr(96) + named registers v96..v147): every
+    # instruction outside the asm statements stays below v96, nothing is spilled, and the descriptor reserves 148 registers
+    text = open(device_asm("k_scanline")).read()
+    for name, body in cal.functions(text):
+        if not re.search(r"k_scanlineILi[12]E", name):
+            continue
+        in_asm, worst = False, -1
+        for line in body:
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if in_asm or not t or t[0] in ";.":
+                continue
+            code = t.split(";")[0]
+            assert "scratch_" not in code, "%s: spill: %s" % (name, code)
+            worst = max([worst] + list(cal.regs(code)))
+        assert 0 <= worst < 96, "%s: the compiler uses v%d (slots start at v96)" % (name, worst)
+        m = re.search(r"\.amdhsa_kernel " + re.escape(name) + r"\n(.*?)\.end_amdhsa_kernel", text, re.S)
+        assert m and re.search(r"\.amdhsa_next_free_vgpr 148\b", m.group(1)), name
 
 
 def test_median_window_prefetch(device_asm):
@@ -69,7 +92,7 @@ def test_checker_catches_a_weakened_wait_and_a_slot_copy(device_asm, tmp_path):
     res = cal.check_file(weak, "k_scanlineILi2ELb0ELb1ELb0E")
     assert any(r["bad"] for r in res.values()), "a wait two operations too weak must be reported"
     # a compiler-style copy of a slot register right after its load has been issued
-    m = re.search(r"(\tglobal_load_dwordx2 (v\[\d+:\d+\]), v\[\d+:\d+\], off\n\t;;#ASMEND\n)", text)
+    m = re.search(r"(\tglobal_load_dwordx2 (v\[\w+:\w+\]), v\[\d+:\d+\], off\n\t;;#ASMEND\n)", text)
     assert m
     copy = str(tmp_path / "copy.s")
     open(copy, "w").write(text.replace(m.group(1), m.group(1) + "\tv_mov_b64_e32 v[250:251], %s\n" % m.group(2), 1))
