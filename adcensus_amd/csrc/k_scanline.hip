@@ -261,7 +261,7 @@ __device__ __forceinline__ void so_rmap_load_words(const uint8_t* __restrict__ r
 #define SO_RR(U) (SO_V0 + 32 + (U))
 #define SO_RW(G) (SO_V0 + 48 + (G))
 #define SO_CLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147"
-template <int VPL, bool VERT, bool DPP, bool WTA>
+template <int VPL, bool VERT, bool DPP, bool WTA, bool PIN>
 __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __restrict__ dst,
                                         const uint32_t* __restrict__ c1w, int ngr,
                                         const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso,
@@ -459,7 +459,13 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         // Loads past the end of the path are clamped to its last element / group (harmless duplicates).
         typedef typename VecT<VPL>::type vec_t;
         constexpr int PF = 16, NG = PF / 4;
-        asm volatile("" ::: SO_CLOBBERS); // the kernel's register count includes the slots (see SO_V0)
+        // PIN: slots in the reserved registers (see SO_V0; the empty statement makes the kernel's register count include
+        // them).  !PIN: slots in compiler-allocated registers -- sound for the single-form loop of these kernels, which is
+        // what the generated-code check (tools/check_async_loads.py) verifies on every build.
+        if constexpr (PIN) asm volatile("" ::: SO_CLOBBERS);
+        vec_t pfc[PIN ? 1 : PF];
+        uint32_t pfr[PIN ? 1 : PF];
+        uint32_t pfw[PIN ? 1 : NG];
         const long long pstep = (long long)(VERT ? W : 1) * dir; // pixels per path step
         const long long fstep = pstep * Dp;
         const size_t px1 = so_pixel<VERT>(g, 1);
@@ -472,12 +478,22 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
 #define SO_ISSUE_D(U)                                                                                          \
     do {                                                                                                       \
         const int ro_ = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last);                                          \
-        if constexpr (VPL == 1) {                                                                              \
-            asm volatile("global_load_dword v[%1], %0, off" ::"v"(spn), "n"(SO_RC(U)) : "memory");               \
-            asm volatile("global_load_ubyte v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory");     \
+        if constexpr (PIN) {                                                                                   \
+            if constexpr (VPL == 1) {                                                                          \
+                asm volatile("global_load_dword v[%1], %0, off" ::"v"(spn), "n"(SO_RC(U)) : "memory");         \
+                asm volatile("global_load_ubyte v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory"); \
+            } else {                                                                                           \
+                asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
+                asm volatile("global_load_ushort v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory"); \
+            }                                                                                                  \
         } else {                                                                                               \
-            asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
-            asm volatile("global_load_ushort v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory");    \
+            if constexpr (VPL == 1) {                                                                          \
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[PIN ? 0 : (U)]) : "v"(spn) : "memory"); \
+                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(pfr[PIN ? 0 : (U)]) : "v"(ro_), "s"(rmap) : "memory"); \
+            } else {                                                                                           \
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[PIN ? 0 : (U)]) : "v"(spn) : "memory"); \
+                asm volatile("global_load_ushort %0, %1, %2" : "=v"(pfr[PIN ? 0 : (U)]) : "v"(ro_), "s"(rmap) : "memory"); \
+            }                                                                                                  \
         }                                                                                                      \
         spn += ii < last ? fstep : 0;                                                                          \
         mpf += ii < last ? dir : 0;                                                                            \
@@ -485,7 +501,8 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
     } while (0)
 #define SO_ISSUE_C(G)                                                                                          \
     do {                                                                                                       \
-        asm volatile("global_load_dword v[%1], %0, off" ::"v"(cwn), "n"(SO_RW(G)) : "memory");                   \
+        if constexpr (PIN) asm volatile("global_load_dword v[%1], %0, off" ::"v"(cwn), "n"(SO_RW(G)) : "memory"); \
+        else asm volatile("global_load_dword %0, %1, off" : "=v"(pfw[PIN ? 0 : (G)]) : "v"(cwn) : "memory");    \
         cwn += gi + 1 < ngr ? 1 : 0;                                                                           \
         gi++;                                                                                                  \
     } while (0)
@@ -513,22 +530,42 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
     do {                                                                                                       \
         vec_t tc_;                                                                                             \
         uint32_t tr_;                                                                                          \
-        if constexpr (((U)&3) == 0) {                                                                          \
-            if constexpr (VPL == 1)                                                                            \
-                asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v[%4]\n\tv_mov_b32 %1, v[%5]\n\tv_mov_b32 %2, v[%6]" \
-                             : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
-                             : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RR(U)), "n"(SO_RW((U) >> 2)) : "memory");     \
-            else                                                                                               \
-                asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b64 %0, v[%4:%5]\n\tv_mov_b32 %1, v[%6]\n\tv_mov_b32 %2, v[%7]" \
-                             : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
-                             : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RC(U) + 1), "n"(SO_RR(U)), "n"(SO_RW((U) >> 2)) : "memory"); \
+        if constexpr (PIN) {                                                                                   \
+            if constexpr (((U)&3) == 0) {                                                                          \
+                if constexpr (VPL == 1)                                                                            \
+                    asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b32 %0, v[%4]\n\tv_mov_b32 %1, v[%5]\n\tv_mov_b32 %2, v[%6]" \
+                                 : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
+                                 : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RR(U)), "n"(SO_RW((U) >> 2)) : "memory");     \
+                else                                                                                               \
+                    asm volatile("s_waitcnt vmcnt(%3)\n\tv_mov_b64 %0, v[%4:%5]\n\tv_mov_b32 %1, v[%6]\n\tv_mov_b32 %2, v[%7]" \
+                                 : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
+                                 : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RC(U) + 1), "n"(SO_RR(U)), "n"(SO_RW((U) >> 2)) : "memory"); \
+            } else {                                                                                               \
+                if constexpr (VPL == 1)                                                                            \
+                    asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, v[%3]\n\tv_mov_b32 %1, v[%4]"                 \
+                                 : "=&v"(tc_), "=&v"(tr_) : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RR(U)) : "memory");  \
+                else                                                                                               \
+                    asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b64 %0, v[%3:%4]\n\tv_mov_b32 %1, v[%5]"            \
+                                 : "=&v"(tc_), "=&v"(tr_) : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RC(U) + 1), "n"(SO_RR(U)) : "memory"); \
+            }                                                                                                      \
         } else {                                                                                               \
-            if constexpr (VPL == 1)                                                                            \
-                asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, v[%3]\n\tv_mov_b32 %1, v[%4]"                 \
-                             : "=&v"(tc_), "=&v"(tr_) : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RR(U)) : "memory");  \
-            else                                                                                               \
-                asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b64 %0, v[%3:%4]\n\tv_mov_b32 %1, v[%5]"            \
-                             : "=&v"(tc_), "=&v"(tr_) : "n"(WAITN), "n"(SO_RC(U)), "n"(SO_RC(U) + 1), "n"(SO_RR(U)) : "memory"); \
+            if constexpr (((U)&3) == 0) {                                                                          \
+                if constexpr (VPL == 1)                                                                            \
+                    asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" \
+                                 : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
+                                 : "v"(pfc[PIN ? 0 : (U)]), "v"(pfr[PIN ? 0 : (U)]), "v"(pfw[PIN ? 0 : ((U) >> 2)]), "n"(WAITN) : "memory"); \
+                else                                                                                               \
+                    asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b64 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" \
+                                 : "=&v"(tc_), "=&v"(tr_), "=&v"(cw)                                               \
+                                 : "v"(pfc[PIN ? 0 : (U)]), "v"(pfr[PIN ? 0 : (U)]), "v"(pfw[PIN ? 0 : ((U) >> 2)]), "n"(WAITN) : "memory"); \
+            } else {                                                                                               \
+                if constexpr (VPL == 1)                                                                            \
+                    asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"                     \
+                                 : "=&v"(tc_), "=&v"(tr_) : "v"(pfc[PIN ? 0 : (U)]), "v"(pfr[PIN ? 0 : (U)]), "n"(WAITN) : "memory"); \
+                else                                                                                               \
+                    asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b64 %0, %2\n\tv_mov_b32 %1, %3"                     \
+                                 : "=&v"(tc_), "=&v"(tr_) : "v"(pfc[PIN ? 0 : (U)]), "v"(pfr[PIN ? 0 : (U)]), "n"(WAITN) : "memory"); \
+            }                                                                                                      \
         }                                                                                                      \
         if constexpr (VPL == 1) (E).c[0] = tc_;                                                                \
         else { (E).c[0] = tc_.x; (E).c[VPL - 1] = tc_.y; }                                                     \
@@ -587,19 +624,23 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
             // row qualify.  The general form keeps its per-step tests and clamps for the rest.
             const int rstep = (VERT ? W : 1) * dir;
             for (; i + PF <= g.plen; i += PF) {
-                bool fast = SO_INTERIOR && SO_FAST && allow_fast && D == Dp && W >= 3 && i + 2 * PF + 4 <= g.plen;
-                if (fast) {
-                    const int ea = i, eb = i + 2 * PF - 1; // path elements the chunk steps on or prefetches
-                    const int ma = dir > 0 ? ea : g.plen - 1 - ea, mb = dir > 0 ? eb : g.plen - 1 - eb;
-                    const int xlo = VERT ? g.path : (ma < mb ? ma : mb), xhi = VERT ? g.path : (ma < mb ? mb : ma);
-                    fast = xlo >= dmin + Dp && xhi - dmin < W - 1;
-                }
-                if (fast) {
-                    int rof = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last); // exact: no clamp is active in this chunk
-                    SO_FAST4(0); SO_FAST4(1); SO_FAST4(2); SO_FAST4(3);
-                    mcur += PF * dir;
-                    mpf += PF * dir;
-                    ii += PF;
+                if constexpr (PIN) { // (two forms of the loop body need the pinned slots, see SO_V0)
+                    bool fast = SO_INTERIOR && SO_FAST && allow_fast && D == Dp && W >= 3 && i + 2 * PF + 4 <= g.plen;
+                    if (fast) {
+                        const int ea = i, eb = i + 2 * PF - 1; // path elements the chunk steps on or prefetches
+                        const int ma = dir > 0 ? ea : g.plen - 1 - ea, mb = dir > 0 ? eb : g.plen - 1 - eb;
+                        const int xlo = VERT ? g.path : (ma < mb ? ma : mb), xhi = VERT ? g.path : (ma < mb ? mb : ma);
+                        fast = xlo >= dmin + Dp && xhi - dmin < W - 1;
+                    }
+                    if (fast) {
+                        int rof = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last); // exact: no clamp is active in this chunk
+                        SO_FAST4(0); SO_FAST4(1); SO_FAST4(2); SO_FAST4(3);
+                        mcur += PF * dir;
+                        mpf += PF * dir;
+                        ii += PF;
+                    } else {
+                        SO_STEADY4(0); SO_STEADY4(1); SO_STEADY4(2); SO_STEADY4(3);
+                    }
                 } else {
                     SO_STEADY4(0); SO_STEADY4(1); SO_STEADY4(2); SO_STEADY4(3);
                 }
@@ -607,8 +648,21 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         }
         // final chunk: fewer than PF elements left, all of them in flight
         SO_LAST4(0) SO_LAST4(1) SO_LAST4(2) SO_LAST4(3)
-        // (slots past the end of the path were loaded, clamped, but never taken: harmless, their registers are reserved)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Slots past the end of the path were loaded (clamped) but never taken.  PIN: harmless, their registers are
+        // reserved.  !PIN: keep their destination registers alive until those loads have landed, or the compiler may reuse
+        // them for the values of the steps above and a late-landing load overwrites them.
+        if constexpr (PIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else {
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(pfc[PIN ? 0 : 0]), "v"(pfc[PIN ? 0 : 1]), "v"(pfc[PIN ? 0 : 2]), "v"(pfc[PIN ? 0 : 3]),
+                         "v"(pfc[PIN ? 0 : 4]), "v"(pfc[PIN ? 0 : 5]), "v"(pfc[PIN ? 0 : 6]), "v"(pfc[PIN ? 0 : 7]), "v"(pfc[PIN ? 0 : 8]),
+                         "v"(pfc[PIN ? 0 : 9]), "v"(pfc[PIN ? 0 : 10]), "v"(pfc[PIN ? 0 : 11]), "v"(pfc[PIN ? 0 : 12]),
+                         "v"(pfc[PIN ? 0 : 13]), "v"(pfc[PIN ? 0 : 14]), "v"(pfc[PIN ? 0 : 15]) : "memory");
+            asm volatile("" ::"v"(pfr[PIN ? 0 : 0]), "v"(pfr[PIN ? 0 : 1]), "v"(pfr[PIN ? 0 : 2]), "v"(pfr[PIN ? 0 : 3]), "v"(pfr[PIN ? 0 : 4]),
+                         "v"(pfr[PIN ? 0 : 5]), "v"(pfr[PIN ? 0 : 6]), "v"(pfr[PIN ? 0 : 7]), "v"(pfr[PIN ? 0 : 8]), "v"(pfr[PIN ? 0 : 9]),
+                         "v"(pfr[PIN ? 0 : 10]), "v"(pfr[PIN ? 0 : 11]), "v"(pfr[PIN ? 0 : 12]), "v"(pfr[PIN ? 0 : 13]),
+                         "v"(pfr[PIN ? 0 : 14]), "v"(pfr[PIN ? 0 : 15]), "v"(pfw[PIN ? 0 : 0]), "v"(pfw[PIN ? 0 : 1]),
+                         "v"(pfw[PIN ? 0 : 2]), "v"(pfw[PIN ? 0 : 3]) : "memory");
+        }
 #undef SO_ISSUE_D
 #undef SO_ISSUE_C
 #undef SO_ISSUE_DF
@@ -658,25 +712,38 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
 #undef SO_WTA
 }
 
-// VPL <= 2 (disparity ranges up to 128): asm prefetch into the reserved slot registers -- the compiler keeps to v0 .. v95
+// VPL <= 2 (disparity ranges up to 128), asm prefetch.  Two kernels: k_scanline keeps the slots in compiler-allocated
+// registers and has ONE form of the steady state (the form every pass with >= 1024 paths runs: such a pass is bound by its
+// memory streams; same-box A/B at 1080p: scanline stage 1.934 ms against 1.963 with the pinned kernel, 1.984 / 2.029 on the
+// structured pair); k_scanline_pin keeps them in the reserved registers and adds the short form of whole interior chunks,
+// for passes that are lone-wave chains (< 1024 paths; KITTI-size row passes 287 -> 194 us).
 template <int VPL, bool VERT, bool DPP, bool WTA>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SO_V0))) void k_scanline(
+__global__ __launch_bounds__(256) void k_scanline(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
+    const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
+    float P2a, float P2b, float P2c, float* __restrict__ disp)
+{
+    static_assert(VPL <= 2, "wider lanes use k_scanline_wide");
+    so_body<VPL, VERT, DPP, WTA, false>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, 0);
+}
+template <int VPL, bool VERT, bool DPP, bool WTA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SO_V0))) void k_scanline_pin(
     const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
     const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
     float P2a, float P2b, float P2c, float* __restrict__ disp, int allow_fast)
 {
     static_assert(VPL <= 2, "wider lanes use k_scanline_wide");
-    so_body<VPL, VERT, DPP, WTA>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, allow_fast);
+    so_body<VPL, VERT, DPP, WTA, true>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, allow_fast);
 }
 // VPL >= 4: compiler-scheduled prefetch, no reserved registers
 template <int VPL, bool VERT, bool DPP, bool WTA>
 __global__ __launch_bounds__(256) void k_scanline_wide(
     const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
     const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
-    float P2a, float P2b, float P2c, float* __restrict__ disp, int allow_fast)
+    float P2a, float P2b, float P2c, float* __restrict__ disp)
 {
-    static_assert(VPL >= 4, "VPL <= 2 uses k_scanline");
-    so_body<VPL, VERT, DPP, WTA>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, allow_fast);
+    static_assert(VPL >= 4, "VPL <= 2 uses k_scanline / k_scanline_pin");
+    so_body<VPL, VERT, DPP, WTA, false>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, 0);
 }
 
 static bool so_use_dpp()
@@ -702,24 +769,25 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
     const SoC1Layout L = so_c1_layout(p.W, p.H);
     const uint32_t* c1w = reinterpret_cast<const uint32_t*>(h->so_cls) + L.off[pass];
     const uint8_t* rmap = vert ? h->cdiff_rv : h->cdiff_rh;
+#define SO_ARGS src, dst, c1w, L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], \
+                h->so_P2[0], h->so_P2[1], h->so_P2[2], disp
 #define SO_LAUNCH(VERT_, DPP_, WTA_)                                                                                   \
     do {                                                                                                               \
-        if constexpr (VPL <= 2)                                                                                        \
-            hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, \
-                               L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], \
-                               h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2], disp, so_fast);                             \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_scanline_wide<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, \
-                               L.ngr[pass], rmap, p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], \
-                               h->so_P1[2], h->so_P2[0], h->so_P2[1], h->so_P2[2], disp, so_fast);                             \
+        if constexpr (VPL <= 2) {                                                                                      \
+            if (so_pin)                                                                                                \
+                hipLaunchKernelGGL((k_scanline_pin<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, SO_ARGS, 1); \
+            else                                                                                                       \
+                hipLaunchKernelGGL((k_scanline<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, SO_ARGS); \
+        } else                                                                                                         \
+            hipLaunchKernelGGL((k_scanline_wide<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, SO_ARGS); \
     } while (0)
     const bool dpp = so_use_dpp();
-    // Short form of whole interior chunks (SO_STEP_F): pays where a pass is a set of lone-wave chains, i.e. fewer paths than
-    // the 1024 SIMDs of the chip (KITTI-size row passes: 375 paths, scanline stage 0.873 -> 0.675 ms, same-box A/B); where
-    // every SIMD has a wave or two the pass is bound by its memory streams and the short form changes nothing (1080p:
-    // 1.97 vs 2.00 ms with it), so those passes keep the general form.  ADC_SO_FAST=0 / 1 forces it off / on everywhere.
+    // Passes that are lone-wave chains (fewer paths than the 1024 SIMDs of the chip) run k_scanline_pin with the short form
+    // of whole interior chunks (KITTI-size row passes: 375 paths, scanline stage 0.873 -> 0.675 ms, same-box A/B); where
+    // every SIMD has a wave or two the pass is bound by its memory streams and runs k_scanline.  ADC_SO_FAST=0 / 1 forces
+    // k_scanline / k_scanline_pin everywhere.
     static const int so_fast_env = [] { const char* e = getenv("ADC_SO_FAST"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-    const int so_fast = so_fast_env >= 0 ? so_fast_env : (npaths < 1024 ? 1 : 0);
+    const bool so_pin = so_fast_env >= 0 ? so_fast_env != 0 : npaths < 1024;
     if (vert) {
         if (dpp && disp) SO_LAUNCH(true, true, true);
         else if (dpp) SO_LAUNCH(true, true, false);
@@ -729,6 +797,7 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
         else SO_LAUNCH(false, false, false);
     }
 #undef SO_LAUNCH
+#undef SO_ARGS
     return hipGetLastError();
 }
 

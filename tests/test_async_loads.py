@@ -42,14 +42,14 @@ def _check(path, want):
 
 
 def test_scanline_prefetch_slots(device_asm):
-    res, seen = _check(device_asm("k_scanline"), ["k_scanlineILi1E", "k_scanlineILi2E"])
-    assert seen["k_scanlineILi1E"] == 5 and seen["k_scanlineILi2E"] == 5, seen  # every asm-prefetch instantiation was analysed
+    res, seen = _check(device_asm("k_scanline"), ["k_scanlineILi1E", "k_scanlineILi2E", "k_scanline_pinILi1E", "k_scanline_pinILi2E"])
+    assert all(v == 5 for v in seen.values()), seen  # every asm-prefetch instantiation of both kernel families was analysed
     assert all(r["asm_loads"] >= 100 for r in res.values())  # prologue + first block + both steady-state forms, 16 slots + d1 words
-    # the slots are registers the compiler cannot allocate (amdgpu_num_vgpr(96) + named registers v96..v147): every
+    # k_scanline_pin: the slots are registers the compiler cannot allocate (amdgpu_num_vgpr(96) + named registers v96..v147): every
     # instruction outside the asm statements stays below v96, nothing is spilled, and the descriptor reserves 148 registers
     text = open(device_asm("k_scanline")).read()
     for name, body in cal.functions(text):
-        if not re.search(r"k_scanlineILi[12]E", name):
+        if not re.search(r"k_scanline_pinILi[12]E", name):
             continue
         in_asm, worst = False, -1
         for line in body:
@@ -89,10 +89,10 @@ def test_checker_catches_a_weakened_wait_and_a_slot_copy(device_asm, tmp_path):
     text = open(device_asm("k_scanline")).read()
     weak = str(tmp_path / "weak.s")
     open(weak, "w").write(text.replace("s_waitcnt vmcnt(50)", "s_waitcnt vmcnt(52)"))
-    res = cal.check_file(weak, "k_scanlineILi2ELb0ELb1ELb0E")
-    assert any(r["bad"] for r in res.values()), "a wait two operations too weak must be reported"
+    res = cal.check_file(weak, "k_scanline(_pin)?ILi2ELb0ELb1ELb0E")
+    assert len(res) == 2 and all(r["bad"] for r in res.values()), "a wait two operations too weak must be reported"
     # a compiler-style copy of a slot register right after its load has been issued
-    m = re.search(r"(\tglobal_load_dwordx2 (v\[\w+:\w+\]), v\[\d+:\d+\], off\n\t;;#ASMEND\n)", text)
+    m = re.search(r"(\tglobal_load_dwordx2 (v\[\d+:\d+\]), v\[\d+:\d+\], off\n\t;;#ASMEND\n)", text)  # a compiler-allocated slot
     assert m
     copy = str(tmp_path / "copy.s")
     open(copy, "w").write(text.replace(m.group(1), m.group(1) + "\tv_mov_b64_e32 v[250:251], %s\n" % m.group(2), 1))

@@ -9,7 +9,7 @@ SRCS=${@:-k_aggregate.hip}
 make -s
 mkdir -p ../build/$NAME ../lib/$NAME
 OBJS=""
-for f in capi k_cost k_arms k_aggregate k_scanline k_wta k_refine k_voting; do
+for f in capi k_cost k_arms k_aggregate k_scanline k_wta k_refine k_voting k_paper; do
   if echo " $SRCS " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-value -Wno-unused-result $FLAGS -c $f.hip -o ../build/$NAME/$f.o
     OBJS="$OBJS ../build/$NAME/$f.o"
