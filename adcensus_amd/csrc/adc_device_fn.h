@@ -121,6 +121,34 @@ ADC_HD void adc_so_class_offsets_interior(const uint32_t* rb, int c1byte, int ts
     }
 }
 
+// ---- scanline prefetch geometry (k_scanline.hip; checked exhaustively on the CPU: tests/test_emul.py) ----
+// Byte offset into the right-image colour-step map of the VPL bytes the path element at coordinate m needs (m = x on a row
+// path, y on a column path; `path` = the row / column; cl_last = dmin + the lane's LAST disparity index, so xr = x - cl_last is
+// the right-image column of that disparity -- the smallest column of the lane).  Clamped to the columns 1 .. W-1 (the class
+// rule never uses the others, see adc_so_class_offsets); R->L row paths read the step to the right neighbour (+1).
+ADC_HD int adc_so_rmap_offset(int W, bool vert, int dir, int path, int m, int cl_last)
+{
+    const int x = vert ? path : m, y = vert ? m : path;
+    const int sy = vert ? (dir > 0 ? y : y + 1) : y;
+    int xr = x - cl_last;
+    xr = xr > W - 1 ? W - 1 : xr;
+    return sy * W + (xr > 1 ? xr : 1) + ((!vert && dir < 0) ? 1 : 0);
+}
+// A chunk of the steady state = path elements i .. i+PF-1, which prefetches elements i+PF .. i+2*PF-1.  It may take the short
+// form (interior class rule without its per-step test, running rmap offset without clamps) when
+//   * every element it steps on or prefetches, and the d1 word groups behind them, lies inside the path (i + 2*PF + 4 <= plen),
+//   * for every such element x >= dmin + Dp (=> x - cl_last >= 1 for every lane: no lower clamp; interior rule, Dp = 64*VPL =
+//     the padded range, which equals the range because the short form also requires D == Dp) and x - dmin < W - 1 (=> interior
+//     rule; xr <= x - dmin < W - 1: no upper clamp).
+ADC_HD bool adc_so_chunk_interior(int i, int PF, int plen, int dir, bool vert, int path, int W, int dmin, int Dp)
+{
+    if (W < 3 || i + 2 * PF + 4 > plen) return false;
+    const int ea = i, eb = i + 2 * PF - 1; // path elements the chunk steps on or prefetches
+    const int ma = dir > 0 ? ea : plen - 1 - ea, mb = dir > 0 ? eb : plen - 1 - eb;
+    const int xlo = vert ? path : (ma < mb ? ma : mb), xhi = vert ? path : (ma < mb ? mb : ma);
+    return xlo >= dmin + Dp && xhi - dmin < W - 1;
+}
+
 // ---- interpolation: empty-space skipping of the ray walk (k_refine.hip; CPU emulation: tests/emul/emul.cpp) ----
 // cdist[cell] = a LOWER BOUND of the Chebyshev distance, in cells of ADC_ITP_CELL x ADC_ITP_CELL pixels, from the cell to
 // the nearest cell that holds a valid pixel (0 = the cell itself; search window +-ADC_ITP_CAP cells, ADC_ITP_CAP + 1 =

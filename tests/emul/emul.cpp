@@ -392,10 +392,17 @@ void emul_scanline_pass(const float* src, float* dst, const uint8_t* cd_left, co
 // disparities, fetches VPL consecutive bytes of the right-image step map at column max(xr_last, 1) (+1 on R->L) and
 // maps them with adc_so_class_offsets (closed form of the sticky-d2 rule).
 } // extern "C"
+// chunked != 0: additionally follows the control flow of the asm-prefetch kernels (k_scanline / k_scanline_pin, VPL <= 2):
+// element e >= 1 is prefetched PF = 16 steps ahead by the chunk that stands on e - PF (prologue / first chunk: clamped form);
+// a steady-state chunk that adc_so_chunk_interior accepts (and D == 64 * VPL) computes the rmap offsets of the elements it
+// prefetches from ONE clamped offset plus a running step, and runs the interior class rule on its own elements without the
+// per-step test.  Returns the number of chunks that took the short form.
 template <int VPL>
-static void scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
-                                int dmin, int D, int vert, int dir, int tso, float p1, float p2)
+static int scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
+                               int dmin, int D, int vert, int dir, int tso, float p1, float p2, int chunked = 0)
 {
+    constexpr int PF = 16;
+    int short_chunks = 0;
     const float P1c[3] = {p1, p1 / 4, p1 / 10}, P2c[3] = {p2, p2 / 4, p2 / 10};
     const int npaths = vert ? W : H, plen = vert ? H : W, Dp = 64 * VPL;
     std::vector<uint8_t> rmap((size_t)W * H + 64, 0); // the kernel's map has slack behind the last element
@@ -422,15 +429,33 @@ static void scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_
             const int sy = vert ? (dir > 0 ? y : y + 1) : y;
             const int d1 = cd_left[(size_t)sy * W + sx];
             const int shift = vert ? 0 : (dir > 0 ? 0 : 1);
+            // chunk of the steady state this element belongs to / was prefetched by (see above)
+            const int Dp_ = 64 * VPL;
+            auto chunk_short = [&](int i0) {
+                return chunked && VPL <= 2 && D == Dp_ && i0 >= 1 + PF && i0 + PF <= plen &&
+                       adc_so_chunk_interior(i0, PF, plen, dir, vert != 0, path, W, dmin, Dp_);
+            };
+            const int i_own = i - ((i - 1) % PF);                               // first element of the chunk that steps on i
+            const int i_pre = i > PF ? (i - PF) - ((i - PF - 1) % PF) : 0;      // ... of the chunk that prefetched i
+            const bool own_short = chunk_short(i_own), pre_short = i_pre >= 1 + PF && chunk_short(i_pre);
+            if (own_short && i == i_own) short_chunks++;
             for (int lane = 0; lane < 64; lane++) {
                 const int cl_last = lane * VPL + VPL - 1 + dmin, xr_last = x - cl_last;
-                const size_t off = (size_t)sy * W + (xr_last > 1 ? xr_last : 1) + shift;
+                size_t off = (size_t)sy * W + (xr_last > 1 ? xr_last : 1) + shift;
+                if (chunked && VPL <= 2) {
+                    const int m = dir > 0 ? i : plen - 1 - i;
+                    if (pre_short) { // running offset: the clamped offset of the chunk's first prefetch + steps
+                        const int e0 = i_pre + PF, m0 = dir > 0 ? e0 : plen - 1 - e0;
+                        off = (size_t)(adc_so_rmap_offset(W, vert != 0, dir, path, m0, cl_last) + (i - e0) * ((vert ? W : 1) * dir));
+                    } else
+                        off = (size_t)adc_so_rmap_offset(W, vert != 0, dir, path, m, cl_last);
+                }
                 uint32_t rb[(VPL + 3) / 4] = {0};
                 for (int j = 0; j < VPL; j++) rb[j >> 2] |= (uint32_t)rmap[off + j] << (8 * (j & 3));
                 int o8[VPL];
                 // the kernel takes the interior form whenever the wave-uniform test allows it
                 const int Dpad = (D + VPL - 1) / VPL * VPL;
-                if (adc_so_interior(x, W, dmin, Dpad)) adc_so_class_offsets_interior<VPL>(rb, d1, tso, o8);
+                if (own_short || adc_so_interior(x, W, dmin, Dpad)) adc_so_class_offsets_interior<VPL>(rb, d1, tso, o8);
                 else adc_so_class_offsets<VPL>(rb, d1, xr_last, W, tso, W >= 3 && x - dmin >= 1, o8);
                 for (int k = 0; k < VPL; k++) cls[lane * VPL + k] = o8[k] / 8;
             }
@@ -449,8 +474,53 @@ static void scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_
             minLp = omin;
         }
     }
+    return short_chunks;
 }
 extern "C" {
+// exhaustive check of what the short form of a chunk relies on (tests/test_emul.py); returns the number of violations
+int emul_so_chunk_predicate_check(void)
+{
+    int bad = 0;
+    const int PF = 16;
+    for (int VPL = 1; VPL <= 2; VPL++)
+        for (int vert = 0; vert <= 1; vert++)
+            for (int dir = -1; dir <= 1; dir += 2)
+                for (int dmin = -70; dmin <= 40; dmin += 11)
+                    for (int W = 1; W <= 260; W += (W < 8 ? 1 : 21))
+                        for (int H = 1; H <= 120; H += (H < 4 ? 1 : 29)) {
+                            const int Dp = 64 * VPL, plen = vert ? H : W, npaths = vert ? W : H;
+                            const int ngr = (plen - 1 + 3) / 4 > 0 ? (plen - 1 + 3) / 4 : 1;
+                            for (int path = 0; path < npaths; path += (npaths > 40 ? 7 : 1))
+                                for (int i = 1 + PF; i + PF <= plen; i += PF) {
+                                    if (!adc_so_chunk_interior(i, PF, plen, dir, vert != 0, path, W, dmin, Dp)) continue;
+                                    for (int e = i; e < i + PF; e++) { // (i) the per-step test agrees
+                                        const int m = dir > 0 ? e : plen - 1 - e, x = vert ? path : m;
+                                        if (!adc_so_interior(x, W, dmin, Dp)) bad++;
+                                    }
+                                    if (i + 2 * PF - 1 > plen - 1) bad++; // prefetches stay inside the path
+                                    if ((i - 1) / 4 + 2 * (PF / 4) - 1 > ngr - 1) bad++; // (iii) groups (i-1)/4 + 4 .. + 7 exist
+                                    const int e0 = i + PF, m0 = dir > 0 ? e0 : plen - 1 - e0, rstep = (vert ? W : 1) * dir;
+                                    for (int lane = 0; lane < 64; lane++) { // (ii) affine offsets, no clamp
+                                        const int cl_last = lane * VPL + VPL - 1 + dmin;
+                                        const int o0 = adc_so_rmap_offset(W, vert != 0, dir, path, m0, cl_last);
+                                        for (int e = e0; e < e0 + PF; e++) {
+                                            const int m = dir > 0 ? e : plen - 1 - e, x = vert ? path : m;
+                                            if (adc_so_rmap_offset(W, vert != 0, dir, path, m, cl_last) != o0 + (e - e0) * rstep) bad++;
+                                            const int xr = x - cl_last;
+                                            if (xr < 1 || xr > W - 1) bad++;
+                                        }
+                                    }
+                                }
+                        }
+    return bad;
+}
+int emul_scanline_pass_chunked(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
+                               int dmin, int D, int vert, int dir, int tso, float p1, float p2)
+{
+    if (D <= 64) return scanline_pass_lanes<1>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2, 1);
+    if (D <= 128) return scanline_pass_lanes<2>(src, dst, cd_left, cd_right, W, H, dmin, D, vert, dir, tso, p1, p2, 1);
+    return -1; // wider lanes have no asm-prefetch form
+}
 void emul_scanline_pass_lanes(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
                               int dmin, int D, int vert, int dir, int tso, float p1, float p2)
 {

@@ -4,11 +4,14 @@ evaluation order, Jacobi interpolation, level-synchronous median) are emulated l
 CPU (tests/emul/emul.cpp, sharing adc_device_fn.h with the device code) and must equal the oracle's
 sequential in-place results bit-for-bit."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def P(a):
@@ -216,6 +219,44 @@ def test_scanline_closed_form(emul, dumps, name):
                                       opt.so_tso, C.c_float(opt.so_p1), C.c_float(opt.so_p2))
         a, b = b, a
     assert same(a, o["cost_so"])
+
+
+@pytest.mark.parametrize("name,want_short", [("s2_320x180_d128", True), ("q_257x131_d64", True), ("cone_neg", True), ("cone_pos", True),
+                                             ("noise_160x90_d128_pos", True), ("s2_150x100_neg", False), ("q_30x7_d8", False)])
+def test_scanline_chunked_forms(emul, dumps, name, want_short):
+    """Control flow of the asm-prefetch scanline kernels: 16-step chunks, the short form of whole interior chunks
+    (adc_so_chunk_interior: interior class rule without its test, rmap offsets of the prefetched elements = one clamped offset
+    + a running step), the clamped general form everywhere else, and the transitions between the two -- against the
+    reference's scanline result.  want_short: the case is wide enough (and D = 64 * VPL) for the short form to occur."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    lh, lv, rh, rv = (np.zeros((h, w), np.uint8) for _ in range(4))
+    emul.emul_color_diffs(P(left), P(lh), P(lv), w, h)
+    emul.emul_color_diffs(P(right), P(rh), P(rv), w, h)
+    a, b = o["cost_aggr"].copy(), np.empty_like(o["cost_aggr"])
+    short = 0
+    for vert, dr in ((0, 1), (0, -1), (1, 1), (1, -1)):
+        n = emul.emul_scanline_pass_chunked(P(a), P(b), P(lv if vert else lh), P(rv if vert else rh), w, h, dmin, D, vert, dr,
+                                            opt.so_tso, C.c_float(opt.so_p1), C.c_float(opt.so_p2))
+        assert n >= 0
+        short += n
+        a, b = b, a
+    assert same(a, o["cost_so"])
+    assert (short > 0) == want_short, short
+
+
+def test_scanline_chunk_predicate_implies_no_clamp_and_interior_rule(emul):
+    """Exhaustive over small geometries: whenever adc_so_chunk_interior accepts a chunk, (i) every element it steps on is
+    interior in the sense of the per-step test, (ii) the clamped rmap offset of every element it prefetches is affine in the
+    element index for every lane (so the running offset of the short form is exact), (iii) the d1 word groups it prefetches
+    exist.  (The kernel's own expressions are the ones restated in adc_device_fn.h: checked textually below.)"""
+    bad = emul.emul_so_chunk_predicate_check()
+    assert bad == 0, bad
+    src = open(os.path.join(ROOT, "adcensus_amd", "csrc", "k_scanline.hip")).read()
+    for expr in ("xlo >= dmin + Dp && xhi - dmin < W - 1", "i + 2 * PF + 4 <= g.plen",
+                 "return sy * g.W + (xr > 1 ? xr : 1) + ((!VERT && g.dir < 0) ? 1 : 0);", "xr = xr > g.W - 1 ? g.W - 1 : xr;"):
+        assert expr in src, "k_scanline.hip no longer contains `%s`: update adc_device_fn.h's restatement with it" % expr
 
 
 @pytest.mark.parametrize("name", LANE_CASES)
