@@ -229,6 +229,8 @@ def k4_roofline(prof, W, H, D, lib, workload, kernel=None, in_flight=1):
     pairs = passes > launches
     if not kernel:
         kernel = "pass-pair launches" if pairs else "one pass per launch"
+    elif pairs:  # the library names the family of the LAST regular launch; say that most launches of this Match fuse two passes
+        kernel = kernel.replace("one pass per launch", "pass-pair launches: %.2f passes per launch" % (passes / float(launches)))
     traffic = pmc_traffic(workload, (W, H, D))
     return {"kernel": kernel, "bound": "hbm", "achieved": round(hbm, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(hbm / 8000.0, 4), "traffic": traffic,
