@@ -235,3 +235,26 @@ def test_pull_queue_four_ranks_gloo_batch_64(fail_rank):
     for r in res:
         assert r[5]["pairs"] == 64 and not r[5]["duplicates"] and not r[5]["mismatches"]
         assert r[5]["cross_checked"] >= 64 - 2 - 16  # everything a healthy rank delivered was recomputed by another healthy rank
+
+
+def test_pull_queue_eight_ranks_gloo_batch_64():
+    """The largest rank count of BASELINE.json configs[4] (a fixed batch of 64 pairs over 1 / 2 / 4 / 8 GPUs) in the CPU tier:
+    8 ranks pull the batch from the job's TCP store; every pair exactly once, one elapsed time, the completion counter equals
+    the batch, the digests of every pair agree with their recomputation on another rank, faster ranks take more pairs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_queue_worker, args=(r, 8, port, q, 64, None)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(sum((r[2] for r in res), [])) == list(range(64))
+    assert len({r[1] for r in res}) == 1
+    assert all(r[4] == 64 for r in res) and not any(r[3] for r in res)
+    assert len(res[0][2]) > len(res[7][2])
+    for r in res:
+        assert r[5]["pairs"] == 64 and not r[5]["duplicates"] and not r[5]["mismatches"] and r[5]["cross_checked"] == 64
