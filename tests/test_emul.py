@@ -410,3 +410,24 @@ def test_voting_packed_halfword_helpers(emul):
     emul.emul_irv_swar_check.restype = C.c_long
     for seed in (1, 2):
         assert emul.emul_irv_swar_check(seed, C.c_long(1000000)) == 0
+
+
+@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_30x7_d8", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "s2_150x100_neg"])
+def test_median_as_asynchronous_blocked_iteration(dumps, name):
+    """The recursive (in-place) 3x3 median is a triangular system: plain Jacobi rounds, and tiles that run T local rounds on a
+    snapshot with a halo of T (top, left, right) and write their cores back in place in ANY order, both end in the reference's
+    in-place result, and a round / kernel that changes nothing proves it (tools/median_rounds.py: the model a tiled median
+    kernel would follow; 1080p noise pair: 55 rounds, 5-8 kernels)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("median_rounds", os.path.join(ROOT, "tools", "median_rounds.py"))
+    mr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mr)
+    left, right, opt, o = dumps(name)
+    inp, ref = mr.fin(o["disp_after_dda"]), mr.fin(o["disp_final"])
+    if min(inp.shape) < 2:
+        pytest.skip("the median-of-nine form of the window rule needs W, H >= 2 (DESIGN 4.4)")
+    cur, rounds = mr.jacobi(inp)
+    assert np.array_equal(cur, ref) and rounds >= 1
+    for S, T, seed in ((16, 4, 1), (8, 8, 2), (32, 2, 3)):
+        cur, kernels = mr.blocked(inp, S, T, np.random.default_rng(seed))
+        assert np.array_equal(cur, ref), (S, T)
