@@ -253,6 +253,27 @@ ADC_HD float adc_median9(float v0, float v1, float v2, float v3, float v4, float
     return adc_med3(adc_max3(lo1, lo2, lo3), adc_med3(me1, me2, me3), adc_min3(hi1, hi2, hi3));
 }
 
+// One pixel of one local round of the tiled chaotic form of the in-place median (used by the experimental kernel of
+// tools/experiments/median_blocked_jacobi.patch and by its CPU emulation, tests/emul/emul.cpp).  A = current iterate of the
+// snapshot (rows y0 .., columns x0 .. x1-1, pitch pa), U = unfiltered map (rows y0 .. y1, columns x0-1 .. x1, pitch pu; positions
+// outside the image hold anything: they are substituted here).  (ly, lx) = position in the snapshot, w = its width.
+// Pixels on a cut edge of the snapshot (not on the image border) keep their value; elsewhere the window takes the iterate at
+// the four raster-earlier neighbours and the unfiltered map at the other five, a missing side-centre neighbour counting as
+// -inf and a missing corner neighbour as +inf (= the reference's wnd[n/2] of the in-image values, see adc_median9).
+ADC_HD float adc_medj_pixel(const float* A, int pa, const float* U, int pu, int ly, int lx, int w, int y0, int x0, int x1, int W, int H)
+{
+    if ((ly == 0 && y0 > 0) || (lx == 0 && x0 > 0) || (lx == w - 1 && x1 < W)) return A[ly * pa + lx];
+    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
+    const int gy = y0 + ly, gx = x0 + lx;
+    const bool up = gy > 0, dn = gy + 1 < H, lf = gx > 0, rt = gx + 1 < W;
+    const float v0 = (up && lf) ? A[(ly - 1) * pa + lx - 1] : PINF, v1 = up ? A[(ly - 1) * pa + lx] : NINF;
+    const float v2 = (up && rt) ? A[(ly - 1) * pa + lx + 1] : PINF, v3 = lf ? A[ly * pa + lx - 1] : NINF;
+    const float v4 = U[ly * pu + lx + 1], v5 = rt ? U[ly * pu + lx + 2] : NINF; // U's column index is lx + 1
+    const float v6 = (dn && lf) ? U[(ly + 1) * pu + lx] : PINF, v7 = dn ? U[(ly + 1) * pu + lx + 1] : NINF;
+    const float v8 = (dn && rt) ? U[(ly + 1) * pu + lx + 2] : PINF;
+    return adc_median9(v0, v1, v2, v3, v5, v6, v7, v8, v4);
+}
+
 // Sorts v[0..8] ascending (25 compare-exchanges, optimal-size network for n=9).
 ADC_HD void adc_sort9(float* v)
 {

@@ -514,6 +514,54 @@ int emul_so_chunk_predicate_check(void)
                         }
     return bad;
 }
+// Tiled chaotic form of the in-place median: one "kernel" = every tile once, in the given order, T local rounds on a snapshot
+// with a halo of T (top, left, right), cores written back in place; src = inp for the first kernel, cur afterwards.  Same loads
+// (clamped reads of the unfiltered map) and the same per-pixel function as the experimental HIP kernel.  Returns the number of
+// core pixels the kernel changed.
+int emul_median_tiles(const float* inp, float* cur, int W, int H, int S, int T, int first, const int* order, int ntiles)
+{
+    const int tw = (W + S - 1) / S;
+    int changed = 0;
+    std::vector<float> A[2], U;
+    for (int t = 0; t < ntiles; t++) {
+        const int tx = (order[t] % tw) * S, ty = (order[t] / tw) * S;
+        const int y0 = ty - T > 0 ? ty - T : 0, x0 = tx - T > 0 ? tx - T : 0;
+        const int y1 = ty + S < H ? ty + S : H, x1 = tx + S + T < W ? tx + S + T : W;
+        const int h = y1 - y0, w = x1 - x0, pa = S + 2 * T + 1, pu = pa + 2;
+        const float* src = first ? inp : cur;
+        A[0].assign((size_t)(S + T) * pa, 0.f);
+        A[1].assign((size_t)(S + T) * pa, 0.f);
+        U.assign((size_t)(S + T + 1) * pu, 0.f);
+        for (int ly = 0; ly < h; ly++)
+            for (int lx = 0; lx < w; lx++) A[0][(size_t)ly * pa + lx] = src[(size_t)(y0 + ly) * W + x0 + lx];
+        for (int ly = 0; ly < h + 1; ly++)
+            for (int lx = 0; lx < w + 2; lx++) {
+                const int gy = y0 + ly < H ? y0 + ly : H - 1, gx0 = x0 - 1 + lx, gx = gx0 < 0 ? 0 : (gx0 < W ? gx0 : W - 1);
+                U[(size_t)ly * pu + lx] = inp[(size_t)gy * W + gx];
+            }
+        int a = 0;
+        for (int r = 0; r < T; r++) {
+            for (int ly = 0; ly < h; ly++)
+                for (int lx = 0; lx < w; lx++)
+                    A[a ^ 1][(size_t)ly * pa + lx] = adc_medj_pixel(A[a].data(), pa, U.data(), pu, ly, lx, w, y0, x0, x1, W, H);
+            a ^= 1;
+        }
+        for (int cy = 0; cy < S; cy++)
+            for (int cx = 0; cx < S; cx++) {
+                const int gy = ty + cy, gx = tx + cx;
+                if (gy < H && gx < W) {
+                    const float v = A[a][(size_t)(gy - y0) * pa + gx - x0];
+                    const size_t q = (size_t)gy * W + gx;
+                    uint32_t b0, b1;
+                    memcpy(&b0, &v, 4);
+                    memcpy(&b1, &src[q], 4);
+                    changed += b0 != b1;
+                    cur[q] = v;
+                }
+            }
+    }
+    return changed;
+}
 int emul_scanline_pass_chunked(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
                                int dmin, int D, int vert, int dir, int tso, float p1, float p2)
 {

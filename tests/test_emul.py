@@ -431,3 +431,26 @@ def test_median_as_asynchronous_blocked_iteration(dumps, name):
     for S, T, seed in ((16, 4, 1), (8, 8, 2), (32, 2, 3)):
         cur, kernels = mr.blocked(inp, S, T, np.random.default_rng(seed))
         assert np.array_equal(cur, ref), (S, T)
+
+
+@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_30x7_d8", "q_9x20_d8", "q_20x40_d32", "s2_150x100_neg", "cone_crop_d40"])
+def test_median_tiles_device_function(emul, dumps, name):
+    """The per-pixel function of the tiled chaotic median (adc_medj_pixel, the one the experimental kernel calls) with the
+    kernel's loads, tile geometry and write-back, tiles in random order: kernels until one changes nothing, result = the
+    reference's in-place median (with its real +inf "invalid" values)."""
+    left, right, opt, o = dumps(name)
+    inp, ref = np.ascontiguousarray(o["disp_after_dda"]), o["disp_final"]
+    h, w = inp.shape
+    for S, T, seed in ((16, 4, 1), (8, 8, 2), (64, 8, 3)):
+        tw, th = (w + S - 1) // S, (h + S - 1) // S
+        cur = np.zeros_like(inp)
+        rng = np.random.default_rng(seed)
+        kernels = 0
+        while True:
+            order = np.ascontiguousarray(rng.permutation(tw * th).astype(np.int32))
+            ch = emul.emul_median_tiles(P(inp), P(cur), w, h, S, T, 1 if kernels == 0 else 0, P(order), tw * th)
+            kernels += 1
+            assert kernels < 200
+            if ch == 0:
+                break
+        assert same(cur, ref), (S, T, kernels)
