@@ -121,6 +121,31 @@ ADC_HD void adc_so_class_offsets_interior(const uint32_t* rb, int c1byte, int ts
     }
 }
 
+// ---- interpolation with rays as the unit of work (experimental: tools/experiments/interp_ray_refill.patch; CPU emulation in
+// tests/emul/emul.cpp).  The 16 first hits of a target are combined by an order-independent minimum of a key:
+//   mismatch list  (colour-nearest hit, FIRST minimum in ray order, multistep_refiner.cpp:276-289):
+//                  key = (L1 colour distance * 16 + ray) << 32 | bits of the hit's disparity     (distance <= 765)
+//   occlusion list (smallest disparity, :290-296): key = the disparity's bits mapped so that unsigned order == float order
+// "no ray hit" = the initial all-ones key (fill value 0, :246,270-272).
+ADC_HD uint32_t adc_f32_bits(float v) { uint32_t b; __builtin_memcpy(&b, &v, 4); return b; }
+ADC_HD float adc_f32_from_bits(uint32_t b) { float v; __builtin_memcpy(&v, &b, 4); return v; }
+ADC_HD uint32_t adc_f32_ordered(float v)
+{
+    if (v == 0.0f) v = 0.0f; // -0 and +0 compare equal: one key (the sequential scan keeps the first of equal values: same value)
+    const uint32_t b = adc_f32_bits(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+ADC_HD float adc_f32_from_ordered(uint32_t k) { return adc_f32_from_bits((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+ADC_HD uint64_t adc_itp_key(bool mismatch, int dist, int ray, float hit)
+{
+    return mismatch ? (((uint64_t)(uint32_t)(dist * 16 + ray) << 32) | adc_f32_bits(hit)) : (uint64_t)adc_f32_ordered(hit);
+}
+ADC_HD float adc_itp_fill_from_key(bool mismatch, uint64_t key)
+{
+    if (key == ~(uint64_t)0) return 0.0f;
+    return mismatch ? adc_f32_from_bits((uint32_t)key) : adc_f32_from_ordered((uint32_t)key);
+}
+
 // ---- scanline prefetch geometry (k_scanline.hip; checked exhaustively on the CPU: tests/test_emul.py) ----
 // Byte offset into the right-image colour-step map of the VPL bytes the path element at coordinate m needs (m = x on a row
 // path, y on a column path; `path` = the row / column; cl_last = dmin + the lane's LAST disparity index, so xr = x - cl_last is

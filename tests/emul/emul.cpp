@@ -888,6 +888,98 @@ long emul_interpolate_skip(const float* din, float* dout, const uint8_t* label, 
     return lookups;
 }
 
+// ------------------------------------------------------------------ interpolation with rays as the unit of work
+// A wave = 64 lanes over a contiguous range of ray ids (id = list entry * 16 + ray).  Every round trip the lanes whose ray has
+// ended take the next ids of the range (in lane order, like a ballot + prefix count would hand them out), then every active
+// lane evaluates NS steps with the same skipping as emul_interpolate_skip; a hit goes into the target's accumulator by
+// minimum of adc_itp_key.  `wave_rays` rays per wave; the waves run in the given order (any order gives the same result).
+// Returns the number of wave round trips (the statistic the form is about).
+long emul_interpolate_refill(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
+                             int max_search, int NS, int wave_rays, unsigned seed)
+{
+    double sc[32];
+    const float pi = 3.1415926f;
+    double ang = 0.0;
+    for (int s = 0; s < 16; s++) { sc[2 * s] = sin(ang); sc[2 * s + 1] = cos(ang); ang += pi / 16; }
+    const int cw = (W + ADC_ITP_CELL - 1) / ADC_ITP_CELL, ch = (H + ADC_ITP_CELL - 1) / ADC_ITP_CELL;
+    std::vector<uint8_t> cell((size_t)cw * ch), rowd((size_t)cw * ch), cdist((size_t)cw * ch);
+    for (int cy = 0; cy < ch; cy++)
+        for (int cx = 0; cx < cw; cx++) {
+            bool any = false;
+            for (int r = 0; r < ADC_ITP_CELL; r++)
+                for (int q = 0; q < ADC_ITP_CELL; q++) {
+                    const int y = cy * ADC_ITP_CELL + r, x = cx * ADC_ITP_CELL + q;
+                    if (y < H && x < W) any = any || din[(size_t)y * W + x] != ADC_INVALID_FLOAT;
+                }
+            cell[(size_t)cy * cw + cx] = any ? 1 : 0;
+        }
+    for (int c = 0; c < cw * ch; c++) rowd[c] = (uint8_t)adc_itp_rowdist(cell.data(), cw, c % cw, c / cw);
+    for (int c = 0; c < cw * ch; c++) cdist[c] = (uint8_t)adc_itp_coldist(rowd.data(), cw, ch, c % cw, c / cw);
+    const bool mismatch = which == ADC_LABEL_MISMATCH;
+    std::vector<int> list;
+    for (int p = 0; p < W * H; p++) {
+        dout[p] = din[p];
+        if (label[p] == which && din[p] == ADC_INVALID_FLOAT) list.push_back(p);
+    }
+    const long nrays = (long)list.size() * 16;
+    std::vector<uint64_t> acc(list.size(), ~(uint64_t)0);
+    const long nwaves = (nrays + wave_rays - 1) / wave_rays;
+    std::vector<long> order(nwaves);
+    for (long i = 0; i < nwaves; i++) order[i] = i;
+    srand(seed);
+    for (long i = nwaves - 1; i > 0; i--) std::swap(order[i], order[rand() % (i + 1)]);
+    long trips = 0;
+    struct Lane { bool active; long id; int m; };
+    for (long wv = 0; wv < nwaves; wv++) {
+        long next = order[wv] * wave_rays;
+        const long end = std::min(nrays, next + wave_rays);
+        Lane lane[64];
+        for (int l = 0; l < 64; l++) lane[l].active = false;
+        while (true) {
+            for (int l = 0; l < 64; l++) // refill in lane order
+                if (!lane[l].active && next < end) {
+                    lane[l].active = true;
+                    lane[l].id = next++;
+                    const int p = list[lane[l].id >> 4], y = p / W, x = p - y * W;
+                    lane[l].m = 1 + adc_itp_skip(cdist[(size_t)(y / ADC_ITP_CELL) * cw + x / ADC_ITP_CELL]);
+                    if (lane[l].m >= max_search) lane[l].active = false, l--; // (search range exhausted before the first step: next ray)
+                }
+            bool any = false;
+            for (int l = 0; l < 64; l++) any = any || lane[l].active;
+            if (!any) break;
+            trips++;
+            for (int l = 0; l < 64; l++) {
+                if (!lane[l].active) continue;
+                const long e = lane[l].id >> 4;
+                const int s = (int)(lane[l].id & 15), p = list[e], y = p / W, x = p - y * W;
+                const double sina = sc[2 * s], cosa = sc[2 * s + 1];
+                int m = lane[l].m, cl = 0;
+                bool walking = true;
+                for (int j = 0; j < NS && walking; j++) {
+                    if (m + j >= max_search) { walking = false; break; }
+                    const int yy = (int)lround((double)y + (double)(m + j) * sina), xx = (int)lround((double)x + (double)(m + j) * cosa);
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) { walking = false; break; }
+                    const float d = din[(size_t)yy * W + xx];
+                    if (d != ADC_INVALID_FLOAT) {
+                        const size_t q = (size_t)yy * W + xx;
+                        const int dist = mismatch ? adc_color_dist_l1(img_l + (size_t)p * 3, img_l + q * 3) : 0;
+                        const uint64_t key = adc_itp_key(mismatch, dist, s, d);
+                        acc[e] = key < acc[e] ? key : acc[e];
+                        walking = false;
+                        break;
+                    }
+                    if (j == NS - 1) cl = cdist[(size_t)(yy / ADC_ITP_CELL) * cw + xx / ADC_ITP_CELL];
+                }
+                m += NS + adc_itp_skip(cl);
+                lane[l].m = m;
+                if (!walking || m >= max_search) lane[l].active = false;
+            }
+        }
+    }
+    for (size_t e = 0; e < list.size(); e++) dout[list[e]] = adc_itp_fill_from_key(mismatch, acc[e]);
+    return trips;
+}
+
 // ------------------------------------------------------------------ k_median_wavefront
 void emul_median_wavefront(const float* in, float* out, int W, int H)
 {

@@ -403,6 +403,35 @@ def test_interpolation_skipping_is_exact(emul, seed, density, ns):
             assert n < 0.6 * plain.value, (n, plain.value)   # the sparse band is crossed in jumps
 
 
+@pytest.mark.parametrize("seed,density,negative", [(1, 0.003, False), (2, 0.02, True), (3, 0.25, False), (6, 0.0, False), (7, 0.05, True)])
+def test_interpolation_with_rays_as_the_unit_of_work(emul, seed, density, negative):
+    """The ray-refill form (adc_itp_key in adc_device_fn.h): lanes take the next ray of the list as soon as theirs has
+    ended, the 16 first hits of a target are combined by an order-independent minimum of a key -- same fills as the plain walk
+    for both rules (colour-nearest with the first minimum in ray order; smallest disparity, also with negative disparities and
+    equal values), for any number of rays per wave and any wave order; and far fewer wave round trips than 4 targets per wave."""
+    rng = np.random.default_rng(seed)
+    w, h, ms = 157, 83, 96
+    valid = rng.random((h, w)) < density
+    valid[:, 100:] |= rng.random((h, w - 100)) < 0.3
+    vals = rng.integers(-40 if negative else 0, 90, (h, w)).astype(np.float32) + (rng.integers(0, 4, (h, w)) / 4).astype(np.float32)
+    disp = np.where(valid, vals, np.float32(np.inf)).astype(np.float32)
+    label = rng.integers(0, 3, (h, w)).astype(np.uint8)
+    img = rng.integers(0, 40, (h, w, 3), dtype=np.uint8)  # few colours: equal colour distances are common (first-minimum rule)
+    emul.emul_interpolate_refill.restype = C.c_long
+    for which in (1, 2):
+        want = np.empty((h, w), np.float32)
+        emul.emul_interpolate(P(disp), P(want), P(label), P(img), w, h, which, ms)
+        trips = {}
+        for wave_rays, sd in ((64, 1), (1024, 2), (4096, 3)):
+            got = np.empty((h, w), np.float32)
+            trips[wave_rays] = emul.emul_interpolate_refill(P(disp), P(got), P(label), P(img), w, h, which, ms, 4, wave_rays, sd)
+            assert same(got, want), (which, wave_rays)
+        n = int(((label == which) & ~valid).sum())
+        if n > 1000 and density <= 0.05:
+            # 64 rays per wave = the present binding of 4 targets to a wave; a long queue per wave needs far fewer trips
+            assert trips[4096] < 0.7 * trips[64], trips
+
+
 def test_voting_packed_halfword_helpers(emul):
     """irv_plan.h: irv_decode_block (eligible / final / invalid-bin / same-bin masks of 8 packed state halfwords by SWAR
     carries) and the change-tile row test (byte masks from a nibble expansion, any-zero-byte trick) agree with per-pixel
