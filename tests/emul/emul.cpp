@@ -387,6 +387,88 @@ void emul_scanline_pass(const float* src, float* dst, const uint8_t* cd_left, co
     }
 }
 
+// ------------------------------------------------------------------ scanline paths cut into verified segments
+// (tools/so_merge_length.py).  A path of plen elements is cut at nseg - 1 seams (multiples of 16).  Segment k > 0
+// starts `warm` elements before its seam with the state of a FIRST element (the raw costs), runs to the seam without storing,
+// and its state at the last warm-up element is compared bit for bit with what the predecessor stored there: equal => the
+// segment continues from its own state (which is the true one), different => it continues from the predecessor's output (the
+// re-run of the real kernel; counted).  Either way the result is the full pass; returns the number of seams that failed.
+long emul_scanline_pass_segments(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H, int dmin,
+                                 int D, int vert, int dir, int tso, float p1, float p2, int nseg, int warm)
+{
+    const float P1c[3] = {p1, p1 / 4, p1 / 10}, P2c[3] = {p2, p2 / 4, p2 / 10};
+    const int npaths = vert ? W : H, plen = vert ? H : W;
+    std::vector<float> Lp(D), out(D);
+    long failed = 0;
+    for (int path = 0; path < npaths; path++) {
+        auto coord = [&](int i, int& x, int& y) {
+            const int m = dir > 0 ? i : plen - 1 - i;
+            if (vert) { x = path; y = m; } else { x = m; y = path; }
+        };
+        auto start = [&](int i, float& minLp, bool store) { // element i as a first element
+            int x, y;
+            coord(i, x, y);
+            minLp = ADC_LARGE_FLOAT;
+            for (int d = 0; d < D; d++) {
+                const float c = src[((size_t)y * W + x) * D + d];
+                if (store) dst[((size_t)y * W + x) * D + d] = c;
+                Lp[d] = c;
+                minLp = c < minLp ? c : minLp;
+            }
+        };
+        auto step = [&](int i, float& minLp, bool store) {
+            int x, y;
+            coord(i, x, y);
+            const int sx = vert ? x : (dir > 0 ? x : x + 1);
+            const int sy = vert ? (dir > 0 ? y : y + 1) : y;
+            const int d1 = cd_left[(size_t)sy * W + sx];
+            const uint8_t* row = cd_right + (size_t)sy * W;
+            const int shift = vert ? 0 : (dir > 0 ? 0 : 1);
+            float omin = ADC_LARGE_FLOAT;
+            for (int d = 0; d < D; d++) {
+                const int col = adc_so_d2_column(x, dmin, d, W);
+                const int d2 = col >= 0 ? (int)row[col + shift] : d1;
+                const int cls = adc_so_penalty_class(d1, d2, tso);
+                const float P1 = P1c[cls], P2 = P2c[cls];
+                const float lm1 = d > 0 ? Lp[d - 1] : ADC_LARGE_FLOAT;
+                const float lp1 = d < D - 1 ? Lp[d + 1] : ADC_LARGE_FLOAT;
+                const float l1 = Lp[d], l2 = lm1 + P1, l3 = lp1 + P1, l4 = minLp + P2;
+                const float m12 = l2 < l1 ? l2 : l1, m34 = l4 < l3 ? l4 : l3;
+                const float mm = m34 < m12 ? m34 : m12;
+                float cs = src[((size_t)y * W + x) * D + d] + mm;
+                cs = cs / 2;
+                out[d] = cs;
+                omin = cs < omin ? cs : omin;
+            }
+            for (int d = 0; d < D; d++) { if (store) dst[((size_t)y * W + x) * D + d] = out[d]; Lp[d] = out[d]; }
+            minLp = omin;
+        };
+        std::vector<int> seam(nseg + 1);
+        for (int k = 0; k <= nseg; k++) seam[k] = k == nseg ? plen : (int)((long)plen * k / nseg) / 16 * 16;
+        for (int k = 0; k < nseg; k++) { // (on the GPU the segments run concurrently; the comparison is what orders them)
+            if (seam[k + 1] <= seam[k]) continue;
+            float minLp;
+            if (k == 0 || seam[k] == 0) start(seam[k], minLp, true);
+            else {
+                const int s = std::max(seam[k] - warm, 0);
+                start(s, minLp, false);
+                for (int i = s + 1; i < seam[k]; i++) step(i, minLp, false);
+                int x, y;
+                coord(seam[k] - 1, x, y);
+                const float* truth = dst + ((size_t)y * W + x) * D; // the predecessor's output at the last warm-up element
+                if (s > 0 && memcmp(Lp.data(), truth, D * sizeof(float))) {
+                    failed++;
+                    minLp = ADC_LARGE_FLOAT;
+                    for (int d = 0; d < D; d++) { Lp[d] = truth[d]; minLp = Lp[d] < minLp ? Lp[d] : minLp; }
+                }
+                step(seam[k], minLp, true);
+            }
+            for (int i = seam[k] + 1; i < seam[k + 1]; i++) step(i, minLp, true);
+        }
+    }
+    return failed;
+}
+
 // ------------------------------------------------------------------ k_scanline, lane structure of the penalty classes
 // Same DP, but the (P1,P2) class of every disparity is derived the way the kernel does it: lane l owns VPL consecutive
 // disparities, fetches VPL consecutive bytes of the right-image step map at column max(xr_last, 1) (+1 on R->L) and

@@ -246,6 +246,33 @@ def test_scanline_chunked_forms(emul, dumps, name, want_short):
     assert (short > 0) == want_short, short
 
 
+@pytest.mark.parametrize("name", ["s2_320x180_d128", "q_257x131_d64", "cone_crop_d40", "s2_150x100_neg", "noise_160x90_d128_pos"])
+def test_scanline_verified_segments(emul, dumps, name):
+    """Paths cut into segments that start with the wrong state 64 elements early and are verified bit for bit at the seam
+    (DESIGN 4.2): the four chained passes still give the reference's volume; with a 64-element warm-up no seam fails on these
+    cases, with a 4-element warm-up most do -- and the result is still exact, because a failed seam falls back to the
+    predecessor's state."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    lh, lv, rh, rv = (np.zeros((h, w), np.uint8) for _ in range(4))
+    emul.emul_color_diffs(P(left), P(lh), P(lv), w, h)
+    emul.emul_color_diffs(P(right), P(rh), P(rv), w, h)
+    emul.emul_scanline_pass_segments.restype = C.c_long
+    for nseg, warm, expect_clean in ((2, 64, True), (3, 64, True), (3, 4, False)):
+        a, b = o["cost_aggr"].copy(), np.empty_like(o["cost_aggr"])
+        failed = 0
+        for vert, dr in ((0, 1), (0, -1), (1, 1), (1, -1)):
+            failed += emul.emul_scanline_pass_segments(P(a), P(b), P(lv if vert else lh), P(rv if vert else rh), w, h, dmin, D, vert, dr,
+                                                       opt.so_tso, C.c_float(opt.so_p1), C.c_float(opt.so_p2), nseg, warm)
+            a, b = b, a
+        assert same(a, o["cost_so"]), (nseg, warm)
+        if expect_clean:
+            assert failed == 0, (nseg, warm, failed)
+        elif min(w, h) >= 96:
+            assert failed > 0
+
+
 def test_scanline_chunk_predicate_implies_no_clamp_and_interior_rule(emul):
     """Exhaustive over small geometries: whenever adc_so_chunk_interior accepts a chunk, (i) every element it steps on is
     interior in the sense of the per-step test, (ii) the clamped rmap offset of every element it prefetches is affine in the
