@@ -48,6 +48,22 @@ def main():
         ok = np.array_equal(d.view(np.uint32), o["disp_after_irv"].view(np.uint32))
         print("  tiles %3dx%-3d  %s, up to %2d local rounds: %3d kernels over the 10 passes %s  %.2f M vote evaluations  equals the reference: %s"
               % (S, S, "parallel rounds" if J else "sequential sweep", T, tot, list(per), ev.value / 1e6, ok))
+    # the same with tile skipping and a per-entry dirty test, per-kernel statistics and a time estimate: a kernel costs its
+    # boundary (2.5 us) + the busiest tile's votes shared by the 16 waves of a workgroup at ~1.5 us per vote and wave (LDS-resident
+    # state) -- or, when more tiles are active than the chip holds workgroups (512), the total votes over all 4096 wave slots
+    lib.irv_local_stats.restype = C.c_long
+    for S, T in ((64, 8), (32, 8), (64, 16)):
+        d = o["disp_after_lr"].copy()
+        st = (C.c_long * (4 * 400))()
+        tot = lib.irv_local_stats(P(d), P(lab), P(arms), W, H, opt.min_disparity, D, opt.irv_ts, C.c_float(opt.irv_th), S, T, 1, st, 400)
+        ok = np.array_equal(d.view(np.uint32), o["disp_after_irv"].view(np.uint32))
+        a = np.array(list(st), np.int64).reshape(-1, 4)[:tot]
+        est = sum(2.5 + max(m / 16.0, v / 4096.0) * 1.5 for _, _, v, m in a)
+        print("  tiles %dx%d, up to %d local rounds, tile skipping + dirty test: %d kernels, %.2f M votes, busiest tile per kernel p50 %d / max %d votes, "
+              "active tiles per kernel p50 %d; equals the reference: %s; estimated %.2f ms at this size"
+              % (S, S, T, tot, a[:, 2].sum() / 1e6, np.median(a[:, 3]), a[:, 3].max(), np.median(a[:, 1]), ok, est / 1e3))
+        first = a[[i for i in range(len(a)) if i == 0 or a[i, 0] != a[i - 1, 0]]]
+        print("      first kernel of a pass: votes %s, busiest tile %s" % (list(first[:, 2]), list(first[:, 3])))
 
 
 if __name__ == "__main__":
