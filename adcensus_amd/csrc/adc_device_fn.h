@@ -299,6 +299,16 @@ ADC_HD float adc_medj_pixel(const float* A, int pa, const float* U, int pu, int 
     return adc_median9(v0, v1, v2, v3, v5, v6, v7, v8, v4);
 }
 
+// The same for a snapshot that does not touch the image border (y0 > 0, y1 < H, x0 > 0, x1 < W): every pixel that is not held
+// has all eight neighbours inside the image, no substitutions.
+ADC_HD float adc_medj_pixel_interior(const float* A, int pa, const float* U, int pu, int ly, int lx, int w)
+{
+    if (ly == 0 || lx == 0 || lx == w - 1) return A[ly * pa + lx];
+    const float* a = A + (ly - 1) * pa + lx;
+    const float* u = U + ly * pu + lx + 1; // U's column index is lx + 1
+    return adc_median9(a[-1], a[0], a[1], a[pa - 1], u[1], u[pu - 1], u[pu], u[pu + 1], u[0]);
+}
+
 // Sorts v[0..8] ascending (25 compare-exchanges, optimal-size network for n=9).
 ADC_HD void adc_sort9(float* v)
 {

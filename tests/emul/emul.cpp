@@ -622,10 +622,12 @@ int emul_median_tiles(const float* inp, float* cur, int W, int H, int S, int T, 
                 U[(size_t)ly * pu + lx] = inp[(size_t)gy * W + gx];
             }
         int a = 0;
+        const bool inner = y0 > 0 && y1 < H && x0 > 0 && x1 < W; // the snapshot does not touch the image border
         for (int r = 0; r < T; r++) {
             for (int ly = 0; ly < h; ly++)
                 for (int lx = 0; lx < w; lx++)
-                    A[a ^ 1][(size_t)ly * pa + lx] = adc_medj_pixel(A[a].data(), pa, U.data(), pu, ly, lx, w, y0, x0, x1, W, H);
+                    A[a ^ 1][(size_t)ly * pa + lx] = inner ? adc_medj_pixel_interior(A[a].data(), pa, U.data(), pu, ly, lx, w)
+                                                           : adc_medj_pixel(A[a].data(), pa, U.data(), pu, ly, lx, w, y0, x0, x1, W, H);
             a ^= 1;
         }
         for (int cy = 0; cy < S; cy++)
