@@ -5,7 +5,7 @@
 #   gpurun --timeout 600 -- 'bash tools/experiments/median_blocked_jacobi.sh'
 # Stops at the first failing step.  ADC_MEDIAN_JACOBI = number of kernels in the chain (8 rounds each; the 1080p noise pair needs
 # 8, the budget below is 12); a chain that has not converged takes the existing fallback in adc_wait, so a wrong result can only
-# come from the kernel itself.  If the 70 KB of static LDS are refused at launch, lower MEDJ_S to 48.
+# come from the kernel itself.
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
 O=gpurun_out
 ADC_MEDIAN_JACOBI=12 timeout 300 python -m pytest tests/test_gpu_stages.py -m gpu -x -q 2>&1 | tail -5 | tee $O/medj_pytest.log
