@@ -72,6 +72,20 @@ def main():
         # the fills of this list are written back before the next list is walked (multistep_refiner.cpp:298-303)
         fin = o["disp_after_interp"]
         dmap.ravel()[targets] = fin.ravel()[targets]
+    # the ray-refill form itself (tests/emul/emul.cpp emul_interpolate_refill: lanes take the next ray of their wave's range when
+    # theirs has ended, atomic-minimum combine), both lists, against the reference's map
+    emul_so = os.path.join(ROOT, "tests", "emul", "_build", "libadcensus_emul.so")
+    if os.path.exists(emul_so):
+        emul = C.CDLL(emul_so)
+        emul.emul_interpolate_refill.restype = C.c_long
+        left = np.ascontiguousarray(l)
+        for rays in (64, 1024, 4096):
+            a, b = o["disp_after_irv"].copy(), np.empty_like(o["disp_after_irv"])
+            t1 = emul.emul_interpolate_refill(P(a), P(b), P(lab), P(left), W, H, 1, D, 4, rays, 1)
+            t2 = emul.emul_interpolate_refill(P(b), P(a), P(lab), P(left), W, H, 2, D, 4, rays, 2)
+            print("  refill form, %4d rays per wave range%s: wave round trips %d + %d; equals the reference's map: %s"
+                  % (rays, " (= 4 targets bound to a wave, the present kernel)" if rays == 64 else "", t1, t2,
+                     np.array_equal(a.view(np.uint32), o["disp_after_interp"].view(np.uint32))))
 
 
 if __name__ == "__main__":
