@@ -510,3 +510,25 @@ def test_median_tiles_device_function(emul, dumps, name):
             if ch == 0:
                 break
         assert same(cur, ref), (S, T, kernels)
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (3, 3), (3, 7), (7, 7), (8, 10), (10, 8), (9, 6), (12, 30), (31, 17), (64, 48), (5, 11)])
+def test_median_ring_padding_reproduces_the_window_rule(shape):
+    """A ring of period-3 values (one -inf, two +inf among any three consecutive cells) around the map lets the PLAIN median of
+    nine reproduce the reference's window rule on the image edges (tools/median_rounds.py ring_padded): what makes every tile of
+    the tiled median an interior tile.  Checked against the explicit substitution rule on random maps incl. invalid (+inf)
+    values, all residues of W and H modulo 3."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("median_rounds", os.path.join(ROOT, "tools", "median_rounds.py"))
+    mr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mr)
+    h, w = shape
+    rng = np.random.default_rng(h * 100 + w)
+    for trial in range(6):
+        inp = rng.integers(0, 50, (h, w)).astype(np.float32)
+        inp[rng.random((h, w)) < 0.2] = mr.BIG
+        cur = inp.copy()
+        cur[rng.random((h, w)) < 0.5] = np.float32(rng.integers(0, 50))
+        want = mr.F(cur, inp, 0, h, 0, w)
+        got = mr.F_ring(cur, inp)
+        assert np.array_equal(want, got), (shape, trial)

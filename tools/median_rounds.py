@@ -47,6 +47,41 @@ def F(cur, inp, y0, y1, x0, x1):
     return np.sort(window(cp, ip, y0, y1, x0, x1), axis=0)[4]
 
 
+def ring_padded(a):
+    """a with one ring of cells around it whose values make the PLAIN median of nine reproduce the window rule on the four image
+    edges: among any three consecutive ring cells along an edge one is -inf and two are +inf (period 3), so an edge pixel's three
+    missing neighbours count as one value below and two above everything -- exactly what the side-centre / corner substitution
+    does.  (The four corner pixels miss five neighbours and keep the explicit rule.)"""
+    H, W = a.shape
+    p = np.full((H + 2, W + 2), np.inf, np.float32)
+    p[1:-1, 1:-1] = a
+    lo = np.float32(-np.inf)
+    for c in range(0, W, 3):
+        p[0, 1 + c] = lo
+        p[H + 1, 1 + c] = lo
+    for r in range(0, H, 3):
+        p[1 + r, 0] = lo
+        p[1 + r, W + 1] = lo
+    return p
+
+
+def F_ring(cur, inp):
+    """one Jacobi round with the ring-padded maps and NO border logic except the four corner pixels"""
+    H, W = inp.shape
+    cp, ip = ring_padded(cur), ring_padded(inp)
+    out = []
+    for dy, dx in PRED:
+        out.append(cp[1 + dy:1 + H + dy, 1 + dx:1 + W + dx])
+    for dy, dx in REST:
+        out.append(ip[1 + dy:1 + H + dy, 1 + dx:1 + W + dx])
+    new = np.sort(np.stack(out), axis=0)[4]
+    ref = F(cur, inp, 0, H, 0, W)  # (the explicit rule, used for the four corner pixels only)
+    for y in (0, H - 1):
+        for x in (0, W - 1):
+            new[y, x] = ref[y, x]
+    return new
+
+
 def fin(m):
     return np.where(np.isinf(m), BIG, m).astype(np.float32)
 
