@@ -309,6 +309,41 @@ ADC_HD float adc_medj_pixel_interior(const float* A, int pa, const float* U, int
     return adc_median9(a[-1], a[0], a[1], a[pa - 1], u[1], u[pu - 1], u[pu], u[pu + 1], u[0]);
 }
 
+// ---- second form of the tiled median (experimental: tools/experiments/median_tiles_v2.patch): maps padded by ONE ring ----
+// The maps are stored with one ring of cells around the image (pitch W + 2, H + 2 rows; pixel (x, y) at (x + 1, y + 1)).  The ring
+// holds a pattern of period 3 along each edge -- cell index % 3 == 0: -inf, else +inf -- so that among the three ring neighbours of
+// an edge pixel exactly one counts below and two above every value: the PLAIN median of the nine cells then equals the
+// reference's window rule (a missing side-centre neighbour = -inf, a missing corner neighbour = +inf).  Only the four image
+// corner pixels, which miss five neighbours, keep the explicit rule (adc_medp_corner).  Checked on the CPU for every residue
+// of W and H modulo 3 (tests/test_emul.py, tools/median_rounds.py ring_padded).
+ADC_HD float adc_medp_ring_value(int idx_along_edge) { return (idx_along_edge % 3 == 0) ? -ADC_INVALID_FLOAT : ADC_INVALID_FLOAT; }
+// value of the padded cell (px, py) of a W x H image when it is a ring cell (px == 0, px == W + 1, py == 0 or py == H + 1);
+// the four ring corners belong to the horizontal edges (their value is never used by the plain form: only corner pixels see them)
+ADC_HD float adc_medp_ring_cell(int px, int py, int W, int H)
+{
+    if (py == 0 || py == H + 1) return (px >= 1 && px <= W) ? adc_medp_ring_value(px - 1) : ADC_INVALID_FLOAT;
+    return adc_medp_ring_value(py - 1);
+}
+// plain form: C = iterate, U = unfiltered map, both padded with pitch `pitch`; (lx, ly) addresses the pixel inside the arrays
+ADC_HD float adc_medp_pixel(const float* C, const float* U, int pitch, int ly, int lx)
+{
+    const float* c = C + (ly - 1) * pitch + lx;
+    const float* u = U + ly * pitch + lx;
+    return adc_median9(c[-1], c[0], c[1], c[pitch - 1], u[1], u[pitch - 1], u[pitch], u[pitch + 1], u[0]);
+}
+// the four image corner pixels: explicit substitution (up / lf = the pixel has a row above / a column to its left; a corner
+// pixel misses exactly one of each pair: up XOR dn, lf XOR rt)
+ADC_HD float adc_medp_corner(const float* C, const float* U, int pitch, int ly, int lx, bool up, bool lf)
+{
+    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
+    const bool dn = !up, rt = !lf;
+    const float* c = C + (ly - 1) * pitch + lx;
+    const float* u = U + ly * pitch + lx;
+    const float v0 = (up && lf) ? c[-1] : PINF, v1 = up ? c[0] : NINF, v2 = (up && rt) ? c[1] : PINF, v3 = lf ? c[pitch - 1] : NINF;
+    const float v5 = rt ? u[1] : NINF, v6 = (dn && lf) ? u[pitch - 1] : PINF, v7 = dn ? u[pitch] : NINF, v8 = (dn && rt) ? u[pitch + 1] : PINF;
+    return adc_median9(v0, v1, v2, v3, v5, v6, v7, v8, u[0]);
+}
+
 // Sorts v[0..8] ascending (25 compare-exchanges, optimal-size network for n=9).
 ADC_HD void adc_sort9(float* v)
 {

@@ -646,6 +646,77 @@ int emul_median_tiles(const float* inp, float* cur, int W, int H, int S, int T, 
     }
     return changed;
 }
+// Second form of the tiled median: maps padded by one ring (adc_medp_*), every tile interior, tiles skipped while their 3x3
+// neighbourhood is quiet.  One call = one kernel: every tile in the given order; a tile runs if first != 0 or one of the 3x3 tiles
+// around it changed in the previous kernel (flags_prev), takes its snapshot from the padded iterate `cur` (kernel 0: from the
+// padded unfiltered map `inp`), runs T local rounds -- the snapshot's first row, first and last column are never computed (a cut
+// edge or the ring) -- and writes its core back in place.  flags_out[t] = the tile changed a value.  Returns changed tiles.
+int emul_median_tiles_padded(const float* inp_p, float* cur_p, int W, int H, int S, int T, int first, const int* order, int ntiles,
+                             const uint8_t* flags_prev, uint8_t* flags_out)
+{
+    const int tw = (W + S - 1) / S, th = (H + S - 1) / S, Wp = W + 2;
+    int nchanged = 0;
+    std::vector<float> A[2], U;
+    for (int t = 0; t < ntiles; t++) flags_out[t] = 0;
+    for (int oi = 0; oi < ntiles; oi++) {
+        const int t = order[oi], txi = t % tw, tyi = t / tw;
+        bool run = first != 0;
+        for (int dy = -1; dy <= 1 && !run; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int yy = tyi + dy, xx = txi + dx;
+                if (yy >= 0 && yy < th && xx >= 0 && xx < tw && flags_prev[yy * tw + xx]) run = true;
+            }
+        if (!run) continue;
+        const int tx = txi * S, ty = tyi * S;
+        const int py0 = ty + 1 - T > 0 ? ty + 1 - T : 0, px0 = tx + 1 - T > 0 ? tx + 1 - T : 0;
+        const int py1 = ty + 1 + (S < H - ty ? S : H - ty), px1 = tx + 1 + S + T < W + 2 ? tx + 1 + S + T : W + 2; // exclusive
+        const int h = py1 - py0, w = px1 - px0;
+        const float* src = first ? inp_p : cur_p;
+        A[0].assign((size_t)h * w, 0.f);
+        A[1].assign((size_t)h * w, 0.f);
+        U.assign((size_t)(h + 1) * w, 0.f);
+        for (int ly = 0; ly < h; ly++)
+            for (int lx = 0; lx < w; lx++) A[0][(size_t)ly * w + lx] = A[1][(size_t)ly * w + lx] = src[(size_t)(py0 + ly) * Wp + px0 + lx];
+        for (int ly = 0; ly < h + 1; ly++)
+            for (int lx = 0; lx < w; lx++) U[(size_t)ly * w + lx] = inp_p[(size_t)(py0 + ly) * Wp + px0 + lx];
+        int a = 0;
+        for (int r = 0; r < T; r++) {
+            for (int ly = 1; ly < h; ly++)
+                for (int lx = 1; lx < w - 1; lx++) {
+                    const int gx = px0 + lx - 1, gy = py0 + ly - 1; // image coordinates
+                    const bool cx = gx == 0 || gx == W - 1, cy = gy == 0 || gy == H - 1;
+                    A[a ^ 1][(size_t)ly * w + lx] = (cx && cy) ? adc_medp_corner(A[a].data(), U.data(), w, ly, lx, gy > 0, gx > 0)
+                                                               : adc_medp_pixel(A[a].data(), U.data(), w, ly, lx);
+                }
+            a ^= 1;
+        }
+        bool changed = false;
+        for (int cy = 0; cy < S; cy++)
+            for (int cx = 0; cx < S; cx++) {
+                const int gy = ty + cy, gx = tx + cx;
+                if (gy < H && gx < W) {
+                    const float v = A[a][(size_t)(gy + 1 - py0) * w + gx + 1 - px0];
+                    const size_t q = (size_t)(gy + 1) * Wp + gx + 1;
+                    uint32_t b0, b1;
+                    memcpy(&b0, &v, 4);
+                    memcpy(&b1, &src[q], 4);
+                    changed = changed || b0 != b1;
+                    cur_p[q] = v;
+                }
+            }
+        flags_out[t] = changed ? 1 : 0;
+        nchanged += changed ? 1 : 0;
+    }
+    return nchanged;
+}
+// padded copy of a map with the ring pattern (what the pad kernel writes)
+void emul_median_pad(const float* in, float* out_p, int W, int H)
+{
+    for (int py = 0; py < H + 2; py++)
+        for (int px = 0; px < W + 2; px++)
+            out_p[(size_t)py * (W + 2) + px] = (px == 0 || px == W + 1 || py == 0 || py == H + 1) ? adc_medp_ring_cell(px, py, W, H)
+                                                                                              : in[(size_t)(py - 1) * W + px - 1];
+}
 int emul_scanline_pass_chunked(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
                                int dmin, int D, int vert, int dir, int tso, float p1, float p2)
 {

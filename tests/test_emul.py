@@ -532,3 +532,30 @@ def test_median_ring_padding_reproduces_the_window_rule(shape):
         want = mr.F(cur, inp, 0, h, 0, w)
         got = mr.F_ring(cur, inp)
         assert np.array_equal(want, got), (shape, trial)
+
+
+@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_30x7_d8", "q_9x20_d8", "q_20x40_d32", "s2_150x100_neg", "cone_crop_d40", "s2_320x180_d128"])
+def test_median_tiles_padded_with_skipping(emul, dumps, name):
+    """Second form of the tiled median (adc_medp_*): ring-padded maps (every tile interior, explicit rule on the four
+    corner pixels only) and tiles that are skipped while their 3x3 neighbourhood was quiet in the previous kernel -- kernels until
+    one changes nothing, result = the reference's in-place median; most tiles are skipped in the later kernels."""
+    left, right, opt, o = dumps(name)
+    inp, ref = np.ascontiguousarray(o["disp_after_dda"]), o["disp_final"]
+    h, w = inp.shape
+    inp_p = np.zeros((h + 2, w + 2), np.float32)
+    emul.emul_median_pad(P(inp), P(inp_p), w, h)
+    for S, T, seed in ((16, 4, 1), (8, 8, 2), (64, 8, 3), (32, 8, 4)):
+        tw, th = (w + S - 1) // S, (h + S - 1) // S
+        cur_p = inp_p.copy()  # (ring in place; the interior is overwritten by kernel 0)
+        rng = np.random.default_rng(seed)
+        flags = [np.zeros(tw * th, np.uint8), np.zeros(tw * th, np.uint8)]
+        kernels, ran = 0, []
+        while True:
+            order = np.ascontiguousarray(rng.permutation(tw * th).astype(np.int32))
+            nch = emul.emul_median_tiles_padded(P(inp_p), P(cur_p), w, h, S, T, 1 if kernels == 0 else 0, P(order), tw * th,
+                                                P(flags[(kernels + 1) & 1]), P(flags[kernels & 1]))
+            kernels += 1
+            assert kernels < 200
+            if nch == 0:
+                break
+        assert same(np.ascontiguousarray(cur_p[1:-1, 1:-1]), ref), (S, T, kernels)
