@@ -1049,8 +1049,17 @@ long emul_interpolate_skip(const float* din, float* dout, const uint8_t* label, 
 // lane evaluates NS steps with the same skipping as emul_interpolate_skip; a hit goes into the target's accumulator by
 // minimum of adc_itp_key.  `wave_rays` rays per wave; the waves run in the given order (any order gives the same result).
 // Returns the number of wave round trips (the statistic the form is about).
+long emul_interpolate_refill_mode(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
+                                  int max_search, int NS, int wave_rays, unsigned seed, int static_lanes);
 long emul_interpolate_refill(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
                              int max_search, int NS, int wave_rays, unsigned seed)
+{
+    return emul_interpolate_refill_mode(din, dout, label, img_l, W, H, which, max_search, NS, wave_rays, seed, 0);
+}
+// static_lanes != 0: lane l of a wave walks the rays base + l, base + l + 64, ... of its range (every lane knows its next ray in
+// advance, so its record can be prefetched while the current ray is walked) instead of taking the next free id by ballot
+long emul_interpolate_refill_mode(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
+                                  int max_search, int NS, int wave_rays, unsigned seed, int static_lanes)
 {
     double sc[32];
     const float pi = 3.1415926f;
@@ -1090,11 +1099,14 @@ long emul_interpolate_refill(const float* din, float* dout, const uint8_t* label
         const long end = std::min(nrays, next + wave_rays);
         Lane lane[64];
         for (int l = 0; l < 64; l++) lane[l].active = false;
+        long lane_next[64];
+        for (int l = 0; l < 64; l++) lane_next[l] = next + l;
         while (true) {
             for (int l = 0; l < 64; l++) // refill in lane order
-                if (!lane[l].active && next < end) {
+                if (!lane[l].active && (static_lanes ? lane_next[l] < end : next < end)) {
                     lane[l].active = true;
-                    lane[l].id = next++;
+                    if (static_lanes) { lane[l].id = lane_next[l]; lane_next[l] += 64; }
+                    else lane[l].id = next++;
                     const int p = list[lane[l].id >> 4], y = p / W, x = p - y * W;
                     lane[l].m = 1 + adc_itp_skip(cdist[(size_t)(y / ADC_ITP_CELL) * cw + x / ADC_ITP_CELL]);
                     if (lane[l].m >= max_search) lane[l].active = false, l--; // (search range exhausted before the first step: next ray)

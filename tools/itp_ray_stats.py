@@ -79,12 +79,14 @@ def main():
         emul = C.CDLL(emul_so)
         emul.emul_interpolate_refill.restype = C.c_long
         left = np.ascontiguousarray(l)
-        for rays in (64, 1024, 4096):
+        emul.emul_interpolate_refill_mode.restype = C.c_long
+        for rays, static in ((64, 0), (1024, 0), (4096, 0), (4096, 1), (16384, 1)):
             a, b = o["disp_after_irv"].copy(), np.empty_like(o["disp_after_irv"])
-            t1 = emul.emul_interpolate_refill(P(a), P(b), P(lab), P(left), W, H, 1, D, 4, rays, 1)
-            t2 = emul.emul_interpolate_refill(P(b), P(a), P(lab), P(left), W, H, 2, D, 4, rays, 2)
-            print("  refill form, %4d rays per wave range%s: wave round trips %d + %d; equals the reference's map: %s"
-                  % (rays, " (= 4 targets bound to a wave, the present kernel)" if rays == 64 else "", t1, t2,
+            t1 = emul.emul_interpolate_refill_mode(P(a), P(b), P(lab), P(left), W, H, 1, D, 4, rays, 1, static)
+            t2 = emul.emul_interpolate_refill_mode(P(b), P(a), P(lab), P(left), W, H, 2, D, 4, rays, 2, static)
+            print("  refill form, %5d rays per wave range, %s%s: wave round trips %d + %d; equals the reference's map: %s"
+                  % (rays, "every lane its own arithmetic sequence of rays (prefetchable)" if static else "next free ray by ballot",
+                     " (= 4 targets bound to a wave, the present kernel)" if rays == 64 else "", t1, t2,
                      np.array_equal(a.view(np.uint32), o["disp_after_interp"].view(np.uint32))))
 
 
