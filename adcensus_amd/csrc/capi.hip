@@ -122,7 +122,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->irv_bbox, P * 4));
     h->irv_grid = adc_irv_grid(P);
     HIP_OK(hipMalloc(&h->vote_list, adc_irv_list_entries(P, p.D, h->irv_grid) * 16)); // int4 per entry, whole batches (irv_plan.h: irv_list_slot)
-    HIP_OK(hipMemset(h->vote_list, 0, adc_irv_list_entries(P, p.D, h->irv_grid) * 16));
+    HIP_OK(hipMemset(h->vote_list, 0xFF, adc_irv_list_entries(P, p.D, h->irv_grid) * 16)); // every slot = IRV_LIST_END
     HIP_OK(hipMalloc(&h->vote_evals_arr, adc_irv_waves(h->irv_grid) * sizeof(int32_t)));
     HIP_OK(hipMalloc(&h->interp_list, P * 4));
     HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));

@@ -75,16 +75,27 @@ ADC_HD void irv_publish(int32_t* ctrl, int k, const IrvState& s)
 }
 
 // Work-list layout.  The chain's grid has G workgroups of WPB waves; a batch is B = 64 * WPB * G entries.  Entry i (in the
-// order the BEGIN phase compacts them: raster order inside chunks of pixels) is evaluated by WORKGROUP (i % B) % G, where it
-// sits in wave t % WPB, lane t / WPB with t = (i % B) / G: consecutive entries -- which tend to be dirty in the same
-// rounds (a fill front is a few hundred adjacent pixels) -- land in different workgroups, so every workgroup's pool of
-// dirty entries holds about dirty / G of them.  Stored so that the 64 entries of a wave are contiguous.
+// order the BEGIN phase compacts them: raster order inside chunks of pixels) belongs to WORKGROUP (i % B) % G: consecutive
+// entries -- which tend to be dirty in the same rounds (a fill front is a few hundred adjacent pixels) -- land in different
+// workgroups, so every workgroup's pool of dirty entries holds about dirty / G of them.  INSIDE the workgroup the entries
+// are packed densely: t = (i % B) / G sits in wave t / 64, lane t % 64 (round 4; before: wave t % WPB, lane t / WPB).  A
+// list of n entries then occupies the first ceil(n / G / 64) waves of every workgroup with all 64 lanes, and the other waves
+// find nothing but end markers (IRV_LIST_END, written over the unused slots by the first round of a pass and by the FINAL
+// kernel) and skip the state / change-tile phase altogether: in the long tail of a pass, where a round is a chain of memory
+// round trips plus the instruction issue of 8192 waves each checking a handful of lanes, a quarter (pass 0) to a tenth
+// (later passes) of the waves do the checking.  The votes are dealt out over ALL waves of the workgroup from the LDS pool.
+#define IRV_LIST_END (-1)
 ADC_HD long irv_list_slot(long i, int G, int WPB)
 {
     const long B = 64L * WPB * G, r = i % B;
     const long blk = r % G, t = r / G;
-    return (i / B) * B + (blk * WPB + t % WPB) * 64 + t / WPB;
+    return (i / B) * B + blk * (64L * WPB) + t;
 }
+// the list index held by lane `lane` of wave `wave` of workgroup `blk` in the batch that starts at b0 (inverse of irv_list_slot)
+ADC_HD long irv_list_index(long b0, int blk, int wave, int lane, int G) { return b0 + (long)(wave * 64 + lane) * G + blk; }
+// Entry = {pixel, arms of the pixel (left | right << 8 | top << 16 | bottom << 24), boxes, row}; boxes = max left | max right << 8
+// over the rows y - top .. y (the dependency box: only pixels that precede p can influence its vote) | max left << 16 |
+// max right << 24 over ALL region rows (the rectangle a vote starts to read before the row arms have arrived).
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Packed-halfword decode of a region row block (8 pixels of the 16-bit state map in four dwords) and of a change-tile row,

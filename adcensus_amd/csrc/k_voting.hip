@@ -54,22 +54,26 @@ extern "C" int adc_debug_irv_timing(long long* out, int which, int n)
 #define IRV_TR(slot) do { } while (0)
 #endif
 
-// Dependency box of a pixel's vote: the cross region of p spans rows y-top..y+bottom, but only pixels that PRECEDE p in
-// raster order can influence it, i.e. rows y-top..y; its horizontal extent is the widest H arm of those rows.
-// bbox[p] = {top, max left arm, max right arm} (computed once per Match; arms do not change).
+// Boxes of a pixel's vote (computed once per Match; arms do not change).  The cross region of p spans rows y-top..y+bottom.
+//   dependency box: only pixels that PRECEDE p in raster order can influence its vote, i.e. rows y-top..y; its horizontal
+//     extent is the widest H arm of those rows                                                      -> {ml, mr}
+//   read box: the widest H arms over ALL region rows -- the rectangle whose state blocks a vote requests together with the row
+//     arms, in the same memory round trip (the row arms then only mask)                             -> {ml_all, mr_all}
+// bbox[p] = {ml, mr, ml_all, mr_all}; it becomes word z of the pixel's work-list entry unchanged.
 __global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arms, uchar4* __restrict__ bbox, int W, int H)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const uchar4 a = arms[(size_t)y * W + x];
-    int ml = 0, mr = 0;
-    for (int t = -(int)a.z; t <= 0; t++) {
+    int ml = 0, mr = 0, mla = 0, mra = 0;
+    for (int t = -(int)a.z; t <= (int)a.w; t++) {
         const uchar4 q = arms[(size_t)(y + t) * W + x];
-        ml = adc_imax(ml, (int)q.x);
-        mr = adc_imax(mr, (int)q.y);
+        mla = adc_imax(mla, (int)q.x);
+        mra = adc_imax(mra, (int)q.y);
+        if (t == 0) { ml = mla; mr = mra; }
     }
-    bbox[(size_t)y * W + x] = make_uchar4(a.z, (unsigned char)ml, (unsigned char)mr, 0);
+    bbox[(size_t)y * W + x] = make_uchar4((unsigned char)ml, (unsigned char)mr, (unsigned char)mla, (unsigned char)mra);
 }
 
 // Did a pixel of the tile box [tx0, tx1] x [ty0, ty1] change in the round whose stamp is want4 (replicated byte)?  A
@@ -146,13 +150,13 @@ __device__ __forceinline__ int irv_row_prefix(int v)
 __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, int k, const uint8_t* __restrict__ label, float* __restrict__ disp,
                                                 float* disp_io, /* the pipeline's map: read by the first BEGIN, written by FINAL (no copies) */
                                                 const uint16_t* __restrict__ sup_h, uint16_t* st16, int4* list, uint8_t* chg,
-                                                const uchar4* __restrict__ bbox, const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
+                                                const uint32_t* __restrict__ bbox32, const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
                                                 int D, int min_region, int chg_bytes, int tpitch, int irv_ts, float irv_th,
                                                 int32_t* __restrict__ evals_arr)
 {
     IRV_TR(8);
     IRV_T(0);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, WPB = blockDim.x >> 6, T = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, WPB = blockDim.x >> 6, T = blockDim.x; // (wave: uniform, kept in a scalar register)
     const int gw = blockIdx.x * WPB + wave, NW = gridDim.x * WPB;
     // Everything the first phase of a ROUND needs is known at launch time: this wave's entries of batch 0, and -- the change
     // tiles being stamped and double-buffered by KERNEL index -- which plane and which stamp to look for.  So the entry,
@@ -166,13 +170,16 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     const uint32_t stamp = (uint32_t)(k % 255) + 1u;
     const uint8_t* chg_rd = chg + (size_t)((k + 1) & 1) * chg_bytes;
     uint8_t* chg_wr = chg + (size_t)(k & 1) * chg_bytes;
-    uint32_t spec_state;
-    bool spec_box;
-    {
-        const int p = spec.x, y = spec.w, x = p - y * W;
+    // Slots behind the end of the list hold IRV_LIST_END (see irv_plan.h): a wave that finds nothing else skips this phase.
+    uint32_t spec_state = IRV_FINAL;
+    bool spec_box = false;
+    if (__ballot(spec.x != IRV_LIST_END) != 0ull) {
+        const bool have = spec.x != IRV_LIST_END;
+        const int p = have ? spec.x : 0, y = have ? spec.w : 0, x = p - y * W;
         spec_state = st16[(uint32_t)(y * SP + x)]; // (32-bit offsets from a uniform base: saddr addressing, no 64-bit VGPR pairs)
         const int top = (int)(((uint32_t)spec.y >> 16) & 255u), ml = spec.z & 255, mr = (spec.z >> 8) & 255;
-        spec_box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, adc_imin(W - 1, x + mr) / IRV_TILE,
+        // (a lane without an entry gets an empty tile range: no loads)
+        spec_box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, have ? adc_imin(W - 1, x + mr) / IRV_TILE : -1,
                                  adc_imax(0, y - top) / IRV_TILE, y / IRV_TILE, want4);
     }
     const IrvState sprev = {__builtin_amdgcn_readlane(cword, 0), __builtin_amdgcn_readlane(cword, 1), __builtin_amdgcn_readlane(cword, 2),
@@ -203,6 +210,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 irv_publish(ctrl, k, fs);
             }
         }
+        // the no-op kernels behind the end of the chain (the budget's surplus) then find no entry and skip the state / tile
+        // round trip: the first batch of the list becomes end markers
+        if (pl.act == IRV_FINAL_WB) list[(size_t)gw * 64 + lane].x = IRV_LIST_END;
         const bool have_state = !(pl.act == IRV_BEGIN && pl.s.pass == 0); // pass 0: the state map is not initialised yet
         const int which = (pl.s.pass & 1) ? ADC_LABEL_OCCLUSION : ADC_LABEL_MISMATCH; // mismatches, then occlusions (:170-171)
         if (pl.act == IRV_BEGIN) // clear both change-tile planes of the pass (bytes, written as dwords)
@@ -268,9 +278,8 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                     off += c;
                 }
                 if (li) { // everything a round needs to know about the entry in ONE 16-byte load
-                    const uchar4 bb = bbox[p];
                     const long i = mine + __popcll(m & ((1ull << lane) - 1ull));
-                    list[irv_list_slot(i, (int)gridDim.x, WPB)] = make_int4(p, (int)arms32[p], (int)bb.y | ((int)bb.z << 8), p / W);
+                    list[irv_list_slot(i, (int)gridDim.x, WPB)] = make_int4(p, (int)arms32[p], (int)bbox32[p], p / W);
                 }
             }
             __syncthreads();
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     const long B = 64L * NW;
     int evals = 0;
     for (long b0 = 0; b0 < n; b0 += B) {
-        const long i = b0 + (long)(lane * WPB + wave) * gridDim.x + blockIdx.x; // (irv_list_slot)
+        const long i = irv_list_index(b0, (int)blockIdx.x, wave, lane, (int)gridDim.x);
         int4 ent = spec;
         if (b0 != 0) {
             ent = list[b0 + (size_t)gw * 64 + lane];
@@ -299,20 +308,25 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         }
         uint32_t mystate = spec_state;
         bool box = spec_box;
-        if (b0 != 0) {
-            const int p = ent.x, y = ent.w, x = p - y * W;
+        if (b0 != 0) { // (later batches are full up to n: entries of this pass, or older ones / end markers behind n)
+            const bool have = ent.x != IRV_LIST_END;
+            const int p = have ? ent.x : 0, y = have ? ent.w : 0, x = p - y * W;
             mystate = st16[(uint32_t)(y * SP + x)];
             const int top = (int)(((uint32_t)ent.y >> 16) & 255u), ml = ent.z & 255, mr = (ent.z >> 8) & 255;
-            box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, adc_imin(W - 1, x + mr) / IRV_TILE,
+            box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, have ? adc_imin(W - 1, x + mr) / IRV_TILE : -1,
                                 adc_imax(0, y - top) / IRV_TILE, y / IRV_TILE, want4);
         }
+        // The first round of a pass marks the unused slots of the first batch (older entries, whatever the BEGIN kernel did not
+        // overwrite) as the end of the list: from round 1 on the waves that hold nothing else skip the phase above.
+        if (round == 0 && b0 == 0 && i >= n && ent.x != IRV_LIST_END) list[(size_t)gw * 64 + lane].x = IRV_LIST_END;
         const bool dirty = i < n && (round == 0 || box) && !(mystate & IRV_FINAL); // final values are never re-evaluated
         IRV_T(2);
         // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
         // consumers find pool item t by a prefix sum over the (<= 16) counts
         const unsigned long long dm = __ballot(dirty);
         if (lane == 0) pcount[wave] = __popcll(dm);
-        if (dirty) pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)mystate, ent.w);
+        if (dirty) // {pixel, arms, state | read box << 16, row}
+            pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)((mystate & 0xFFFFu) | ((uint32_t)ent.z & 0xFFFF0000u)), ent.w);
         __syncthreads();
         const int cnt_l = lane < WPB ? pcount[lane] : 0;
         const int incl = irv_row_prefix(cnt_l); // inclusive prefix over the first 16 lanes
@@ -324,21 +338,30 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
             const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
             const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
-            const uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z); // (only this wave writes the entry in this round)
+            const uint32_t pz = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z);
+            const uint32_t cur = pz & 0xFFFFu; // (only this wave writes the entry in this round)
             const int x = p - y * W;
             for (int b = lane; b < D; b += 64) hist[b] = 0;
             bool deps_open = false;
             const int top = (int)(((uint32_t)armsp >> 16) & 255u), nrows = top + (int)((uint32_t)armsp >> 24) + 1; // region rows y-top .. y+bottom
             const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
+            // the read box: blocks blkL .. blkR cover the widest row of the region
+            const int blkL = (x - (int)((pz >> 16) & 255u)) >> 3, blkR = (x + (int)(pz >> 24)) >> 3;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int rbase = 0; rbase < nrows; rbase += 64) {
-                // the H arms of (up to 64) region rows in ONE round trip (lane r holds row rbase + r), handed to the row
-                // slots with a shuffle
+                // the H arms of (up to 64) region rows (lane r holds row rbase + r; handed to the row slots with a shuffle) AND
+                // the first 16 rows x 4 blocks of the read box in ONE memory round trip: the arms only decide which pixels of a
+                // block belong to the region (round 4; before, the blocks were requested when the arms had arrived)
                 const int myr = rbase + lane;
                 uint32_t a2 = 0;
                 if (myr < nrows) a2 = arms32[(uint32_t)((y - top + myr) * W + x)];
-                IRV_T(4);
                 const int rend = adc_imin(nrows - rbase, 64);
+                uint4 vfirst;
+                {
+                    const bool in0 = sub < rend && blkL + bslot <= blkR;
+                    vfirst = *reinterpret_cast<const uint4*>(st16 + (in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own));
+                }
+                IRV_T(4);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (int r0 = 0; r0 < rend; r0 += 16) {
                     const int r = r0 + sub;
@@ -348,11 +371,14 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                     const int xl = x - (int)(arm2 & 255u), xr = x + (int)((arm2 >> 8) & 255u);
                     const int b0x = xl >> 3, b1x = xr >> 3;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                    for (int bo = 0;; bo += 4) { // one iteration unless a row spans more than 4 blocks
-                        const int blk = b0x + bo + bslot;
-                        const bool use = rowok && blk <= b1x;
-                        const uint32_t addr = use ? (uint32_t)(yt * SP + blk * 8) : own;
-                        const uint4 v = *reinterpret_cast<const uint4*>(st16 + addr); // loads stay unconditional
+                    for (int bo = 0;; bo += 4) { // one iteration unless the read box spans more than 4 blocks
+                        const int blk = blkL + bo + bslot;
+                        const bool use = rowok && blk >= b0x && blk <= b1x;
+                        uint4 v = vfirst;
+                        if (r0 + bo != 0) { // (uniform) loads stay unconditional: masked-out lanes read the entry's own block
+                            const uint32_t addr = rowok && blk <= blkR ? (uint32_t)(yt * SP + blk * 8) : own;
+                            v = *reinterpret_cast<const uint4*>(st16 + addr);
+                        }
                         IRV_T(5);
                         // The 8 pixels of the block, decoded as packed halfwords (irv_plan.h: irv_decode_block): which pixels
                         // count, and do they all fall into ONE bin?
@@ -376,7 +402,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                                 atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
                             }
                         }
-                        if (!__any(rowok && (b0x + bo + 4 <= b1x))) break;
+                        if (!__any(rowok && (blkL + bo + 4 <= b1x))) break;
                     }
                 }
             }
@@ -451,7 +477,7 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count)
     for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(k_irv_u, dim3((unsigned)h->irv_grid), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
                            h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
-                           reinterpret_cast<const uchar4*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
+                           reinterpret_cast<const uint32_t*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
                            p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr);
     return hipGetLastError();
 }

@@ -90,7 +90,7 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
                 for (int gw : waves) {
                     int todo[64], nt = 0;
                     for (int lane = 0; lane < 64; lane++) {
-                        const long i = b0 + (long)(lane * WPB + gw % WPB) * G + gw / WPB;
+                        const long i = irv_list_index(b0, gw / WPB, gw % WPB, lane, G);
                         if (i >= n) continue;
                         const Ent& e = list[b0 + (size_t)gw * 64 + lane];
                         const int p = e.p, y = e.y, x = p - y * W;
