@@ -174,6 +174,35 @@ ADC_HD bool adc_so_chunk_interior(int i, int PF, int plen, int dir, bool vert, i
     return xlo >= dmin + Dp && xhi - dmin < W - 1;
 }
 
+// ---- scanline row passes cut into VERIFIED SEGMENTS (k_scanline.hip, round 4) ----
+// L = (C + min(...)) / 2 halves every perturbation per step, so a pass that starts in the middle of a path from the raw costs
+// (like the reference's first pixel) runs into the full pass's state bit for bit after a few dozen steps (measured: <= 42 on
+// the row passes, tools/so_merge_length.py).  A path of plen elements is therefore cut into nseg segments, one wave each.
+// Segment s > 0 owns the outputs [a, b) and starts at element e0 = a - warm - 1 as a FIRST element, runs `warm` steps whose
+// outputs go to its seam slot (the last one stays there: its state at element a - 1), then stores from a on.  Its seam slot is
+// compared bit for bit with what segment s - 1 stored at element a - 1 (k_so_seam_check): equal => every output of the
+// segment is the full pass's; different => the Match is redone without segments (adc_wait).
+// The kernel's prefetch groups need e0 % 4 == 0 (the d1 words hold path elements 1+4g .. 4+4g) and warm % 16 == 0 (the switch
+// from the seam slot to the volume happens between chunks of 16 steps): a = 1 (mod 4).  All segments take (nearly) the same
+// number of steps T = ceil((plen + (nseg - 1) * (warm + 1)) / nseg).
+#define ADC_SO_WARM 64
+#define ADC_SO_MAX_SEG 8
+ADC_HD int adc_so_seg_start(int plen, int nseg, int warm, int s)
+{
+    if (s <= 0) return 0;
+    if (s >= nseg) return plen;
+    const int T = (plen + (nseg - 1) * (warm + 1) + nseg - 1) / nseg;
+    return ((T + (s - 1) * (T - warm - 1)) & ~3) + 1;
+}
+// can a path of plen elements be cut into nseg segments?  (every segment keeps >= 2 chunks of real outputs behind its warm-up)
+ADC_HD bool adc_so_seg_ok(int plen, int nseg, int warm)
+{
+    if (nseg < 2 || nseg > ADC_SO_MAX_SEG || warm < 16 || (warm & 15)) return false;
+    for (int s = 1; s <= nseg; s++)
+        if (adc_so_seg_start(plen, nseg, warm, s) - adc_so_seg_start(plen, nseg, warm, s - 1) < 32 + (s == 1 ? warm + 1 : 0)) return false;
+    return true;
+}
+
 // ---- interpolation: empty-space skipping of the ray walk (k_refine.hip; CPU emulation: tests/emul/emul.cpp) ----
 // cdist[cell] = a LOWER BOUND of the Chebyshev distance, in cells of ADC_ITP_CELL x ADC_ITP_CELL pixels, from the cell to
 // the nearest cell that holds a valid pixel (0 = the cell itself; search window +-ADC_ITP_CAP cells, ADC_ITP_CAP + 1 =

@@ -53,6 +53,10 @@ struct adc_handle {
     float* agg_sink;           // 256 KiB scratch: store target of the halo steps of a pass pair (k_aggregate_rr.h)
     uint8_t *cdiff_lh, *cdiff_lv, *cdiff_rh, *cdiff_rv;
     uint8_t* so_cls; // path-ordered left-image colour-step words (d1) of the 4 scanline pass types (k_scanline.hip)
+    float* so_seam;  // seam slots of the row passes cut into verified segments: [2 passes][H][ADC_SO_MAX_SEG - 1][Dp] (k_scanline.hip)
+    int so_seg_off;  // > 0: row passes run whole (a seam failed: the redo and the next so_seg_off Matches of the handle)
+    int so_nseg_last; // segments per row of the last scanline run (1 = whole rows)
+    int so_seam_redos; // how often adc_wait had to redo a Match because a seam failed
     // volumes
     float *vol_a, *vol_b;
     // host-built tables: same libm as the CPU reference
@@ -148,6 +152,8 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations); // vol_a -> vol_
 hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream);
 size_t adc_so_cls_bytes(int W, int H);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
+int adc_so_segments(const adc_handle* h, int* warm_out);        // verified segments per row of the next scanline run
+size_t adc_so_seam_bytes(int W, int H, int Dp);
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_wta_left(adc_handle* h);                  // vol_a -> disp_l only (debug form of the left view)
 hipError_t adc_paper_aggregate(adc_handle* h, int iterations);  // k_paper.hip: aggregation limited by both images' arms

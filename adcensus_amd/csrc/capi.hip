@@ -106,6 +106,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->cdiff_rh, P + 64));
     HIP_OK(hipMalloc(&h->cdiff_rv, P + 64));
     HIP_OK(hipMalloc(&h->so_cls, adc_so_cls_bytes(p.W, p.H)));
+    if (p.VPL <= 2) HIP_OK(hipMalloc(&h->so_seam, adc_so_seam_bytes(p.W, p.H, p.Dp))); // (verified segments of the scanline row passes)
     HIP_OK(hipMalloc(&h->vol_a, VB));
     HIP_OK(hipMalloc(&h->vol_b, VB));
     HIP_OK(hipMalloc(&h->lut_ad, 768 * sizeof(float)));
@@ -270,7 +271,7 @@ void adc_destroy(adc_handle* h)
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
-                    h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
+                    h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->so_seam, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
                     h->chg_a, h->edge, h->arms_r, h->bgrx_r, h->armmax_r, h->vol_c};
     for (void* b : bufs) if (b) hipFree(b);
@@ -520,9 +521,11 @@ int adc_wait(adc_handle* h)
     // (1) the aggregation assumed the arm maxima of the previous Match; a longer arm raised the flag and the pass was
     //     skipped: redo the whole Match with the full ring (valid for every image).  The inputs are still in HBM.
     if (h->pin_flags) {
-        if (h->pin_flags[7] != 0) {
-            h->arm_redos++;
-            h->arm_known = 0;
+        // (1b) a row of the scanline passes was cut into segments and a segment's warm-up did not reach the state of the full
+        //     pass (pin_flags[6] = seams that failed): redo the Match with whole rows, and keep them for the next Matches
+        if (h->pin_flags[7] != 0 || h->pin_flags[6] != 0) {
+            if (h->pin_flags[7] != 0) { h->arm_redos++; h->arm_known = 0; }
+            if (h->pin_flags[6] != 0) { h->so_seam_redos++; h->so_seg_off = 64; }
             hipError_t e = run_pipeline(h);
             if (e == hipSuccess) e = enqueue_output(h);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -531,6 +534,7 @@ int adc_wait(adc_handle* h)
         h->armmax_host[0] = h->pin_flags[4];
         h->armmax_host[1] = h->pin_flags[5];
         h->arm_known = 1;
+        if (h->so_seg_off > 0 && h->pin_flags[6] == 0) h->so_seg_off--; // (whole rows for a while after a failed seam)
     }
     // (2) the voting chain ran out of its launch budget before it converged: continue it, redo the stages behind it
     int continued = 0;
@@ -865,6 +869,12 @@ int64_t adc_debug_counter(adc_handle* h, int which)
     case 1: return h->irv_overflows;
     case 2: return h->arm_redos;
     case 3: return h->irv_budget;
+    case 4: return h->so_seam_redos;
+    case 5: return h->so_nseg_last; // segments per row of the last scanline run
+    case 6: { // seams that failed in the last scanline run (debug surface: nothing redoes it there)
+        int v = -1;
+        return hipMemcpy(&v, h->armmax + 2, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess ? v : -1;
+    }
     default: return -1;
     }
 }

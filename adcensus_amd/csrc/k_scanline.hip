@@ -261,14 +261,17 @@ __device__ __forceinline__ void so_rmap_load_words(const uint8_t* __restrict__ r
 #define SO_RR(U) (SO_V0 + 32 + (U))
 #define SO_RW(G) (SO_V0 + 48 + (G))
 #define SO_CLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147"
-template <int VPL, bool VERT, bool DPP, bool WTA, bool PIN>
+// SEG (row passes, VPL <= 2): the path is cut into nseg verified segments (adc_device_fn.h: adc_so_seg_start), wave = (segment,
+// path); `seam` = this pass's seam slots [path][nseg - 1][Dp].
+template <int VPL, bool VERT, bool DPP, bool WTA, bool PIN, bool SEG = false>
 __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __restrict__ dst,
                                         const uint32_t* __restrict__ c1w, int ngr,
                                         const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso,
                                         int dir, float P1a, float P1b, float P1c, float P2a, float P2b, float P2c,
-                                        float* __restrict__ disp, int allow_fast)
+                                        float* __restrict__ disp, int allow_fast, int nseg = 1, int warm = 0, float* __restrict__ seam = nullptr)
 {
     static_assert(!WTA || DPP, "the fused winner-takes-all relies on the uniform (SGPR) path minimum of the DPP reduction");
+    static_assert(!SEG || (!WTA && !VERT && VPL <= 2), "verified segments: row passes of the asm-prefetch kernels");
     constexpr int Dp = 64 * VPL;
     // (P1,P2) by penalty class, 8-byte entries addressed with class*8 (selecting them with v_cndmask instead was
     // measured: no faster)
@@ -284,8 +287,24 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
     SoGeom g;
     g.W = W; g.H = H; g.dir = dir; g.lane = lane;
     g.path = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (int)(blockDim.x >> 6) + wave);
+    int seg = 0;
+    if constexpr (SEG) { // waves 0 .. npaths-1 run segment 0, the next npaths segment 1, ...
+        seg = g.path / npaths;
+        g.path -= seg * npaths;
+        if (seg >= nseg) return;
+    }
     if (g.path >= npaths) return;
     g.plen = VERT ? H : W;
+    // the elements this wave visits: [e0, e1); a segment behind the first starts warm + 1 elements before its first output
+    int e0 = 0, e1 = g.plen, efirst = 0;
+    if constexpr (SEG) {
+        e1 = adc_so_seg_start(g.plen, nseg, warm, seg + 1);
+        if (seg > 0) {
+            efirst = adc_so_seg_start(g.plen, nseg, warm, seg);
+            e0 = efirst - warm - 1;
+        }
+    }
+    const int plen_v = e1 - e0; // path length as this wave sees it
     g.d0 = lane * VPL; // first disparity index of this lane
     const uint32_t* c1p = c1w + (size_t)g.path * ngr; // this path's d1 words (uniform)
     const int cl_last = g.d0 + VPL - 1 + dmin;         // xr of the lane's last disparity = x - cl_last
@@ -293,10 +312,10 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
     float Lp[VPL]; // previous path element's costs; padding lanes (d >= D) hold the sentinel
     float minLp;
     {
-        const size_t pix = so_pixel<VERT>(g, 0);
+        const size_t pix = so_pixel<VERT>(g, e0);
         float c[VPL];
         vload<VPL>(src + pix * Dp + g.d0, c);
-        vstore<VPL>(dst + pix * Dp + g.d0, c); // first pixel: dst = src (scanline_optimizer.cpp:99,208)
+        if (!SEG || seg == 0) vstore<VPL>(dst + pix * Dp + g.d0, c); // first pixel: dst = src (scanline_optimizer.cpp:99,208)
         float lmin = ADC_LARGE_FLOAT; // sentinels take part in the first minimum (scanline_optimizer.cpp:107-110)
 #pragma unroll
         for (int k = 0; k < VPL; k++) {
@@ -356,9 +375,9 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         }                                                                                                  \
     }
     SO_WTA(0);
-    if (g.plen <= 1) return;
+    if (plen_v <= 1) return;
 
-    int mcur = dir > 0 ? 1 : g.plen - 2; // coordinate of path element 1, advanced by every SO_STEP
+    int mcur = dir > 0 ? e0 + 1 : g.plen - 2 - e0; // coordinate of path element e0 + 1, advanced by every SO_STEP
     const int dpad = (D + VPL - 1) / VPL * VPL;
 // one DP step for path element I with inputs E (a macro keeps every array in registers)
 #define SO_STEP(I, E)                                                                                      \
@@ -405,7 +424,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
 #define SO_STORE(I, OUT)              \
     do {                              \
         vstore<VPL>(dpn, OUT);        \
-        dpn += fstep;                 \
+        dpn += dstep;                 \
     } while (0)
 // The same step for a chunk of the path that is interior as a whole (see the steady-state loop below): interior class
 // rule without its per-step test, no padding lanes (D == 64 * VPL), the four-way minimum as v_min3 + v_min without the
@@ -468,13 +487,22 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         uint32_t pfw[PIN ? 1 : NG];
         const long long pstep = (long long)(VERT ? W : 1) * dir; // pixels per path step
         const long long fstep = pstep * Dp;
-        const size_t px1 = so_pixel<VERT>(g, 1);
+        const size_t px1 = so_pixel<VERT>(g, e0 + 1);
         const float* spn = src + px1 * Dp + g.d0; // next element to prefetch
-        const uint32_t* cwn = c1p;                 // next d1 word to prefetch
+        const uint32_t* cwn = c1p + (e0 >> 2);     // next d1 word to prefetch (e0 is a multiple of 4)
         float* dpn = dst + px1 * Dp + g.d0;        // next element to store
-        const int last = g.plen - 1;
-        int ii = 1, gi = 0; // element / group the prefetch stands on
-        int mpf = dir > 0 ? 1 : g.plen - 2; // coordinate of element ii
+        long long dstep = fstep;                   // ... and how far the store pointer moves per step
+        if constexpr (SEG) {
+            // warm-up steps store to the segment's seam slot (every step keeps its store: the wait counts below assume it);
+            // the last of them leaves the state at element efirst - 1 there
+            if (seg > 0) {
+                dpn = seam + ((size_t)g.path * (nseg - 1) + (seg - 1)) * Dp + g.d0;
+                dstep = 0;
+            }
+        }
+        const int last = e1 - 1;
+        int ii = e0 + 1, gi = e0 >> 2; // element / group the prefetch stands on
+        int mpf = mcur; // coordinate of element ii
 #define SO_ISSUE_D(U)                                                                                          \
     do {                                                                                                       \
         const int ro_ = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last);                                          \
@@ -595,7 +623,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
     SO_PIPE(4 * (G) + 3, 37 + 4 * (G))
 #define SO_STEADY4(G) SO_PIPE(4 * (G), 49); SO_PIPE(4 * (G) + 1, 50); SO_PIPE(4 * (G) + 2, 50); SO_PIPE(4 * (G) + 3, 50)
 #define SO_LAST(U)                                                                                             \
-    if (i + (U) < g.plen) {                                                                                    \
+    if (i + (U) < plen_v) {                                                                                    \
         SoElem<VPL> cur_;                                                                                      \
         SO_TAKE(U, 33 - 9 * ((U) >> 2) - 2 * ((U)&3), cur_);                                                   \
         SO_STEP(i + (U), cur_);                                                                                \
@@ -612,8 +640,18 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
             SO_ISSUE_D(4 * G + 2);
             SO_ISSUE_D(4 * G + 3);
         }
-        int i = 1;
-        if (i + PF <= g.plen) {
+        int i = 1; // (relative to e0)
+// a segment's warm-up ends between two chunks: from element efirst on the outputs go to the volume
+#define SO_SEG_SWITCH()                                                                                        \
+    do {                                                                                                       \
+        if constexpr (SEG) {                                                                                   \
+            if (seg > 0 && i == warm + 1) {                                                                    \
+                dpn = dst + so_pixel<VERT>(g, efirst) * Dp + g.d0;                                             \
+                dstep = fstep;                                                                                 \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+        if (i + PF <= plen_v) {
             SO_FIRST4(0); SO_FIRST4(1); SO_FIRST4(2); SO_FIRST4(3);
             i += PF;
             // Steady state.  A chunk of PF steps takes the short form when it is interior as a whole: no padding lanes,
@@ -623,11 +661,13 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
             // the general form, so the two can alternate under the same wait counts; at 1080p 109 of the 120 chunks of a
             // row qualify.  The general form keeps its per-step tests and clamps for the rest.
             const int rstep = (VERT ? W : 1) * dir;
-            for (; i + PF <= g.plen; i += PF) {
+            for (; i + PF <= plen_v; i += PF) {
+                SO_SEG_SWITCH();
                 if constexpr (PIN) { // (two forms of the loop body need the pinned slots, see SO_V0)
-                    bool fast = SO_INTERIOR && SO_FAST && allow_fast && D == Dp && W >= 3 && i + 2 * PF + 4 <= g.plen;
+                    // (adc_device_fn.h restates this predicate for the CPU checks, with e0 = 0: adc_so_chunk_interior)
+                    bool fast = SO_INTERIOR && SO_FAST && allow_fast && D == Dp && W >= 3 && i + 2 * PF + 4 <= plen_v;
                     if (fast) {
-                        const int ea = i, eb = i + 2 * PF - 1; // path elements the chunk steps on or prefetches
+                        const int ea = e0 + i, eb = e0 + i + 2 * PF - 1; // path elements the chunk steps on or prefetches
                         const int ma = dir > 0 ? ea : g.plen - 1 - ea, mb = dir > 0 ? eb : g.plen - 1 - eb;
                         const int xlo = VERT ? g.path : (ma < mb ? ma : mb), xhi = VERT ? g.path : (ma < mb ? mb : ma);
                         fast = xlo >= dmin + Dp && xhi - dmin < W - 1;
@@ -647,7 +687,9 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
             }
         }
         // final chunk: fewer than PF elements left, all of them in flight
+        SO_SEG_SWITCH();
         SO_LAST4(0) SO_LAST4(1) SO_LAST4(2) SO_LAST4(3)
+#undef SO_SEG_SWITCH
         // Slots past the end of the path were loaded (clamped) but never taken.  PIN: harmless, their registers are
         // reserved.  !PIN: keep their destination registers alive until those loads have landed, or the compiler may reuse
         // them for the values of the steps above and a late-landing load overwrites them.
@@ -735,6 +777,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SO_V0))) void k
     static_assert(VPL <= 2, "wider lanes use k_scanline_wide");
     so_body<VPL, VERT, DPP, WTA, true>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, disp, allow_fast);
 }
+// Row passes cut into verified segments (round 4): the same two families, wave = (segment, row)
+template <int VPL, bool DPP>
+__global__ __launch_bounds__(256) void k_scanline_seg(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
+    const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
+    float P2a, float P2b, float P2c, int nseg, int warm, float* __restrict__ seam)
+{
+    static_assert(VPL <= 2, "asm-prefetch kernels only");
+    so_body<VPL, false, DPP, false, false, true>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, nullptr, 0,
+                                                 nseg, warm, seam);
+}
+template <int VPL, bool DPP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SO_V0))) void k_scanline_pin_seg(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
+    const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
+    float P2a, float P2b, float P2c, int allow_fast, int nseg, int warm, float* __restrict__ seam)
+{
+    static_assert(VPL <= 2, "asm-prefetch kernels only");
+    so_body<VPL, false, DPP, false, true, true>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, nullptr,
+                                                allow_fast, nseg, warm, seam);
+}
+// Seam check of the two row passes of a Match (both outputs are still intact behind the second pass: L->R wrote dst0, R->L
+// wrote dst1): one wave per (pass, row, seam); the segment's state at its last warm-up element must equal what its predecessor
+// stored there, bit for bit, in every disparity of the range.  A difference is counted; adc_wait then redoes the Match
+// without segments.
+__global__ __launch_bounds__(256) void k_so_seam_check(const float* __restrict__ dst0, const float* __restrict__ dst1,
+                                                       const float* __restrict__ seam, int W, int H, int Dp, int D, int nseg, int warm,
+                                                       int* __restrict__ fails)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), per_pass = H * (nseg - 1);
+    if (gw >= 2 * per_pass) return;
+    const int pass = gw / per_pass, r = gw - pass * per_pass, path = r / (nseg - 1), s = 1 + r % (nseg - 1);
+    const int e = adc_so_seg_start(W, nseg, warm, s) - 1; // last warm-up element of segment s = last output of segment s - 1
+    const int x = pass == 0 ? e : W - 1 - e;
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(pass == 0 ? dst0 : dst1) + ((size_t)path * W + x) * Dp;
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(seam) + ((size_t)pass * per_pass + r) * Dp;
+    bool bad = false;
+    for (int d = lane; d < D; d += 64) bad |= a[d] != b[d];
+    if (__ballot(bad) != 0ull && lane == 0) atomicAdd(fails, 1);
+}
 // VPL >= 4: compiler-scheduled prefetch, no reserved registers
 template <int VPL, bool VERT, bool DPP, bool WTA>
 __global__ __launch_bounds__(256) void k_scanline_wide(
@@ -752,8 +835,25 @@ static bool so_use_dpp()
     return v;
 }
 
+// Number of verified segments a row pass of this handle is cut into (1 = whole rows).  Automatic choice: enough chains for
+// two waves on every SIMD of the chip (1080 rows -> 2 x 1080, 375 rows -> 5 x 375); ADC_SO_SEG = 0 / 1 switches the segments
+// off, N >= 2 forces N; ADC_SO_WARM = warm-up steps (multiple of 16; the tests use short ones to provoke seam failures).
+int adc_so_segments(const adc_handle* h, int* warm_out)
+{
+    static const int seg_env = [] { const char* e = getenv("ADC_SO_SEG"); return e ? atoi(e) : -1; }();
+    static const int warm_env = [] { const char* e = getenv("ADC_SO_WARM"); return e ? atoi(e) : ADC_SO_WARM; }();
+    const AdcParams& p = h->p;
+    if (warm_out) *warm_out = warm_env;
+    if (p.VPL > 2 || h->so_seg_off || !h->so_seam || seg_env == 0 || seg_env == 1) return 1;
+    int n = seg_env >= 2 ? seg_env : (2048 + p.H / 2) / p.H;
+    if (n > ADC_SO_MAX_SEG) n = ADC_SO_MAX_SEG;
+    while (n >= 2 && !adc_so_seg_ok(p.W, n, warm_env)) n--;
+    return n >= 2 ? n : 1;
+}
+size_t adc_so_seam_bytes(int W, int H, int Dp) { (void)W; return (size_t)2 * H * (ADC_SO_MAX_SEG - 1) * Dp * sizeof(float); }
+
 template <int VPL>
-static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool vert, int dir, float* disp = nullptr)
+static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool vert, int dir, float* disp = nullptr, int nseg = 1, int warm = 0)
 {
     const AdcParams& p = h->p;
     const int npaths = vert ? p.W : p.H;
@@ -764,7 +864,7 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
     static const int wpb_row = [] { const char* e = getenv("ADC_SO_WPB_ROW"); const int v = e ? atoi(e) : 1; return v == 1 || v == 2 ? v : 4; }();
     static const int wpb_col = [] { const char* e = getenv("ADC_SO_WPB_COL"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
     const int wpb = vert ? wpb_col : wpb_row;
-    const unsigned blocks = (unsigned)((npaths + wpb - 1) / wpb);
+    const unsigned blocks = (unsigned)((npaths * nseg + wpb - 1) / wpb);
     const int pass = (vert ? 2 : 0) + (dir > 0 ? 0 : 1);
     const SoC1Layout L = so_c1_layout(p.W, p.H);
     const uint32_t* c1w = reinterpret_cast<const uint32_t*>(h->so_cls) + L.off[pass];
@@ -787,7 +887,21 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
     // every SIMD has a wave or two the pass is bound by its memory streams and runs k_scanline.  ADC_SO_FAST=0 / 1 forces
     // k_scanline / k_scanline_pin everywhere.
     static const int so_fast_env = [] { const char* e = getenv("ADC_SO_FAST"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-    const bool so_pin = so_fast_env >= 0 ? so_fast_env != 0 : npaths < 1024;
+    const bool so_pin = so_fast_env >= 0 ? so_fast_env != 0 : npaths * nseg < 1024;
+    if constexpr (VPL <= 2) {
+        if (nseg > 1 && !vert && dpp) { // verified segments: wave = (segment, row); seam slots of this pass
+            float* seam = h->so_seam + (size_t)pass * p.H * (nseg - 1) * p.Dp;
+            if (so_pin)
+                hipLaunchKernelGGL((k_scanline_pin_seg<VPL, true>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, L.ngr[pass], rmap,
+                                   p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1],
+                                   h->so_P2[2], 1, nseg, warm, seam);
+            else
+                hipLaunchKernelGGL((k_scanline_seg<VPL, true>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, L.ngr[pass], rmap, p.W,
+                                   p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1],
+                                   h->so_P2[2], nseg, warm, seam);
+            return hipGetLastError();
+        }
+    }
     if (vert) {
         if (dpp && disp) SO_LAUNCH(true, true, true);
         else if (dpp) SO_LAUNCH(true, true, false);
@@ -821,8 +935,20 @@ static hipError_t run_so(adc_handle* h, int passes)
         }
         return e;
     }
-    if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1);
-    if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1);
+    // Row passes as verified segments (needs both passes: the seam check runs once, behind the second one, while both outputs
+    // are intact).  h->armmax[2] counts the seams that failed; adc_wait looks at it.
+    int warm = 0;
+    const int nseg = (passes >= 2 && so_use_dpp()) ? adc_so_segments(h, &warm) : 1;
+    h->so_nseg_last = nseg;
+    if (e == hipSuccess && nseg > 1) e = hipMemsetAsync(h->armmax + 2, 0, sizeof(int), h->heavy);
+    if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1, nullptr, nseg, warm);
+    if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1, nullptr, nseg, warm);
+    if (e == hipSuccess && nseg > 1) {
+        const int waves = 2 * h->p.H * (nseg - 1);
+        hipLaunchKernelGGL(k_so_seam_check, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, h->heavy, h->vol_b, h->vol_a, h->so_seam, h->p.W,
+                           h->p.H, h->p.Dp, h->p.D, nseg, warm, h->armmax + 2);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess && passes >= 3) e = launch_so<VPL>(h, h->vol_a, h->vol_b, true, +1);
     if (e == hipSuccess && passes >= 4) {
         // production pipeline: the left-view winner-takes-all rides on the last pass (capi.hip sets fuse_wta)

@@ -469,6 +469,91 @@ long emul_scanline_pass_segments(const float* src, float* dst, const uint8_t* cd
     return failed;
 }
 
+// The same pass in the form the kernel runs it: segment bounds from adc_so_seg_start, warm + 1 elements of overlap, the seam
+// check behind the pass; a failed seam is only COUNTED (the product then redoes the Match with whole rows).
+int emul_so_seg_ok(int plen, int nseg, int warm) { return adc_so_seg_ok(plen, nseg, warm) ? 1 : 0; }
+int emul_so_seg_start(int plen, int nseg, int warm, int s) { return adc_so_seg_start(plen, nseg, warm, s); }
+long emul_scanline_pass_kernel_segments(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H, int dmin,
+                                 int D, int vert, int dir, int tso, float p1, float p2, int nseg, int warm)
+{
+    const float P1c[3] = {p1, p1 / 4, p1 / 10}, P2c[3] = {p2, p2 / 4, p2 / 10};
+    const int npaths = vert ? W : H, plen = vert ? H : W;
+    std::vector<float> Lp(D), out(D);
+    long failed = 0;
+    std::vector<std::vector<float>> slots;
+    std::vector<size_t> slot_pix;
+    for (int path = 0; path < npaths; path++) {
+        auto coord = [&](int i, int& x, int& y) {
+            const int m = dir > 0 ? i : plen - 1 - i;
+            if (vert) { x = path; y = m; } else { x = m; y = path; }
+        };
+        auto start = [&](int i, float& minLp, bool store) { // element i as a first element
+            int x, y;
+            coord(i, x, y);
+            minLp = ADC_LARGE_FLOAT;
+            for (int d = 0; d < D; d++) {
+                const float c = src[((size_t)y * W + x) * D + d];
+                if (store) dst[((size_t)y * W + x) * D + d] = c;
+                Lp[d] = c;
+                minLp = c < minLp ? c : minLp;
+            }
+        };
+        auto step = [&](int i, float& minLp, bool store) {
+            int x, y;
+            coord(i, x, y);
+            const int sx = vert ? x : (dir > 0 ? x : x + 1);
+            const int sy = vert ? (dir > 0 ? y : y + 1) : y;
+            const int d1 = cd_left[(size_t)sy * W + sx];
+            const uint8_t* row = cd_right + (size_t)sy * W;
+            const int shift = vert ? 0 : (dir > 0 ? 0 : 1);
+            float omin = ADC_LARGE_FLOAT;
+            for (int d = 0; d < D; d++) {
+                const int col = adc_so_d2_column(x, dmin, d, W);
+                const int d2 = col >= 0 ? (int)row[col + shift] : d1;
+                const int cls = adc_so_penalty_class(d1, d2, tso);
+                const float P1 = P1c[cls], P2 = P2c[cls];
+                const float lm1 = d > 0 ? Lp[d - 1] : ADC_LARGE_FLOAT;
+                const float lp1 = d < D - 1 ? Lp[d + 1] : ADC_LARGE_FLOAT;
+                const float l1 = Lp[d], l2 = lm1 + P1, l3 = lp1 + P1, l4 = minLp + P2;
+                const float m12 = l2 < l1 ? l2 : l1, m34 = l4 < l3 ? l4 : l3;
+                const float mm = m34 < m12 ? m34 : m12;
+                float cs = src[((size_t)y * W + x) * D + d] + mm;
+                cs = cs / 2;
+                out[d] = cs;
+                omin = cs < omin ? cs : omin;
+            }
+            for (int d = 0; d < D; d++) { if (store) dst[((size_t)y * W + x) * D + d] = out[d]; Lp[d] = out[d]; }
+            minLp = omin;
+        };
+        // the kernel's form (k_scanline.hip, SEG): segment s visits the elements [e0, e1) with e0 = a - warm - 1 for s > 0, the
+        // first of them as a FIRST element; steps 1 .. warm (relative to e0) store to the seam slot, the later ones to the volume;
+        // k_so_seam_check compares the slot with the predecessor's output at element a - 1 (only d < D)
+        std::vector<float> slot(D);
+        for (int k = 0; k < nseg; k++) {
+            const int a = adc_so_seg_start(plen, nseg, warm, k), e1 = adc_so_seg_start(plen, nseg, warm, k + 1);
+            const int e0 = k == 0 ? 0 : a - warm - 1;
+            if (e0 < 0 || (e0 & 3) || e1 - e0 < 2) return -1;
+            float minLp;
+            start(e0, minLp, k == 0);
+            for (int i = e0 + 1; i < e1; i++) {
+                const bool real = k == 0 || i - e0 > warm;
+                step(i, minLp, real);
+                if (!real) slot = Lp; // (the warm-up steps overwrite the slot; the last one stays)
+            }
+            if (k > 0) {
+                int x, y;
+                coord(a - 1, x, y);
+                slots.push_back(slot);
+                slot_pix.push_back((size_t)y * W + x);
+            }
+        }
+    }
+    // the seam check runs behind the pass (all segments of a pass run concurrently)
+    for (size_t q = 0; q < slots.size(); q++)
+        if (memcmp(slots[q].data(), dst + slot_pix[q] * D, D * sizeof(float))) failed++;
+    return failed;
+}
+
 // ------------------------------------------------------------------ k_scanline, lane structure of the penalty classes
 // Same DP, but the (P1,P2) class of every disparity is derived the way the kernel does it: lane l owns VPL consecutive
 // disparities, fetches VPL consecutive bytes of the right-image step map at column max(xr_last, 1) (+1 on R->L) and

@@ -38,14 +38,16 @@ def _check(path, want):
 
 
 def test_scanline_prefetch_slots(device_asm):
-    res, seen = _check(device_asm("k_scanline"), ["k_scanlineILi1E", "k_scanlineILi2E", "k_scanline_pinILi1E", "k_scanline_pinILi2E"])
-    assert all(v == 5 for v in seen.values()), seen  # every asm-prefetch instantiation of both kernel families was analysed
+    res, seen = _check(device_asm("k_scanline"), ["k_scanlineILi1E", "k_scanlineILi2E", "k_scanline_pinILi1E", "k_scanline_pinILi2E",
+                                                  "k_scanline_segILi1E", "k_scanline_segILi2E", "k_scanline_pin_segILi1E", "k_scanline_pin_segILi2E"])
+    # every asm-prefetch instantiation of both kernel families was analysed (+ the row passes cut into verified segments)
+    assert all(v == (1 if "_seg" in k else 5) for k, v in seen.items()), seen
     assert all(r["asm_loads"] >= 100 for r in res.values())  # prologue + first block + both steady-state forms, 16 slots + d1 words
     # k_scanline_pin: the slots are registers the compiler cannot allocate (amdgpu_num_vgpr(96) + named registers v96..v147): every
     # instruction outside the asm statements stays below v96, nothing is spilled, and the descriptor reserves 148 registers
     text = open(device_asm("k_scanline")).read()
     for name, body in cal.functions(text):
-        if not re.search(r"k_scanline_pinILi[12]E", name):
+        if not re.search(r"k_scanline_pin(_seg)?ILi[12]E", name):
             continue
         in_asm, worst = False, -1
         for line in body:

@@ -273,6 +273,73 @@ def test_scanline_verified_segments(emul, dumps, name):
             assert failed > 0
 
 
+@pytest.mark.parametrize("name", ["cone_crop_d40", "s2_150x100_neg", "s2_150x100_pos", "s2_320x180_d128", "noise_160x90_d128_pos"])
+def test_scanline_kernel_segments(emul, dumps, name):
+    """The row passes in the form k_scanline_seg runs them (round 4): segment bounds from adc_so_seg_start (first outputs = 1 mod 4,
+    warm + 1 elements of overlap, equal step counts), warm-up outputs in the seam slot, seam check behind the pass.  With the
+    production warm-up (64) no seam fails and the two row passes equal whole-row passes bit for bit; with a 16-step warm-up seams
+    fail on the larger cases -- which is all the product needs to know (it redoes the Match with whole rows)."""
+    left, right, opt, o = dumps(name)
+    h, w = left.shape[:2]
+    D, dmin = opt.max_disparity - opt.min_disparity, opt.min_disparity
+    lh, lv, rh, rv = (np.zeros((h, w), np.uint8) for _ in range(4))
+    emul.emul_color_diffs(P(left), P(lh), P(lv), w, h)
+    emul.emul_color_diffs(P(right), P(rh), P(rv), w, h)
+    emul.emul_scanline_pass_kernel_segments.restype = C.c_long
+    emul.emul_scanline_pass_segments.restype = C.c_long
+    emul.emul_so_seg_ok.restype = C.c_int
+    # whole-row passes (nseg = 1 of the older model = the plain chained passes)
+    ref_a, ref_b = o["cost_aggr"].copy(), np.empty_like(o["cost_aggr"])
+    for dr in (1, -1):
+        emul.emul_scanline_pass_segments(P(ref_a), P(ref_b), P(lh), P(rh), w, h, dmin, D, 0, dr, opt.so_tso, C.c_float(opt.so_p1),
+                                         C.c_float(opt.so_p2), 1, 64)
+        ref_a, ref_b = ref_b, ref_a
+    ran = 0
+    for nseg, warm in ((2, 64), (3, 64), (5, 64), (2, 16), (4, 16)):
+        if not emul.emul_so_seg_ok(w, nseg, warm):
+            continue
+        ran += 1
+        a, b = o["cost_aggr"].copy(), np.empty_like(o["cost_aggr"])
+        failed = 0
+        for dr in (1, -1):
+            r = emul.emul_scanline_pass_kernel_segments(P(a), P(b), P(lh), P(rh), w, h, dmin, D, 0, dr, opt.so_tso, C.c_float(opt.so_p1),
+                                                        C.c_float(opt.so_p2), nseg, warm)
+            assert r >= 0, (nseg, warm, r)
+            failed += r
+            a, b = b, a
+        if warm == 64:
+            assert failed == 0, (nseg, warm, failed)
+        if failed == 0:
+            assert same(a, ref_a), (nseg, warm)
+    assert ran >= 1
+
+
+def test_scanline_segment_bounds(emul):
+    """adc_so_seg_start / adc_so_seg_ok: first outputs = 1 (mod 4) (the kernel's d1 word groups), strictly increasing, the
+    warm-up fits in front of every later segment, every segment keeps two chunks of outputs, step counts within 8 of each other."""
+    emul.emul_so_seg_ok.restype = C.c_int
+    emul.emul_so_seg_start.restype = C.c_int
+    checked = 0
+    for plen in list(range(40, 700, 7)) + [1242, 1920, 2048, 3840]:
+        for warm in (16, 64):
+            for nseg in range(2, 9):
+                if not emul.emul_so_seg_ok(plen, nseg, warm):
+                    continue
+                checked += 1
+                st = [emul.emul_so_seg_start(plen, nseg, warm, s) for s in range(nseg + 1)]
+                assert st[0] == 0 and st[-1] == plen
+                steps = []
+                for s in range(nseg):
+                    a, b = st[s], st[s + 1]
+                    assert b - a >= 32
+                    if s > 0:
+                        assert a % 4 == 1 and a - warm - 1 >= 0 and (a - warm - 1) % 4 == 0
+                    steps.append(b - (a - warm - 1 if s else 0))
+                assert max(steps[:-1] + [steps[-1]]) - min(steps[:-1]) <= 8 or nseg == 2, (plen, nseg, warm, steps)
+    assert checked > 500
+    assert emul.emul_so_seg_ok(1920, 2, 64) and emul.emul_so_seg_ok(1242, 5, 64) and not emul.emul_so_seg_ok(1920, 2, 40)
+
+
 def test_scanline_chunk_predicate_implies_no_clamp_and_interior_rule(emul):
     """Exhaustive over small geometries: whenever adc_so_chunk_interior accepts a chunk, (i) every element it steps on is
     interior in the sense of the per-step test, (ii) the clamped rmap offset of every element it prefetches is affine in the
@@ -281,7 +348,7 @@ def test_scanline_chunk_predicate_implies_no_clamp_and_interior_rule(emul):
     bad = emul.emul_so_chunk_predicate_check()
     assert bad == 0, bad
     src = open(os.path.join(ROOT, "adcensus_amd", "csrc", "k_scanline.hip")).read()
-    for expr in ("xlo >= dmin + Dp && xhi - dmin < W - 1", "i + 2 * PF + 4 <= g.plen",
+    for expr in ("xlo >= dmin + Dp && xhi - dmin < W - 1", "i + 2 * PF + 4 <= plen_v", "const int ea = e0 + i, eb = e0 + i + 2 * PF - 1;",
                  "return sy * g.W + (xr > 1 ? xr : 1) + ((!VERT && g.dir < 0) ? 1 : 0);", "xr = xr > g.W - 1 ? g.W - 1 : xr;"):
         assert expr in src, "k_scanline.hip no longer contains `%s`: update adc_device_fn.h's restatement with it" % expr
 
