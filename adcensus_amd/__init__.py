@@ -111,6 +111,9 @@ def lib():
     L.adc_memcpy_d2h.restype = C.c_int
     L.adc_device_copy_ms.argtypes = [vp, vp, C.c_size_t, C.c_int]
     L.adc_device_copy_ms.restype = C.c_double
+    if hasattr(L, "adc_device_copy_kernel_ms"):  # (absent from A/B builds of older revisions, ADC_HIP_LIB)
+        L.adc_device_copy_kernel_ms.argtypes = [vp, vp, C.c_size_t, C.c_int]
+        L.adc_device_copy_kernel_ms.restype = C.c_double
     L.adc_debug_read.argtypes = [vp, C.c_int, vp]
     L.adc_debug_read.restype = C.c_int
     L.adc_debug_write.argtypes = [vp, C.c_int, vp]

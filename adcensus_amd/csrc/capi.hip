@@ -44,6 +44,27 @@ static void set_error(const char* what, hipError_t e)
         }                                     \
     } while (0)
 
+// The guide's yardstick (MI355X_MICROARCH.md: "float4 copy"): a grid-stride copy kernel, 16 bytes per lane, four loads in
+// flight per lane; best time over a few grid sizes and plain / non-temporal accesses (tools/ubench/copy_ceiling.hip sweeps more
+// shapes on the same box: profiles/r4_ubench_copy_ceiling.txt).  bench.py reports the better of this and hipMemcpyAsync.
+typedef float adc_vf4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy_yardstick(const adc_vf4* __restrict__ src, adc_vf4* __restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        adc_vf4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = NT ? __builtin_nontemporal_load(&src[i + u * stride]) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (NT) __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
 extern "C" {
 
 void adc_option_default(adc_option* o)
@@ -740,6 +761,29 @@ double adc_device_copy_ms(void* dst, const void* src, size_t bytes, int reps)
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     return best;
+}
+double adc_device_copy_kernel_ms(void* dst, const void* src, size_t bytes, int reps)
+{
+    hipEvent_t e0, e1;
+    if ((bytes & 15) || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+    double best = -1.0;
+    const size_t n = bytes / 16;
+    for (int variant = 0; variant < 6 && best > -2.0; variant++) {
+        const unsigned grid = variant < 2 ? 8192u : (variant < 4 ? 32768u : 65536u);
+        for (int r = 0; r < (reps < 1 ? 1 : reps) + 1; r++) { // first copy = warm-up
+            hipEventRecord(e0, 0);
+            if (variant & 1) hipLaunchKernelGGL((k_copy_yardstick<true>), dim3(grid), dim3(256), 0, 0, (const adc_vf4*)src, (adc_vf4*)dst, n);
+            else hipLaunchKernelGGL((k_copy_yardstick<false>), dim3(grid), dim3(256), 0, 0, (const adc_vf4*)src, (adc_vf4*)dst, n);
+            hipEventRecord(e1, 0);
+            if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { best = -3.0; break; }
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (r > 0 && (best < 0 || ms < best)) best = ms;
+        }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return best < 0 ? -1.0 : best;
 }
 int adc_memcpy_h2d(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1; }
 int adc_memcpy_d2h(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1; }

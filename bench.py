@@ -194,20 +194,25 @@ def make_pair(workload, W, H, D, pid):
 
 
 def device_copy_rate(lib, nbytes):
-    """Device-to-device copy of one volume (read nbytes + write nbytes), GB/s, or None."""
+    """Device-to-device copy of one volume (read nbytes + write nbytes), GB/s, or None: (best, hipMemcpyAsync, copy kernel).
+    The kernel is the hardware guide's yardstick shape (float4 grid-stride copy, best of a few grids, plain / non-temporal)."""
     try:
         ca, cb = lib.adc_device_malloc(nbytes), lib.adc_device_malloc(nbytes)
-        rate = None
+        rates = [None, None]
         if ca and cb:
-            t = lib.adc_device_copy_ms(cb, ca, nbytes, 5)
-            if t > 0:
-                rate = round(2.0 * nbytes / (t * 1e-3) / 1e9, 1)
+            for k, name in enumerate(("adc_device_copy_ms", "adc_device_copy_kernel_ms")):
+                if not hasattr(lib, name):
+                    continue
+                t = getattr(lib, name)(cb, ca, nbytes, 5)
+                if t > 0:
+                    rates[k] = round(2.0 * nbytes / (t * 1e-3) / 1e9, 1)
         for q in (ca, cb):
             if q:
                 lib.adc_device_free(q)
-        return rate
+        have = [r for r in rates if r]
+        return (max(have) if have else None, rates[0], rates[1])
     except Exception:
-        return None
+        return (None, None, None)
 
 
 def k4_roofline(prof, W, H, D, lib, workload, kernel=None, in_flight=1):
@@ -225,7 +230,7 @@ def k4_roofline(prof, W, H, D, lib, workload, kernel=None, in_flight=1):
     alg_per_launch, hbm_per_launch = alg_total / launches, hbm_total / launches
     alg = alg_per_launch / (ms * 1e-3) / 1e9
     hbm = hbm_per_launch / (ms * 1e-3) / 1e9
-    copy_gbps = device_copy_rate(lib, int(V))
+    copy_gbps, copy_memcpy, copy_kernel = device_copy_rate(lib, int(V))
     pairs = passes > launches
     if not kernel:
         kernel = "pass-pair launches" if pairs else "one pass per launch"
@@ -240,6 +245,7 @@ def k4_roofline(prof, W, H, D, lib, workload, kernel=None, in_flight=1):
             "algorithmic_frac": round(alg / 8000.0, 4),
             "traffic_over_bytes": round(traffic / hbm_per_launch, 4) if traffic else None,
             "device_copy_GBps": copy_gbps, "frac_of_device_copy": round(hbm / copy_gbps, 4) if copy_gbps else None,
+            "device_copy_detail_GBps": {"hipMemcpyAsync": copy_memcpy, "float4_grid_stride_kernel": copy_kernel},
             "in_flight_while_measured": in_flight,
             "note": "achieved = HBM bytes a regular launch moves (read V + write V + records) / HIP-event launch-to-launch time; "
                     "algorithmic_* = SURVEY 8d numerator (2V+4P[+2P] per algorithmic pass; a pass-pair launch covers two)"}
@@ -316,12 +322,14 @@ def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair
     if queue_factory is not None:  # the units really processed: this rank's share of the batch, SUMmed over the ranks
         total = farm.done_counter(len(m.mine), dist, tensor_device)
     keep = max(1, (steps + inflight - 1) // inflight)
-    m.fallbacks = {"median_handoff": 0, "voting_continuations": 0, "aggregation_redos": 0, "matches": warmup + steps}
+    m.fallbacks = {"median_handoff": 0, "voting_continuations": 0, "aggregation_redos": 0, "scanline_seam_redos": 0, "matches": warmup + steps}
     if host_pairs is None:
         # how often adc_wait had to complete an assumption of the asynchronous pipeline (warm-up + timed region, all pipelines)
         for st in m.handles:
-            for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2)):
+            for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2), ("scanline_seam_redos", 4)):
                 m.fallbacks[key] += int(st.debug_counter(which))
+            m.fallbacks["scanline_segments_per_row"] = int(m.handles[0].debug_counter(5))
+            m.fallbacks["voting_chain_budget"] = int(m.handles[0].debug_counter(3))
     return m, elapsed, total, stages[-keep:], prof[-keep:]
 
 

@@ -183,6 +183,8 @@ int   adc_memcpy_d2h(void* dst, const void* src, size_t bytes);
  * negative on error.  bench.py reports 2*bytes/time next to the 8 TB/s peak: the practical HBM ceiling of this device
  * for a pass that reads one volume and writes another. */
 double adc_device_copy_ms(void* dst, const void* src, size_t bytes, int reps);
+/* the same with a float4 grid-stride copy KERNEL (the hardware guide's yardstick shape), best of a few grid sizes; -1 on error */
+double adc_device_copy_kernel_ms(void* dst, const void* src, size_t bytes, int reps);
 
 /* -------------------------------------------------------------------------------------------
  * Test-only debug surface (parity tests drive single stages with oracle-provided inputs).

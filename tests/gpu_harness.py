@@ -82,6 +82,13 @@ def stage_report(left, right, opt, o, device=0, paper_modes=0):
         st.debug_write(A.BUF_VOLUME_A, o["cost_aggr"])
         st.debug_run(A.RUN_SCANLINE, 4)
         rec("cost_so", st.debug_read(A.BUF_VOLUME_A), o["cost_so"])
+        # the row passes were cut into verified segments when counter 5 > 1: no seam may have failed (counter 6) -- with the
+        # production warm-up; a run with ADC_SO_WARM < 64 (test_scanline_segment_variants) expects failures and checks the redo
+        import os
+        rep["cost_so"]["segments"] = st.debug_counter(5)
+        rep["cost_so"]["seam_fails"] = st.debug_counter(6) if st.debug_counter(5) > 1 else 0
+        if int(os.environ.get("ADC_SO_WARM", "64")) >= 64:
+            assert rep["cost_so"]["seam_fails"] == 0, rep["cost_so"]
 
         # production form of the scanline stage: the last pass also delivers the left-view winner-takes-all
         # (ADCensusStereo::ComputeDisparity, ADCensusStereo.cpp:188-243) -- isolated: oracle cost_aggr in, both

@@ -295,6 +295,49 @@ def test_aggregation_kernel_families_ab(hip, env):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env,expect_redo", [({"ADC_SO_SEG": "0"}, False), ({"ADC_SO_SEG": "2"}, False), ({"ADC_SO_SEG": "3"}, False),
+                                             ({"ADC_SO_SEG": "5", "ADC_SO_FAST": "1"}, False), ({"ADC_SO_SEG": "4", "ADC_SO_FAST": "0"}, False),
+                                             ({"ADC_SO_SEG": "3", "ADC_SO_WARM": "16"}, True)])
+def test_scanline_segment_variants(hip, env, expect_redo):
+    """K5 row passes cut into verified segments (k_scanline_seg / k_scanline_pin_seg): forced segment counts on both kernel
+    families stay bit-exact stage by stage (oracle cost_aggr in, cost_so out; no seam fails with the production warm-up), and
+    with a 16-step warm-up seams DO fail on the device -- then the whole Match must still equal the reference (adc_wait
+    redoes it with whole rows, counter 4) and the handle keeps whole rows for the next Matches.  Switches are read once per
+    process: own interpreter per variant."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import adcensus_amd as A\n"
+            "from tests import cases, gpu_harness\n"
+            "from oracle import pyoracle\n"
+            "bad, redos, segs = {}, 0, []\n"
+            "for name in ('s2_320x180_d128', 'noise_160x90_d128_pos', 's2_360x60_d300', 'cone_crop_d40', 's2_150x100_neg'):\n"
+            "    l, r, opt = cases.make_case(name)\n"
+            "    o = pyoracle.load('auto').run(l, r, opt)\n"
+            "    if %r:\n"
+            "        st = A.ADCensusStereo(device=0)\n"
+            "        assert st.Initialize(l.shape[1], l.shape[0], cases.to_product_option(opt))\n"
+            "        for rep_ in range(3):\n"
+            "            d = st.match(l, r)\n"
+            "            if not np.array_equal(d.view(np.uint32), o['disp_final'].view(np.uint32)): bad[name + ':match%%d' %% rep_] = 1\n"
+            "        redos += st.debug_counter(4)\n"
+            "        st.Release()\n"
+            "    else:\n"
+            "        rep = gpu_harness.stage_report(l, r, opt, o)\n"
+            "        segs.append(rep['cost_so']['segments'])\n"
+            "        bad.update({name + ':' + k: v['bad'] for k, v in gpu_harness.failing(rep).items()})\n"
+            "print('FAILING', bad, 'REDOS', redos, 'SEGMENTS', segs)\n"
+            "want_seg = int(%r)\n"
+            "if want_seg >= 2 and not %r and max(segs) < 2: sys.exit(3)\n"
+            "if %r and redos == 0: sys.exit(2)\n"
+            "sys.exit(1 if bad else 0)\n") % (root, expect_redo, env.get("ADC_SO_SEG", "0"), expect_redo, expect_redo)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_registered_host_buffers(hip, oracle):
     """adc_host_register: images / map inside a page-locked range go by DMA straight from / to the caller's memory (no staging);
     same result, also when only some of the three buffers are registered, and the plain path works again after unregister."""
