@@ -91,6 +91,9 @@ struct adc_handle {
     int wta_left_done;    // the scanline stage did so: adc_launch_wta only runs the right view
     float* med_hand;      // banded median: per-band hand-off rows [bands][med_hpitch], indexed by wavefront level
     int med_hpitch;
+    int med_spec_off;     // > 0: the banded median runs in its chained form (a speculative seam failed; counts down per Match)
+    int med_spec_last;    // the last banded launch used speculative bands
+    int med_spec_fails;   // how often adc_wait had to redo the median because a speculative seam differed
     int force_median_fallback; // test hook (ADC_DEBUG_FORCE_MEDIAN_FALLBACK via adc_debug_run): adc_wait takes the fallback path
     int median_fallbacks;      // how often adc_wait had to redo the median
     int32_t* pin_flags;   // pinned host word: error flag of the banded median's hand-off (read back after every Match)

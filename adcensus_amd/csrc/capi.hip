@@ -108,7 +108,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->cost_rrec, (size_t)p.H * h->rrec_pitch * 16));
     HIP_OK(hipMalloc(&h->cost_lrec, P * 16));
     h->med_hpitch = ((p.W + 2 * p.H + 64 + 15) / 16) * 16;
-    HIP_OK(hipMalloc(&h->med_hand, (size_t)((p.H + 63) / 64 + 1) * h->med_hpitch * sizeof(float)));
+    HIP_OK(hipMalloc(&h->med_hand, (size_t)(5 * ((p.H + 63) / 64) + 1) * h->med_hpitch * sizeof(float))); // (bands + chains of <= 4 speculative copies per band)
     HIP_OK(hipMalloc(&h->gray_r, P));
     HIP_OK(hipMalloc(&h->census_l, P * 8));
     HIP_OK(hipMalloc(&h->census_r, P * 8));
@@ -578,14 +578,15 @@ int adc_wait(adc_handle* h)
     // (3) a median band gave up waiting for its upstream band: the map is incomplete -- redo the filter with the
     //     single-workgroup kernel (no inter-workgroup dependency) and deliver that result
     if (h->pin_flags && (h->pin_flags[0] != 0 || h->force_median_fallback)) {
+        e = adc_median_fallback(h); // (looks at pin_flags[0]: 2 = a speculative seam differed -> chained form first)
         h->pin_flags[0] = 0;
-        e = adc_median_fallback(h);
         if (e == hipSuccess) e = enqueue_output(h);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         h->median_fallbacks++;
         if (e != hipSuccess) { set_error("adc_wait: median fallback", e); return 2; }
     }
     h->force_median_fallback = 0;
+    if (h->med_spec_off > 0 && h->med_spec_last == 0) h->med_spec_off--;
     if (h->async_dst) {
         if (h->async_dst_direct == 2) {
             if (hipMemcpy(h->async_dst, h->disp_l, (size_t)h->p.W * h->p.H * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("adc_wait: copy-out", hipGetLastError()); return 2; }
@@ -894,6 +895,7 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     case ADC_RUN_DISCONTINUITY: e = adc_launch_discontinuity(h); break;
     case ADC_RUN_MEDIAN: // arg 100: test hook -- arm the fallback path of the NEXT adc_wait (as if a band had timed out)
         if (arg == 100) { h->force_median_fallback = 1; return 0; }
+        if (arg == 101) { h->force_median_fallback = 2; return 0; } // ... as if a speculative seam had differed (chained form redone)
         e = adc_launch_median(h);
         break;
     default: return 1;
@@ -902,6 +904,12 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     e = hipStreamSynchronize(h->heavy);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { set_error("adc_debug_run sync", e); return 2; }
+    if (stage == ADC_RUN_MEDIAN && h->pin_flags && h->pin_flags[0] != 0) { // what adc_wait does behind a Match
+        e = adc_median_fallback(h);
+        h->pin_flags[0] = 0;
+        h->median_fallbacks++;
+        if (e != hipSuccess) { set_error("adc_debug_run: median fallback", e); return 2; }
+    }
     return 0;
 }
 
@@ -913,6 +921,8 @@ int64_t adc_debug_counter(adc_handle* h, int which)
     case 1: return h->irv_overflows;
     case 2: return h->arm_redos;
     case 3: return h->irv_budget;
+    case 7: return h->med_spec_fails;
+    case 8: return h->med_spec_last;
     case 4: return h->so_seam_redos;
     case 5: return h->so_nseg_last; // segments per row of the last scanline run
     case 6: { // seams that failed in the last scanline run (debug surface: nothing redoes it there)

@@ -638,12 +638,31 @@ typedef float medb_v2f __attribute__((ext_vector_type(2)));
 // one-column form: 35 % of the wave's cycles in s_waitcnt although the data is prefetched a block ahead, and removing a
 // third of its vector instructions changed nothing -- it is bound by the rate at which the address coalescer takes those
 // 64-line instructions.  Half as many of them: see profiles/README.md.  Odd widths run the one-column form.
+//
+// SPECULATIVE BANDS (round 4, spec = R > 0).  In the chained form band b trails band b-1, which trails band b-2, ...: 17 bands
+// at 1080p, every one of them running all W + 2H levels -- 0.68 ms for an 8 MB map.  But the recursive filter forgets: bands
+// that start from the UNFILTERED row above them (instead of the filtered one) produce, R bands further down, exactly the rows the
+// true filter produces (measured on the CPU with the oracle's maps, tools/median_spec_bands.py, profiles/r4_median_spec_bands.txt:
+// with a run-in of 128 rows no seam of any bench pair differs; with 64 rows 1 of 16 seams of ONE of the four 1080p noise pairs
+// tried, by two pixels).  So the real band b > R takes its hand-off not from the real band b-1 but from a private CHAIN OF COPIES
+// of the bands b-R .. b-1: the copy of band b-R takes the raw row above it, each further copy the hand-off of the copy before,
+// all of them write nothing to the map (workgroups nbands ..: chain of target b = workgroups nbands + (b-R-1)*R + j, j = 0 .. R-1).
+// Bands 1 .. R chain from the real band 0, which has no row above.  Every dependency chain is R + 1 waves long instead of 17,
+// and a wave only runs the levels at which its rows (or the hand-off its successor re-checks) are active: ~2200 instead of 4078.
+// k_median_spec_check then compares what the last copy of each chain handed over with what the real band b-1 published -- bit
+// for bit, every column; a difference raises the error word (2) and adc_wait redoes the filter in the chained form.
 template <bool PAIRS>
 __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* __restrict__ out, int W, int H,
-                                                             int* progress, int* error_word, float* hand, int hpitch)
+                                                             int* progress, int* error_word, float* hand, int hpitch, int nbands, int spec)
 {
     const int tid = threadIdx.x;
-    const int band = blockIdx.x;
+    const bool is_spec = (int)blockIdx.x >= nbands; // a copy (writes no map): link ck of the chain of target band ct
+    const int ck = is_spec ? ((int)blockIdx.x - nbands) % spec : 0, ct = is_spec ? spec + 1 + ((int)blockIdx.x - nbands) / spec : 0;
+    const int band = is_spec ? ct - spec + ck : (int)blockIdx.x; // the rows this wave filters
+    const int myslot = (int)blockIdx.x;                          // hand-off row it publishes its last row into
+    const bool raw_above = is_spec && ck == 0;                    // first link of a chain: the raw row above as its row above
+    // hand-off row this wave reads: the link before it / for a real band the last link of its chain, or the real band above
+    const int upslot = is_spec ? (int)blockIdx.x - 1 : ((spec && band > spec) ? nbands + (band - spec - 1) * spec + spec - 1 : band - 1);
     const int y = band * MEDB_ROWS + tid;
     const int nsteps = W + 2 * (H - 1);
     const int yfirst = band * MEDB_ROWS, ylast = adc_imin(yfirst + MEDB_ROWS, H) - 1; // rows of this band (wave-uniform)
@@ -658,9 +677,17 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     // one auxiliary load stream serves two lanes: lane 0 of a band > 0 reads the upstream hand-off row (by level), the
     // band's last lane reads the unfiltered row below (column x+1); every other lane reads dummy elements of `in`,
     // so the loads are unconditional yet cost a single cache line per instruction
-    const float* rowX = first_row ? hand + (size_t)(band - 1) * hpitch + MEDB_HPAD - 1 : in + (own_b ? (size_t)yb * W : 0);
+    // (a speculative copy reads the RAW row above, indexed by level like a hand-off row: rowX[t] = in[y-1][t - 2y + 1])
+    const float* rowX = first_row ? (raw_above ? in + (size_t)(y - 1) * W - 2 * y + 1 : hand + (size_t)upslot * hpitch + MEDB_HPAD - 1)
+                                  : in + (own_b ? (size_t)yb * W : 0);
+    // levels this wave runs: everything (chained form), or from one block before its first row becomes active (that block is
+    // idle for all its rows, like block 0 of the chained form: hand-off values taken before the first re-check are never used)
+    // to the last level the band BELOW re-checks hand-off values for (its first row stands on its last column at level
+    // W + 2 * ylast + 1 and takes over whole blocks)
+    const int tb = spec ? adc_imax(0, 2 * yfirst - MEDB_K) & ~(MEDB_K - 1) : 0;
+    const int te = spec ? adc_imin(nsteps, W + 2 * ylast + 3 * MEDB_K) : nsteps;
     const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
-    int x = -2 * y; // column at level 0
+    int x = tb - 2 * y; // column at the first level
     float A0 = rowA[clampc(x)], A1 = rowA[clampc(x + 1)], A2 = rowA[clampc(x + 2)];
     const float* rowBfull = in + (size_t)yb * W;
     float Bm = rowBfull[clampc(x - 1)], B0 = rowBfull[clampc(x)];
@@ -733,7 +760,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     const float* pA = row_ok ? rowA + (x + 3) : in;
     // auxiliary stream: lane 0 of a band > 0 -> hand-off row of the upstream band by level (rowX[t + k] = its result of level
     // t + k - 1; block 0 is idle there), the band's last lane -> unfiltered row below at column x + 1 + k
-    const float* pX = first_row ? rowX : ((own_b && row_ok) ? rowX + (x + 1) : in);
+    const float* pX = first_row ? rowX + tb : ((own_b && row_ok) ? rowX + (x + 1) : in);
     // block 0: a band's first row is idle there (x < 0), whatever it reads from the hand-off row is never used
     MEDB_ISSUE(a);
     MEDB_TAKE(a, "s_waitcnt vmcnt(0)\n\t", "s_waitcnt vmcnt(0)\n\t");
@@ -742,8 +769,9 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(Bm), "+v"(B0));
     float* const sinkf = reinterpret_cast<float*>(error_word + 2);  // store target of inactive lanes (8 bytes, 8-byte aligned)
     float* const sink4 = reinterpret_cast<float*>(error_word + 4);  // 16-byte sink (hand-off stores of the other lanes)
-    float* const hrow = hand + (size_t)band * hpitch + MEDB_HPAD;
+    float* const hrow = hand + (size_t)myslot * hpitch + MEDB_HPAD;
     float* const orow = out + (size_t)(row_ok ? y : 0) * W;
+    const bool st_ok = row_ok && !is_spec; // (a speculative copy stores to the sink)
 
     // One block of MEDB_K levels (SI = register set the prefetch of this iteration goes into, ST = set taken over at its end).
     // band > 0 stays behind the upstream band: the block uses hand-off values of levels < t0+MEDB_K-1 and prefetches those of
@@ -767,7 +795,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
 // before the band's first row becomes active are never consumed and are not waited for.
 #define MEDB_RECHECK(T1)                                                                                                \
     do {                                                                                                                \
-        if (band > 0 && (T1) + MEDB_K > 2 * yfirst - 2) {                                                               \
+        if (band > 0 && !raw_above && (T1) + MEDB_K > 2 * yfirst - 2 && (T1) <= W + 2 * yfirst) { /* (only while the first row still needs them) */                                                              \
             int spins = 0;                                                                                              \
             while (true) {                                                                                              \
                 uint32_t mx = 0u;                                                                                       \
@@ -818,11 +846,11 @@ _Pragma("unroll")                                                               
                 if ((k & 1) == 0) res_even = res;                                                                       \
                 else {                                                                                                  \
                     const medb_v2f pr = {res_even, res};                                                                \
-                    float* dst = (row_ok && x >= 1 && x < W) ? orow + (x - 1) : sinkf;                                  \
+                    float* dst = (st_ok && x >= 1 && x < W) ? orow + (x - 1) : sinkf;                                   \
                     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pr) : "memory");                    \
                 }                                                                                                       \
             } else {                                                                                                    \
-                float* dst = active ? orow + x : sinkf;                                                                 \
+                float* dst = (active && !is_spec) ? orow + x : sinkf;                                                   \
                 asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(res) : "memory");                         \
             }                                                                                                           \
             hr[k] = res;                                                                                                \
@@ -843,14 +871,14 @@ _Pragma("unroll")                                                               
             }                                                                                                           \
         }                                                                                                               \
         t0 += MEDB_K;                                                                                                   \
-        done = t0 >= nsteps;                                                                                            \
+        done = t0 >= te;                                                                                                \
         if (!done) {                                                                                                    \
             MEDB_TAKE(a, "s_waitcnt vmcnt(20)\n\t", "s_waitcnt vmcnt(12)\n\t");                                         \
             MEDB_RECHECK(t0);                                                                                           \
         }                                                                                                               \
     } while (0)
     {
-        int t0 = 0;
+        int t0 = tb;
         bool done = false;
         while (!done) MEDB_BLOCK();
     }
@@ -879,6 +907,19 @@ _Pragma("unroll")                                                               
 #undef MEDB_TAKE8
 }
 
+// Seam check of the speculative bands: the last copy of the chain of target band b (a copy of band b - 1) must have handed over
+// exactly what the real band b - 1 published (hand-off row b - 1), at every level at which that band's last row stands on a column.
+__global__ __launch_bounds__(256) void k_median_spec_check(const float* __restrict__ hand, int hpitch, int nbands, int spec, int W, int* error_word)
+{
+    const int b = spec + 1 + (int)blockIdx.y; // targets spec + 1 .. nbands - 1
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (b > nbands - 1 || x >= W) return;
+    const int t = x + 2 * ((b - 1) * MEDB_ROWS + MEDB_ROWS - 1); // level at which row 64 (b - 1) + 63 stands on column x
+    const uint32_t real = reinterpret_cast<const uint32_t*>(hand)[(size_t)(b - 1) * hpitch + MEDB_HPAD + t];
+    const uint32_t copy = reinterpret_cast<const uint32_t*>(hand)[(size_t)(nbands + (b - spec - 1) * spec + spec - 1) * hpitch + MEDB_HPAD + t];
+    if (real != copy) atomicMax(error_word, 2);
+}
+
 static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float* out)
 {
     const AdcParams& p = h->p;
@@ -905,6 +946,34 @@ static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float*
     return hipGetLastError();
 }
 
+// in -> out with the banded kernel; spec = 1: speculative bands + seam check.  The error word (0 ok, 1 hand-off time-out,
+// 2 speculative seam differs) goes to pin_flags[0], looked at by adc_wait.
+static hipError_t launch_median_banded(adc_handle* h, const float* in, float* out, int spec)
+{
+    const AdcParams& p = h->p;
+    const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
+    const int ncopies = spec ? (nbands - 1 - spec) * spec : 0; // a chain of `spec` copies per target band spec + 1 .. nbands - 1
+    // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
+    // the hand-off rows are reset to the "not written yet" sentinel (all ones) before every launch
+    int* prog = h->vote_counters + 160;
+    hipMemsetAsync(prog + 256, 0, 16 * sizeof(int32_t), h->stream);
+    hipMemsetAsync(h->med_hand, 0xFF, (size_t)(nbands + ncopies + 1) * h->med_hpitch * sizeof(float), h->stream);
+    // pairs of columns per instruction when the width is even (ADC_MEDIAN_PAIRS=0: always one column per instruction)
+    static const bool pairs_env = [] { const char* e = getenv("ADC_MEDIAN_PAIRS"); return e ? atoi(e) != 0 : true; }();
+    if (pairs_env && (p.W & 1) == 0)
+        hipLaunchKernelGGL(k_median_banded<true>, dim3(nbands + ncopies), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
+                           h->med_hand, h->med_hpitch, nbands, spec);
+    else
+        hipLaunchKernelGGL(k_median_banded<false>, dim3(nbands + ncopies), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
+                           h->med_hand, h->med_hpitch, nbands, spec);
+    if (spec)
+        hipLaunchKernelGGL(k_median_spec_check, dim3((p.W + 255) / 256, nbands - 1 - spec), dim3(256), 0, h->stream, h->med_hand, h->med_hpitch,
+                           nbands, spec, p.W, prog + 260);
+    h->med_spec_last = spec;
+    if (h->pin_flags) hipMemcpyAsync(h->pin_flags, prog + 260, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream); // checked by adc_wait
+    return hipGetLastError();
+}
+
 hipError_t adc_launch_median(adc_handle* h)
 {
     const AdcParams& p = h->p;
@@ -913,18 +982,11 @@ hipError_t adc_launch_median(adc_handle* h)
     if (banded && nbands > 1 && nbands <= 256 && p.W >= 2 && p.H >= 2 && h->med_hand) {
         // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
         // the hand-off rows are reset to the "not written yet" sentinel (all ones) before every launch
-        int* prog = h->vote_counters + 160;
-        hipMemsetAsync(prog + 256, 0, 16 * sizeof(int32_t), h->stream);
-        hipMemsetAsync(h->med_hand, 0xFF, (size_t)(nbands + 1) * h->med_hpitch * sizeof(float), h->stream);
-        // pairs of columns per instruction when the width is even (ADC_MEDIAN_PAIRS=0: always one column per instruction)
-        static const bool pairs_env = [] { const char* e = getenv("ADC_MEDIAN_PAIRS"); return e ? atoi(e) != 0 : true; }();
-        if (pairs_env && (p.W & 1) == 0)
-            hipLaunchKernelGGL(k_median_banded<true>, dim3(nbands), dim3(MEDB_ROWS), 0, h->stream, h->disp_l, h->disp_tmp, p.W, p.H, prog,
-                               prog + 260, h->med_hand, h->med_hpitch);
-        else
-            hipLaunchKernelGGL(k_median_banded<false>, dim3(nbands), dim3(MEDB_ROWS), 0, h->stream, h->disp_l, h->disp_tmp, p.W, p.H, prog,
-                               prog + 260, h->med_hand, h->med_hpitch);
-        if (h->pin_flags) hipMemcpyAsync(h->pin_flags, prog + 260, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream); // checked by adc_wait
+        // speculative bands (ADC_MEDIAN_SPEC=0: chained form; also for a while after a seam of this handle has failed)
+        // (ADC_MEDIAN_SPEC = run-in in bands, default 2 = 128 rows, 0 = chained form)
+        static const int spec_env = [] { const char* e = getenv("ADC_MEDIAN_SPEC"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 4 ? 4 : v); }();
+        const int spec = (nbands >= spec_env + 2 && h->med_spec_off == 0) ? spec_env : 0;
+        launch_median_banded(h, h->disp_l, h->disp_tmp, spec);
         float* t = h->disp_l;
         h->disp_l = h->disp_tmp;
         h->disp_tmp = t;
@@ -944,7 +1006,18 @@ hipError_t adc_launch_median(adc_handle* h)
 // to the other buffer).  Called by adc_wait after the stream has drained.
 hipError_t adc_median_fallback(adc_handle* h)
 {
-    hipError_t e = launch_median_wavefront(h, h->disp_tmp, h->disp_l);
+    hipError_t e;
+    if (h->med_spec_last && h->pin_flags && (h->pin_flags[0] == 2 || h->force_median_fallback == 2) && h->force_median_fallback != 1) {
+        // a speculative seam differed: the chained form of the banded kernel needs no assumption (and may itself report a
+        // time-out, then the single-workgroup kernel below runs); whole bands for the next Matches of the handle
+        h->med_spec_fails++;
+        h->med_spec_off = 64;
+        e = launch_median_banded(h, h->disp_tmp, h->disp_l, 0);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return e;
+        if (h->pin_flags[0] == 0) return hipSuccess;
+    }
+    e = launch_median_wavefront(h, h->disp_tmp, h->disp_l);
     if (e != hipSuccess) return e;
     return hipStreamSynchronize(h->stream);
 }

@@ -230,7 +230,8 @@ enum {
  * specific (ADC_RUN_AGGREGATE: number of iterations, 0 -> 4, +100 fused cost, +200 host-chosen
  * ring / pass pairs; ADC_RUN_SCANLINE: number of chained passes 1..4, 0 -> 4, +100 = the
  * production form whose last pass also writes DISP_LEFT (the fused left-view winner-takes-all);
- * ADC_RUN_MEDIAN: 100 = do not run, arm the fallback path of the next adc_wait; else ignored). */
+ * ADC_RUN_MEDIAN: 100 = do not run, arm the fallback path of the next adc_wait (single-workgroup kernel); 101 = the same as if
+ * a seam of the speculative bands had differed (the chained form of the banded kernel is redone); else ignored). */
 int adc_debug_run(adc_handle* h, int stage, int arg);
 /* Test-only event counters of the handle: which = 0 -> number of times adc_wait had to redo the median filter with the
  * single-workgroup kernel (hand-off time-out of the banded kernel); 1 -> continuations of the voting chain (launch budget

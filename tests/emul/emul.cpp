@@ -1287,6 +1287,64 @@ void emul_median_padded(const float* in, float* out, int W, int H)
     std::copy(cur.begin(), cur.end(), out);
 }
 
+// Speculative bands of the banded median (k_median_banded, spec = 1): bands of `rows` rows; the real band c + 1 (c >= 1) takes as
+// its "filtered row above" the last row of a COPY of band c that was filtered starting from the RAW row above band c; band 1
+// takes the real band 0's last row.  `out` = the map the real bands write; returns the number of copies whose last row differs
+// from the last row the real band wrote (what k_median_spec_check counts) -- 0 means out is the true in-place filter.
+static void emul_median_band_rows(const float* raw, float* dst_rows, const float* above /* filtered row y0 - 1 or nullptr */, int W, int H, int y0, int y1)
+{
+    // rows [y0, y1) filtered in raster order: row above = `above` (already filtered), rows below = raw
+    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
+    std::vector<float> prev(W), cur(W);
+    if (above) std::copy(above, above + W, prev.begin());
+    for (int y = y0; y < y1; y++) {
+        for (int x = 0; x < W; x++) {
+            float v[9];
+            for (int r = -1; r <= 1; r++)
+                for (int c = -1; c <= 1; c++) {
+                    const int row = y + r, col = x + c, i = (r + 1) * 3 + (c + 1);
+                    const bool corner = (r != 0) && (c != 0);
+                    float val = corner ? PINF : NINF;
+                    if (row >= 0 && row < H && col >= 0 && col < W) {
+                        if (r < 0) val = prev[col];                       // filtered row above
+                        else if (r == 0 && c < 0) val = cur[col];         // filtered left neighbour
+                        else val = raw[(size_t)row * W + col];            // not filtered yet
+                    }
+                    v[i] = val;
+                }
+            cur[x] = adc_median9(v[0], v[1], v[6], v[5], v[7], v[8], v[2], v[3], v[4]);
+        }
+        std::copy(cur.begin(), cur.end(), dst_rows + (size_t)(y - y0) * W);
+        prev = cur;
+    }
+}
+long emul_median_spec_bands(const float* raw, float* out, int W, int H, int rows, int depth)
+{
+    // depth = run-in in bands (k_median_banded: spec): the real band b > depth takes its row above from the last link of a chain
+    // of copies of the bands b - depth .. b - 1, whose first link starts from the RAW row above it; bands 1 .. depth chain from the
+    // real band 0
+    const int nb = (H + rows - 1) / rows;
+    long fails = 0;
+    std::vector<float> copy_rows((size_t)rows * W), handoff(W);
+    for (int b = 0; b < nb; b++) {
+        const int y0 = b * rows, y1 = std::min(H, y0 + rows);
+        const float* above = nullptr;
+        if (b >= 1 && b <= depth) above = out + (size_t)(y0 - 1) * W; // the real band above (exact chain from band 0)
+        if (b > depth) {
+            for (int j = 0; j < depth; j++) { // copy of band b - depth + j
+                const int c0 = (b - depth + j) * rows;
+                std::vector<float> prev(handoff);
+                emul_median_band_rows(raw, copy_rows.data(), j == 0 ? raw + (size_t)(c0 - 1) * W : prev.data(), W, H, c0, c0 + rows);
+                std::copy(copy_rows.begin() + (size_t)(rows - 1) * W, copy_rows.begin() + (size_t)rows * W, handoff.begin());
+            }
+            above = handoff.data();
+        }
+        emul_median_band_rows(raw, out + (size_t)y0 * W, above, W, H, y0, y1);
+        if (b > depth && memcmp(handoff.data(), out + (size_t)(y0 - 1) * W, (size_t)W * sizeof(float))) fails++; // (the real band b - 1 is done by now)
+    }
+    return fails;
+}
+
 // gray of a single pixel (device function check over all 2^24 triples is done from Python in chunks)
 void emul_gray(const uint8_t* bgr, uint8_t* gray, size_t n)
 {

@@ -458,6 +458,29 @@ def test_median_padded_matches_reference_small(emul, oracle):
         assert same(got, want), (h, w)
 
 
+@pytest.mark.parametrize("kind,w,h,d,seed,rows,depth", [("structured", 200, 300, 32, 5, 64, 1), ("noise", 160, 330, 16, 9, 64, 2),
+                                                        ("structured", 240, 330, 32, 6, 64, 2), ("noise", 160, 400, 16, 9, 64, 3),
+                                                        ("structured", 200, 300, 32, 5, 8, 1), ("structured", 200, 300, 32, 5, 8, 2)])
+def test_median_speculative_bands(emul, port_oracle, kind, w, h, d, seed, rows, depth):
+    """k_median_banded with speculative bands (round 4): band b > depth takes its row above from the last link of a chain of copies
+    of the bands b - depth .. b - 1, the first of which was filtered starting from the RAW row above it.  With a run-in of 64+
+    rows no chain differs from the real band on these maps and the result IS the reference's in-place filter; with 8-row bands
+    they do differ -- the count is what the device reports, and the product then redoes the filter in the chained form."""
+    from adcensus_amd import workloads
+    from oracle import pyoracle
+    l, r = workloads.structured_pair(w, h, d, seed=seed) if kind == "structured" else workloads.noise_pair(w, h, seed=seed)
+    o = port_oracle.run(l, r, pyoracle.Option(max_disparity=d), stages=["disp_after_interp", "disp_final"])
+    raw, out = np.ascontiguousarray(o["disp_after_interp"]), np.empty((h, w), np.float32)
+    emul.emul_median_spec_bands.restype = C.c_long
+    fails = emul.emul_median_spec_bands(P(raw), P(out), w, h, rows, depth)
+    if rows == 64:
+        assert fails == 0
+    if fails == 0:
+        assert same(out, o["disp_final"])
+    else:
+        assert not same(out, o["disp_final"]) or rows < 64
+
+
 def test_markstein_division_is_ieee_division(tmp_path):
     """The register-ring aggregation divides by the support count with Markstein's sequence on the correctly rounded
     reciprocal (k_aggregate_rr.h: rr_divide).  tools/markstein_check.c compares it with IEEE division over EVERY binary32

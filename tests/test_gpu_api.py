@@ -100,6 +100,72 @@ def test_median_handoff_timeout_falls_back(hip, oracle):
     st.Release()
 
 
+def test_median_speculative_bands(hip, oracle):
+    """K11 with speculative bands (round 4): 330 rows = 6 bands, so bands 3..5 take their hand-off from chains of two copies that
+    start from raw rows (run-in 128 rows).  Result bit-exact, the speculation held (no fallback), counter 8 says the speculative
+    form ran.  Then the redo path: a 'seam differed' verdict armed through the debug hook makes adc_wait redo the filter in the
+    chained form -- same result, counters 0 and 7 move, and the handle keeps the chained form for the next Matches."""
+    A = hip
+    from oracle import pyoracle
+    from adcensus_amd import workloads
+    w, h, d = 240, 330, 32
+    left, right = workloads.structured_pair(w, h, d, seed=11)
+    opt = pyoracle.Option(max_disparity=d)
+    want = oracle.run(left, right, opt, stages=["disp_final"])["disp_final"]
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(w, h, cases.to_product_option(opt))
+    got = np.zeros((h, w), np.float32)
+    assert st.Match(left, right, got)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert st.debug_counter(0) == 0 and st.debug_counter(7) == 0 and st.debug_counter(8) >= 1
+    st.debug_run(A.RUN_MEDIAN, 101)
+    got[:] = -1
+    assert st.Match(left, right, got)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert st.debug_counter(0) == 1 and st.debug_counter(7) == 1
+    got[:] = -1
+    assert st.Match(left, right, got) and st.debug_counter(8) == 0  # chained form for a while
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert st.debug_counter(0) == 1
+    st.Release()
+
+
+@pytest.mark.parametrize("env", [{"ADC_MEDIAN_SPEC": "0"}, {"ADC_MEDIAN_SPEC": "1"}, {"ADC_MEDIAN_SPEC": "3"}, {"ADC_MEDIAN_SPEC": "2", "ADC_MEDIAN_PAIRS": "0"}])
+def test_median_band_variants(hip, env):
+    """The banded median in its chained form (ADC_MEDIAN_SPEC=0) and with run-ins of 1 / 3 bands, and the one-column form with
+    speculative bands: stage-isolated median + whole Match on maps of 5-9 bands (odd and even widths).  Own interpreter per
+    variant (switches are read once).  With a run-in of ONE band (64 rows) a seam may differ on some map: then the fallback
+    must have produced the exact result anyway (the harness compares after the debug run's own redo)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import adcensus_amd as A\n"
+            "from adcensus_amd import workloads\n"
+            "from tests import cases\n"
+            "from oracle import pyoracle\n"
+            "bad = {}\n"
+            "for kind, w, h, d, seed in (('structured', 240, 330, 32, 11), ('noise', 161, 400, 16, 12), ('structured', 200, 520, 32, 13), ('noise', 96, 330, 8, 14)):\n"
+            "    l, r = workloads.structured_pair(w, h, d, seed=seed) if kind == 'structured' else workloads.noise_pair(w, h, seed=seed)\n"
+            "    opt = pyoracle.Option(max_disparity=d)\n"
+            "    o = pyoracle.load('auto').run(l, r, opt, stages=['disp_after_interp', 'disp_final'])\n"
+            "    st = A.ADCensusStereo(device=0)\n"
+            "    assert st.Initialize(w, h, cases.to_product_option(opt))\n"
+            "    st.debug_write(A.BUF_DISP_LEFT, o['disp_after_interp'])\n"
+            "    st.debug_run(A.RUN_MEDIAN)\n"
+            "    if not np.array_equal(st.debug_read(A.BUF_DISP_LEFT).view(np.uint32), o['disp_final'].view(np.uint32)): bad[(kind, w, h, 'stage')] = 1\n"
+            "    for rep in range(2):\n"
+            "        if not np.array_equal(st.match(l, r).view(np.uint32), o['disp_final'].view(np.uint32)): bad[(kind, w, h, 'match', rep)] = 1\n"
+            "    print(kind, w, h, 'speculative form:', st.debug_counter(8), 'fallbacks', st.debug_counter(0), 'seam failures', st.debug_counter(7))\n"
+            "    st.Release()\n"
+            "print('FAILING', bad)\n"
+            "sys.exit(1 if bad else 0)\n") % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_async_pipeline_assumptions_and_budgets(hip, oracle):
     """Match never waits for the device in mid-pipeline: the aggregation ASSUMES the arm maxima of the previous Match of the
     handle and the voting chain has a launch BUDGET adapted from the previous Match.  Both are verified / completed by
