@@ -680,11 +680,12 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     // (a speculative copy reads the RAW row above, indexed by level like a hand-off row: rowX[t] = in[y-1][t - 2y + 1])
     const float* rowX = first_row ? (raw_above ? in + (size_t)(y - 1) * W - 2 * y + 1 : hand + (size_t)upslot * hpitch + MEDB_HPAD - 1)
                                   : in + (own_b ? (size_t)yb * W : 0);
-    // levels this wave runs: everything (chained form), or from one block before its first row becomes active (that block is
-    // idle for all its rows, like block 0 of the chained form: hand-off values taken before the first re-check are never used)
-    // to the last level the band BELOW re-checks hand-off values for (its first row stands on its last column at level
-    // W + 2 * ylast + 1 and takes over whole blocks)
-    const int tb = spec ? adc_imax(0, 2 * yfirst - MEDB_K) & ~(MEDB_K - 1) : 0;
+    // levels this wave runs: everything (chained form), or from TWO blocks before its first row becomes active -- the first
+    // block is taken over in front of the loop, without a re-check, so it must not hold a level whose hand-off value is used:
+    // the first one used is level 2 * yfirst - 1 (the value the first row needs as "above" on column 0), which sits in the
+    // second block -- to the last level the band BELOW re-checks hand-off values for (its first row stands on its last column
+    // at level W + 2 * ylast + 1 and takes over whole blocks)
+    const int tb = spec ? adc_imax(0, 2 * yfirst - 2 * MEDB_K) & ~(MEDB_K - 1) : 0;
     const int te = spec ? adc_imin(nsteps, W + 2 * ylast + 3 * MEDB_K) : nsteps;
     const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
     int x = tb - 2 * y; // column at the first level

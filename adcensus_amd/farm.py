@@ -97,6 +97,16 @@ class PullQueue:
         self._main_exhausted = self.n == 0
         # (idempotent initialisation of the CAS-managed head: every rank may do it)
         self.store.compare_set("rq_head", "", "0")
+        # A claim writes "<index>|<claimant>" with a token no other claimant uses: compare_set returns the CURRENT value on
+        # failure too, so a bare "<index>" would look like success to a rank that lost the race to exactly one other rank
+        # (both would then compute the same re-queued pair and `done` would be over-counted).
+        import uuid
+        self._token = uuid.uuid4().hex[:16]
+
+    @staticmethod
+    def _head_index(value):
+        v = value.decode() if isinstance(value, bytes) else str(value)
+        return int(v.split("|", 1)[0])
 
     def try_pull(self):
         if not self._main_exhausted:
@@ -106,10 +116,15 @@ class PullQueue:
             self._main_exhausted = True
         while True:  # re-queued pairs: claim index head+1 with a compare-and-set
             tail = self.store.add("rq_tail", 0)
-            head = int(self.store.get("rq_head"))
+            cur = self.store.get("rq_head")
+            cur = cur.decode() if isinstance(cur, bytes) else str(cur)
+            head = self._head_index(cur)
             if head >= tail:
                 return None
-            if int(self.store.compare_set("rq_head", str(head), str(head + 1))) == head + 1:
+            mine = "%d|%s" % (head + 1, self._token)
+            got = self.store.compare_set("rq_head", cur, mine)
+            got = got.decode() if isinstance(got, bytes) else str(got)
+            if got == mine:  # (the whole value, token included: unambiguous)
                 key = "rq/%d" % (head + 1)
                 for _ in range(20000):  # the writer bumps rq_tail before it sets the entry: wait for the entry
                     try:
