@@ -163,6 +163,15 @@ def _img(a):
     return a
 
 
+class PreviousPairFailed(RuntimeError):
+    """adc_farm_submit returned ADC_FARM_PREVIOUS_FAILED: the pair that occupied the pipeline before (`failed_ticket`) failed
+    while it was collected; the NEW pair is in flight all the same and `ticket` is its ticket."""
+
+    def __init__(self, ticket, failed_ticket, message):
+        RuntimeError.__init__(self, message)
+        self.ticket, self.failed_ticket = int(ticket), int(failed_ticket)
+
+
 class PairFarm:
     """Persistent farm of `pipelines` matchers of one geometry on one device (adc_farm_* of the C ABI): submit() enqueues
     a whole Match asynchronously from host buffers, results land in the caller's arrays in submission order."""
@@ -186,8 +195,8 @@ class PairFarm:
         ticket = int(t.value)
         self._keep[ticket] = disp_left  # the output array must stay alive until the pair is delivered
         self._keep.pop(ticket - self.pipelines, None)  # submit() has just delivered the pair that held this pipeline before
-        if rc == 3:  # ADC_FARM_PREVIOUS_FAILED: the new pair IS in flight; the message names the ticket that failed
-            raise RuntimeError("adc_farm_submit: " + last_error())
+        if rc == 3:  # ADC_FARM_PREVIOUS_FAILED: the new pair IS in flight (ticket), the pipeline's previous pair failed
+            raise PreviousPairFailed(ticket, ticket - self.pipelines, "adc_farm_submit: " + last_error())
         return ticket
 
     def wait(self, ticket):

@@ -91,6 +91,7 @@ struct adc_handle {
     int wta_left_done;    // the scanline stage did so: adc_launch_wta only runs the right view
     float* med_hand;      // banded median: per-band hand-off rows [bands][med_hpitch], indexed by wavefront level
     int med_hpitch;
+    float* med_sink;      // banded median: 16-byte store sink per lane of every wave (bands + speculative copies)
     int med_spec_off;     // > 0: the banded median runs in its chained form (a speculative seam failed; counts down per Match)
     int med_spec_last;    // the last banded launch used speculative bands
     int med_spec_fails;   // how often adc_wait had to redo the median because a speculative seam differed

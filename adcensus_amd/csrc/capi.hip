@@ -109,6 +109,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->cost_lrec, P * 16));
     h->med_hpitch = ((p.W + 2 * p.H + 64 + 15) / 16) * 16;
     HIP_OK(hipMalloc(&h->med_hand, (size_t)(5 * ((p.H + 63) / 64) + 1) * h->med_hpitch * sizeof(float))); // (bands + chains of <= 4 speculative copies per band)
+    HIP_OK(hipMalloc(&h->med_sink, (size_t)(5 * ((p.H + 63) / 64) + 1) * 64 * 16));
     HIP_OK(hipMalloc(&h->gray_r, P));
     HIP_OK(hipMalloc(&h->census_l, P * 8));
     HIP_OK(hipMalloc(&h->census_r, P * 8));
@@ -293,7 +294,7 @@ void adc_destroy(adc_handle* h)
     if (h->heavy) hipStreamSynchronize(h->heavy);
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->so_seam, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
-                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
+                    h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->med_sink, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
                     h->chg_a, h->edge, h->arms_r, h->bgrx_r, h->armmax_r, h->vol_c};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
@@ -490,7 +491,11 @@ static int match_async_impl(adc_handle* h, const uint8_t* left, const uint8_t* r
     // stage through the handle's pinned buffers (complete on return) unless the caller registered its memory.
     static const bool direct_env = [] { const char* e = getenv("ADC_HOST_DIRECT"); return e ? atoi(e) != 0 : true; }();
     const bool direct = direct_env && sync_call;
-    const bool reg_in = host_registered(left, P * 3) && host_registered(right, P * 3);
+    // Registered (page-locked) INPUT images are DMA-ed in place only by the synchronous adc_match, which returns after the
+    // copy: the asynchronous entry points (adc_match_async, adc_farm_submit) promise that the caller may refill its images as
+    // soon as the call returns, so they always stage the inputs (a DMA still in flight would read the refilled pixels).  The
+    // OUTPUT map of a registered range is written in place by every entry point (it is the caller's until adc_wait anyway).
+    const bool reg_in = sync_call && host_registered(left, P * 3) && host_registered(right, P * 3);
     if (reg_in || direct) { // DMA from the caller's memory (page-locked by the caller: asynchronous; pageable: the runtime stages)
         if (hipMemcpyAsync(h->img_l, left, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
         if (hipMemcpyAsync(h->img_r, right, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
@@ -662,13 +667,20 @@ int adc_farm_submit(adc_farm* f, const uint8_t* left, const uint8_t* right, floa
     // failed ticket in adc_last_error(): the caller can tell which output is invalid
     const uint64_t prev = f->in_flight[slot];
     const int rc_prev = farm_collect(f, slot);
+    const std::string prev_error = rc_prev != 0 ? g_last_error : std::string();
     int rc = adc_match_async(f->pipes[slot], left, right, disp);
-    if (rc != 0) return rc;
+    if (rc != 0) {
+        // nothing was enqueued; when the pipeline's previous pair failed as well, say so first (its output is invalid too)
+        if (rc_prev != 0)
+            g_last_error = "adc_farm_submit: the pair with ticket " + std::to_string((unsigned long long)prev) + " failed (" + prev_error +
+                           ") AND the new pair could not be enqueued (" + g_last_error + ")";
+        return rc;
+    }
     f->in_flight[slot] = t;
     f->next_ticket++;
     if (ticket) *ticket = t;
     if (rc_prev != 0) {
-        g_last_error = "adc_farm_submit: the pair with ticket " + std::to_string((unsigned long long)prev) + " failed (" + g_last_error + "); the new pair was enqueued";
+        g_last_error = "adc_farm_submit: the pair with ticket " + std::to_string((unsigned long long)prev) + " failed (" + prev_error + "); the new pair was enqueued";
         return ADC_FARM_PREVIOUS_FAILED;
     }
     return 0;
@@ -705,9 +717,17 @@ int adc_set_paper_modes(adc_handle* h, uint32_t modes)
     if (!h || (modes & ~(ADC_PAPER_CENSUS5X5 | ADC_PAPER_SO_SUM | ADC_PAPER_RIGHT_ARMS))) return 1;
     hipSetDevice(h->device);
     const size_t P = (size_t)h->p.W * h->p.H;
-    if ((modes & ADC_PAPER_RIGHT_ARMS) && !h->arms_r) {
-        if (hipMalloc(&h->arms_r, P * 4) != hipSuccess || hipMalloc(&h->bgrx_r, P * 4) != hipSuccess ||
-            hipMalloc(&h->armmax_r, 4 * sizeof(int)) != hipSuccess) { g_last_error = "adc_set_paper_modes: allocation failed"; return 2; }
+    if ((modes & ADC_PAPER_RIGHT_ARMS) && !(h->arms_r && h->bgrx_r && h->armmax_r)) {
+        // all three or none: a partial set left behind by a failed call must not pass for "allocated" in the next one
+        if ((!h->arms_r && hipMalloc(&h->arms_r, P * 4) != hipSuccess) || (!h->bgrx_r && hipMalloc(&h->bgrx_r, P * 4) != hipSuccess) ||
+            (!h->armmax_r && hipMalloc(&h->armmax_r, 4 * sizeof(int)) != hipSuccess)) {
+            if (h->arms_r) hipFree(h->arms_r);
+            if (h->bgrx_r) hipFree(h->bgrx_r);
+            if (h->armmax_r) hipFree(h->armmax_r);
+            h->arms_r = nullptr; h->bgrx_r = nullptr; h->armmax_r = nullptr;
+            g_last_error = "adc_set_paper_modes: allocation failed";
+            return 2;
+        }
     }
     if ((modes & ADC_PAPER_SO_SUM) && !h->vol_c) {
         if (hipMalloc(&h->vol_c, P * h->p.Dp * sizeof(float)) != hipSuccess) { g_last_error = "adc_set_paper_modes: allocation failed"; return 2; }

@@ -653,7 +653,8 @@ typedef float medb_v2f __attribute__((ext_vector_type(2)));
 // for bit, every column; a difference raises the error word (2) and adc_wait redoes the filter in the chained form.
 template <bool PAIRS>
 __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* __restrict__ out, int W, int H,
-                                                             int* progress, int* error_word, float* hand, int hpitch, int nbands, int spec)
+                                                             int* progress, int* error_word, float* hand, int hpitch, int nbands, int spec,
+                                                             float* sinks)
 {
     const int tid = threadIdx.x;
     const bool is_spec = (int)blockIdx.x >= nbands; // a copy (writes no map): link ck of the chain of target band ct
@@ -768,8 +769,12 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
 
     // the compiler-issued window loads above are consumed here, so that no wait for them ends up inside the loop
     asm volatile("" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(Bm), "+v"(B0));
-    float* const sinkf = reinterpret_cast<float*>(error_word + 2);  // store target of inactive lanes (8 bytes, 8-byte aligned)
-    float* const sink4 = reinterpret_cast<float*>(error_word + 4);  // 16-byte sink (hand-off stores of the other lanes)
+    // Store targets of lanes that have nothing to store (every block keeps its fixed number of vector-memory operations): ONE
+    // 16-byte slot PER LANE (sinks[workgroup][lane][4]) -- the 64 stores of an instruction then fall into one contiguous KiB.
+    // (Round 4: with a shared 8-byte sink word the speculative copies, whose 64 lanes ALL store there at every level, ran three
+    // times slower than a real band: 64 same-address stores per instruction serialise.)
+    float* const sinkf = sinks + ((size_t)blockIdx.x * MEDB_ROWS + tid) * 4;
+    float* const sink4 = sinkf;
     float* const hrow = hand + (size_t)myslot * hpitch + MEDB_HPAD;
     float* const orow = out + (size_t)(row_ok ? y : 0) * W;
     const bool st_ok = row_ok && !is_spec; // (a speculative copy stores to the sink)
@@ -952,6 +957,11 @@ static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float*
 static hipError_t launch_median_banded(adc_handle* h, const float* in, float* out, int spec)
 {
     const AdcParams& p = h->p;
+    // The kernel prefetches past the end of the last row without clamping (and a speculative copy reads a few elements behind
+    // the row above its band): only the two maps that capi.hip allocates with 1 KiB of slack may be passed.  (It also relies
+    // on 0xFFFFFFFF never being a disparity value -- that NaN is the hand-off rows' "not written yet" mark; a debug upload of
+    // such a value makes the bands re-read until the bounded spin gives up and adc_wait runs the single-workgroup kernel.)
+    if ((in != h->disp_l && in != h->disp_tmp) || (out != h->disp_l && out != h->disp_tmp) || in == out) return hipErrorInvalidValue;
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
     const int ncopies = spec ? (nbands - 1 - spec) * spec : 0; // a chain of `spec` copies per target band spec + 1 .. nbands - 1
     // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
@@ -963,10 +973,10 @@ static hipError_t launch_median_banded(adc_handle* h, const float* in, float* ou
     static const bool pairs_env = [] { const char* e = getenv("ADC_MEDIAN_PAIRS"); return e ? atoi(e) != 0 : true; }();
     if (pairs_env && (p.W & 1) == 0)
         hipLaunchKernelGGL(k_median_banded<true>, dim3(nbands + ncopies), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
-                           h->med_hand, h->med_hpitch, nbands, spec);
+                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink);
     else
         hipLaunchKernelGGL(k_median_banded<false>, dim3(nbands + ncopies), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
-                           h->med_hand, h->med_hpitch, nbands, spec);
+                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink);
     if (spec)
         hipLaunchKernelGGL(k_median_spec_check, dim3((p.W + 255) / 256, nbands - 1 - spec), dim3(256), 0, h->stream, h->med_hand, h->med_hpitch,
                            nbands, spec, p.W, prog + 260);

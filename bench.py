@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the structured / host-inclusive / throughput legs")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample strip (0 = the whole frame, ~20 s)")
+    ap.add_argument("--cpu-baseline-structured", action="store_true",
+                    help="also time the reference on the structured pair (SURVEY 8d S2; ~35 s on one host core) -> structured.cpu_baseline")
+    ap.add_argument("--no-cone-leg", action="store_true", help="skip the Cone 450x375 D=64 leg (BASELINE.json configs[0] / [1])")
     ap.add_argument("--write-digests", default="", help="write {pair id: sha256} of the batch outputs to this file (N = 1)")
     return ap.parse_args()
 
@@ -176,11 +179,24 @@ class HostFedMatcher:
         self.ticket = {}
 
     def submit(self, slot, pid):
+        from adcensus_amd import farm
         l, r = self.pairs[pid]
-        self.ticket[slot] = self.farm.submit(l, r, self.out[pid])
+        try:
+            self.ticket[slot] = self.farm.submit(l, r, self.out[pid])
+        except self.A.PreviousPairFailed as e:
+            # the NEW pair is in flight (its ticket is valid: a later wait(slot) finds it); the pipeline's previous pair failed:
+            # the pull queue re-queues what this rank has in flight and retires the rank
+            self.ticket[slot] = e.ticket
+            raise farm.MatchFailed(str(e))
+        except RuntimeError as e:
+            raise farm.MatchFailed(str(e))
 
     def wait(self, slot):
-        self.farm.wait(self.ticket.pop(slot))
+        from adcensus_amd import farm
+        try:
+            self.farm.wait(self.ticket.pop(slot))
+        except RuntimeError as e:
+            raise farm.MatchFailed(str(e))
 
     def release(self):
         self.farm.close()
@@ -395,7 +411,12 @@ def main():
     dist, tensor_device, backend, comm = None, "cpu", None, None
     if world > 1 or os.environ.get("ADC_BENCH_FORCE_DIST") == "1":  # (FORCE_DIST: exercise the RCCL calls with one rank)
         dist, backend, tensor_device, local_rank, comm = init_dist(world, local_rank)
-    import adcensus_amd as A
+    stub_module = os.environ.get("ADC_BENCH_MATCHER_MODULE", "")
+    if stub_module:  # test hook (tests/bench_stub.py): the N > 1 path end to end on a machine without a GPU; never a measurement
+        import importlib
+        A = importlib.import_module(stub_module)
+    else:
+        import adcensus_amd as A
     from adcensus_amd import farm
     lib = A.lib()
     if A.device_count() < 1:
@@ -482,6 +503,8 @@ def main():
                        "spinup_ms": a.spinup_ms,
                        "comm_backend": (backend if dist is not None else None), "comm": comm},
             "farm_check": check,
+            "device_binding": {"rank": rank, "local_rank_env": int(os.environ.get("LOCAL_RANK", "0")), "device_index": local_rank,
+                               "matcher_module": stub_module or "adcensus_amd"},
             "ms_per_pair_latency": round(float(np.sum(list(stage.values()))), 4) if stage else None,
             "stage_ms": stage,
             "roofline": k4_roofline(prof, W, H, D, lib, a.workload, m.handles[0].aggregate_kernel(), F),
@@ -544,6 +567,10 @@ def main():
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(make_pair(a.workload, W, H, D, 0), D, a.cpu_rows, H)
+            if a.cpu_baseline_structured and "structured" in out:
+                out["structured"]["cpu_baseline"] = cpu_baseline(make_pair("structured", W, H, D, 0), D, a.cpu_rows, H)
+        if world == 1 and not a.no_cone_leg and not a.no_extra_legs:
+            out["cone"] = cone_leg(A, local_rank, with_cpu=not a.no_cpu_baseline)
         sys.stdout.flush()
         try:
             import ctypes
@@ -583,6 +610,59 @@ def host_inclusive_leg(A, device, W, H, D, workload, n, registered=False):
                             "staging (12.4 MB), H2D, kernels, D2H (8.3 MB), copy-out; synchronous")}
 
 
+def cone_leg(A, device, with_cpu=True, reps=5):
+    """BASELINE.json configs[0] / [1]: the Middlebury Cone pair (450 x 375, D = 64; tests/golden/cone_pair.npz = the reference's
+    Data/Cone) through the drop-in entry point adc_match on one MI355X, >= 3 repetitions, and through the reference's own
+    ADCensusStereo::Match on one host core, 3 repetitions (ADCensusStereo.cpp:69-132), the two maps compared bit for bit."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cone_pair.npz"))
+    left, right = np.ascontiguousarray(z["left"]), np.ascontiguousarray(z["right"])
+    H, W, D = left.shape[0], left.shape[1], 64
+    st = A.ADCensusStereo(device=device)
+    if not st.Initialize(W, H, A.ADCensusOption(min_disparity=0, max_disparity=D)):
+        raise SystemExit("Initialize failed: " + A.last_error())
+    disp = np.empty((H, W), np.float32)
+    for _ in range(3):
+        assert st.Match(left, right, disp)
+    ts = []
+    for _ in range(max(3, reps)):
+        t0 = time.perf_counter()
+        assert st.Match(left, right, disp)
+        ts.append(time.perf_counter() - t0)
+    st.Release()
+    out = {"workload": "Cone 450x375 D=64 (Middlebury, the reference's Data/Cone)", "gpu": {
+        "entry_point": "adc_match(left, right, disp): pageable host buffers in and out, synchronous (PCIe inclusive)",
+        "repetitions": len(ts), "ms_per_pair": [round(1000.0 * t, 4) for t in ts], "value": round(len(ts) / sum(ts), 3), "unit": "pairs/s"}}
+    if with_cpu:
+        from oracle import pyoracle  # checker / baseline leg only
+        orc = pyoracle.load("auto")
+        opt = pyoracle.Option(max_disparity=D)
+        devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)
+        sys.stdout.flush()
+        os.dup2(devnull, 1)  # (the reference printf()s its stage timings)
+        secs, ref = [], None
+        try:
+            for _ in range(3):
+                ref, s_ = orc.match(left, right, opt)
+                secs.append(s_)
+        finally:
+            sys.stdout.flush()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(saved, 1)
+            os.close(devnull)
+            os.close(saved)
+        same = int((np.asarray(ref, np.float32).view(np.uint32) == disp.view(np.uint32)).sum())
+        out["cpu"] = {"kind": "reference" if orc.kind == "reference" else "port", "cores": 1, "repetitions": 3,
+                      "s_per_pair": [round(s_, 4) for s_ in secs], "value": round(3.0 / sum(secs), 4), "unit": "pairs/s",
+                      "cpu_model": cpu_model(), "host_cores": os.cpu_count() or 0}
+        out["check"] = {"pixels": int(disp.size), "bit_identical": same, "ok": same == int(disp.size)}
+        out["gpu_over_cpu"] = round(out["gpu"]["value"] / out["cpu"]["value"], 1)
+    return out
+
+
 def host_farm_leg(A, device, W, H, D, workload, n):
     """The persistent farm of the C ABI (adc_farm_*): pageable host buffers in, pageable host buffers out, 3 pipelines."""
     pairs = [make_pair(workload, W, H, D, i) for i in range(min(n, 6))]
@@ -607,15 +687,16 @@ def pmc_traffic(workload, whd):
     or when it was collected on other aggregation kernel sources (k4_source_hash)."""
     if whd != (1920, 1080, 128):
         return None
-    p = os.path.join(ROOT, "profiles", "r3_k4_pmc_traffic_%s.json" % workload)
-    try:
-        with open(p) as f:
-            o = json.load(f)
-        if o.get("k4_src_sha16") != k4_source_hash():
-            return None
-        return float(o["traffic_bytes_per_launch_avg"])
-    except Exception:
-        return None
+    for rnd in ("r4", "r3"):  # the newest measurement taken on exactly these kernel sources
+        p = os.path.join(ROOT, "profiles", "%s_k4_pmc_traffic_%s.json" % (rnd, workload))
+        try:
+            with open(p) as f:
+                o = json.load(f)
+            if o.get("k4_src_sha16") == k4_source_hash():
+                return float(o["traffic_bytes_per_launch_avg"])
+        except Exception:
+            pass
+    return None
 
 
 def cpu_model():

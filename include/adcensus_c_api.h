@@ -106,7 +106,10 @@ int adc_wait(adc_handle* h);
 /* Opt-in for host callers that keep their buffers alive: page-lock a host range (hipHostRegister) and tell the library.
  * Images / disparity maps passed to adc_match / adc_match_async / adc_farm_submit that lie inside a registered range are
  * then transferred by DMA straight from / to the caller's memory -- no pinned staging copies (2 x 6.2 MB in, 8.3 MB out
- * per 1080p pair).  The caller must adc_host_unregister(ptr) BEFORE freeing the memory.  Process-wide, thread-safe.
+ * per 1080p pair).  INPUT images are read in place only by the synchronous adc_match (which returns after the copy);
+ * adc_match_async and adc_farm_submit keep their contract "the images may be reused as soon as the call returns" and still
+ * stage them.  A registered OUTPUT map is written in place by every entry point (it belongs to the library until adc_wait /
+ * adc_farm_wait has delivered it).  The caller must adc_host_unregister(ptr) BEFORE freeing the memory.  Process-wide, thread-safe.
  * 0 ok, 1 bad argument / unknown pointer, 2 HIP failure. */
 int adc_host_register(void* ptr, size_t bytes);
 int adc_host_unregister(void* ptr);

@@ -113,3 +113,47 @@ def test_roofline_arithmetic():
     sr = bench.stage_roofline({"scanline": 2.0, "wta": 0.3, "aggregate": 3.5}, 6.0, W, H, D)
     assert abs(sr["scanline_K5"]["bytes"] - 4 * (2 * V + 3 * P)) < 1 and abs(sr["wta_right_K6"]["bytes"] - V) < 1
     assert abs(sr["whole_match"]["bytes"] - 26 * V) < 1 and all(v["frac"] < 1.0 for v in sr.values())
+
+
+def test_bench_two_ranks_gloo_stub():
+    """First-contact insurance for the multi-GPU path (round-3 review item 8): `bench.py --gpus 2` end to end on this machine --
+    the torchrun re-exec, one process per rank, LOCAL_RANK -> device binding, torch.distributed collectives (gloo here, RCCL on
+    the node), static partition + neighbour re-check, the host-fed leg, the scaling reference and the ONE JSON line of rank 0 --
+    with a stub matcher (tests/bench_stub.py) in place of the HIP library.  The first real 8-GPU run is then not the first time
+    this code runs with more than one rank."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ADC_BENCH_BACKEND="gloo", ADC_BENCH_MATCHER_MODULE="tests.bench_stub", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "64", "--height", "48",
+                        "--disp", "16", "--spinup-ms", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout: rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["comm"]["ranks_in_all_reduce"] == 2 and d["config"]["comm"]["world_size"] == 2
+    assert d["farm_check"]["ok"], d["farm_check"]
+    assert d["device_binding"]["device_index"] == d["device_binding"]["local_rank_env"] == 0  # rank 0 -> device LOCAL_RANK
+    assert d["device_binding"]["matcher_module"] == "tests.bench_stub"
+    assert "scaling_reference" in d and d["scaling_reference"]["n_gpus"] == 1
+    assert "host_farm" in d and d["host_farm"]["n_gpus"] == 2
+    assert d["value"] > 0 and d["unit"] == "pairs/s" and d["higher_is_better"] is True
+
+
+def test_bench_pull_queue_two_ranks_gloo_stub():
+    """The same for the fixed batch through the pull queue (BASELINE.json configs[4]: --batch B, strong scaling)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ADC_BENCH_BACKEND="gloo", ADC_BENCH_MATCHER_MODULE="tests.bench_stub", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--warmup", "1", "--width", "64", "--height", "48",
+                        "--disp", "16", "--spinup-ms", "0", "--no-host-leg"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["farm_check"]["ok"]
+    assert d["config"]["comm"]["ranks_in_all_reduce"] == 2

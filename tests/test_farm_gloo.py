@@ -182,6 +182,35 @@ def test_pull_queue_requeue_and_all_failed():
         farm.run_queue(farm.PullQueue(store2, 3, world=1), good.submit, good.wait, inflight=1)
 
 
+def test_pull_queue_claim_is_unambiguous():
+    """Advisor finding (round 3): compare_set returns the CURRENT value also when it fails, so a claim that writes a bare
+    "head + 1" looks successful to a rank that lost the race to exactly one other rank -- two ranks would compute the same
+    re-queued pair.  The claim now carries a claimant token.  Model: both ranks have read head = 0; the slower one's
+    compare_set runs after the faster one's."""
+    from adcensus_amd import farm
+
+    class RacyStore(farm.LocalStore):
+        """Lets a second queue claim the entry between this queue's read of rq_head and its compare_set."""
+        def __init__(self):
+            super().__init__()
+            self.intruder = None
+
+        def compare_set(self, key, expected, desired):
+            if key == "rq_head" and self.intruder is not None:
+                q, self.intruder = self.intruder, None
+                self.stolen = q.try_pull()  # the other rank wins the race
+            return super().compare_set(key, expected, desired)
+
+    store = RacyStore()
+    a, b = farm.PullQueue(store, 0, world=2), farm.PullQueue(store, 0, world=2)
+    a.requeue(7)
+    store.intruder = b
+    got_a = a.try_pull()   # a read head = 0, then b claimed entry 1, then a's compare_set failed
+    assert store.stolen == 7 and got_a is None
+    a.requeue(9)
+    assert a.try_pull() == 9 and b.try_pull() is None
+
+
 def _queue_worker(rank, world, port, q, batch, fail_rank):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
