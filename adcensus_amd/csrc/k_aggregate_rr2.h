@@ -81,22 +81,12 @@ RR_FN rr2_f2 rr2_make(float a, float b) { rr2_f2 r; r.x = a; r.y = b; return r; 
     } while (0)
 #define RR2_SAD(A, B) __builtin_amdgcn_sad_u8((A), (B), 0u)
 #define RR2_POPC(X) ((uint32_t)__popc(X))
-// the decoded scalars of a group of four steps are pinned in SGPRs where they are computed (an empty statement that reads
-// them): the machine-sinking pass otherwise moves every decode back in front of its only use, behind the branches of the
-// steps in between, and the four chains run one after the other again
-#define RR2_ANCHOR4(A) asm volatile("" ::"s"((A)[0]), "s"((A)[1]), "s"((A)[2]), "s"((A)[3]))
 
 #define RR2_CLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239"
 // ring[slot] = v
 RR_FN void rr2_push(int slot, rr2_f2 v)
 {
     const int s2 = RR_UNIFORM(2 * slot);
-    asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b64 v[96:97], %1\n\ts_set_gpr_idx_off" ::"s"(s2), "v"(v)
-                 : "m0", RR2_CLOBBERS);
-}
-// the same with the ready-made index value (M0 = 2 * slot)
-RR_FN void rr2_push_m0(int s2, rr2_f2 v)
-{
     asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b64 v[96:97], %1\n\ts_set_gpr_idx_off" ::"s"(s2), "v"(v)
                  : "m0", RR2_CLOBBERS);
 }
@@ -197,17 +187,11 @@ RR_FN uint32_t rr2_sad_u8(uint32_t a, uint32_t b)
 }
 #define RR2_SAD(A, B) rr2_sad_u8((A), (B))
 #define RR2_POPC(X) ((uint32_t)__builtin_popcount(X))
-#define RR2_ANCHOR4(A) ((void)0)
 RR_FN void rr2_push(int slot, rr2_f2 v)
 {
     assert(slot >= 0 && slot < RR2_SLOTS);
     rr_emul.vgpr[RR2_V0 + 2 * slot] = v.x;
     rr_emul.vgpr[RR2_V0 + 2 * slot + 1] = v.y;
-}
-RR_FN void rr2_push_m0(int s2, rr2_f2 v)
-{
-    assert(s2 % 2 == 0);
-    rr2_push(s2 / 2, v);
 }
 RR_FN void rr2_run(rr2_f2& acc, int m2, int off)
 {
@@ -364,65 +348,6 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
         dpn += fstep;                                                                                                \
     } while (0)
 
-// Steady state, round 4: the wave-uniform control of FOUR consecutive steps is decoded in one go (RR2_DECODE4), before the
-// first of them runs.  A step's decode is a dependent chain of ~12 scalar instructions behind a v_readlane (record -> biased
-// arm, span -> first slot with the unsigned-min wrap -> run length -> M0 value and jump offset); inside the step it sat between
-// the push and the computed jump, on the critical path of every step (a lone chain issues an instruction every 5-7 cycles:
-// ~70 cycles of a ~270-cycle step, profiles/r3_sq_all_structured.md: more scalar than vector instructions per step, 0.47 of the
-// wave cycles waiting to issue).  Four independent chains side by side take about as long as one.  A step then is: take /
-// reload / push (M0 = ds2) / one run with ready-made M0 and jump offset (dm2, doff) / divide / store; spans longer than the add
-// block and spans that wrap around the ring end (dslow) take the generic path on the same decoded values.
-// wb = slot of the entry the step pushes (w1 before the push); the step leaves w1 = (wb + 1) mod R.
-#define RR2_DECODE4(POS0)                                                                                            \
-    uint32_t dr[4], dy[4];                                                                                           \
-    int ds2[4], dwa[4], dm2[4], doff[4], dslow[4];                                                                   \
-    {                                                                                                                \
-        int wb_ = w1;                                                                                                \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++)                                                             \
-        {                                                                                                            \
-            dr[q_] = RR_READLANE(c1x, (POS0) + q_);                                                                  \
-            dy[q_] = 0u;                                                                                             \
-            if constexpr (DIVIDE) dy[q_] = RR_READLANE(c1y, (POS0) + q_);                                            \
-            ds2[q_] = 2 * wb_;                                                                                       \
-            wb_ = wb_ + 1 == R ? 0 : wb_ + 1;                                                                        \
-            dwa[q_] = wb_;                                                                                           \
-            const int alo_ = (int)(dr[q_] & 255u), an_ = (int)((dr[q_] >> 8) & 255u);                                \
-            uint32_t i1_ = (uint32_t)(wb_ - alo_);                                                                   \
-            i1_ = i1_ < i1_ + (uint32_t)R ? i1_ : i1_ + (uint32_t)R; /* min_u32: wraps a negative index */            \
-            const int n1_ = adc_imin(an_, R - (int)i1_);                                                             \
-            dm2[q_] = 2 * ((int)i1_ + n1_);                                                                          \
-            doff[q_] = 12 + 8 * RR2_BLK - 8 * n1_;                                                                   \
-            const int over_ = n1_ - RR2_BLK;                                                                         \
-            dslow[q_] = (an_ - n1_) | (over_ > 0 ? over_ : 0); /* (scalar max: the flag stays in an SGPR) */           \
-        }                                                                                                            \
-        RR2_ANCHOR4(dr); RR2_ANCHOR4(ds2); RR2_ANCHOR4(dwa); RR2_ANCHOR4(dm2); RR2_ANCHOR4(doff); RR2_ANCHOR4(dslow);  \
-        if constexpr (DIVIDE) RR2_ANCHOR4(dy);                                                                       \
-    }
-// push with the decoded slot of step Q (0..3) of the group
-#define RR2_PUSH_D(Q, VAL) do { rr2_push_m0(ds2[Q], (VAL)); w1 = dwa[Q]; } while (0)
-// output of step Q of the group from the decoded scalars; exactly one store
-#define RR2_EMIT_D(Q)                                                                                                \
-    do {                                                                                                             \
-        rr2_f2 acc_ = rr2_make(0.0f, 0.0f);                                                                          \
-        if (__builtin_expect(dslow[Q] == 0, 1)) {                                                                    \
-            rr2_run(acc_, dm2[Q], doff[Q]); /* t = -arm .. +arm, one run */                                          \
-        } else { /* a span longer than the add block, or one that wraps around the ring end */                        \
-            const int alo_ = (int)(dr[Q] & 255u), an_ = (int)((dr[Q] >> 8) & 255u);                                  \
-            uint32_t i1_ = (uint32_t)(dwa[Q] - alo_);                                                                \
-            i1_ = i1_ < i1_ + (uint32_t)R ? i1_ : i1_ + (uint32_t)R;                                                 \
-            const int n1_ = adc_imin(an_, R - (int)i1_);                                                             \
-            acc_ = rr2_sum(acc_, (int)i1_, n1_);                                                                     \
-            if (an_ > n1_) acc_ = rr2_sum(acc_, 0, an_ - n1_);                                                       \
-        }                                                                                                            \
-        if constexpr (DIVIDE) {                                                                                      \
-            const float y_ = RR_BITS_TO_F32(dy[Q]);                                                                  \
-            const float cf_ = (float)(dr[Q] >> 16);                                                                  \
-            acc_ = rr2_make(rr_divide(acc_.x, cf_, y_), rr_divide(acc_.y, cf_, y_)); /* cross_aggregator.cpp:389 */  \
-        }                                                                                                            \
-        *reinterpret_cast<rr2_f2*>(dpn) = acc_;                                                                      \
-        dpn += fstep;                                                                                                \
-    } while (0)
-
     // ---- phase A: entries lo .. jB-1 precede the first output's look-ahead (no output yet)
     const int jB = adc_imin(hi, m0 + L);
     if constexpr (COSTIN) {
@@ -463,26 +388,19 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
             RR2_CREC_ISSUE(bx0);
             RR2_CREC_TAKE(RR_WAIT_ALL_STR, cR0, cR1, cR2, cL0, cL1, cL2, nR0, nR1, nR2, nL0, nL1, nL2);
             RR2_CREC_ISSUE(bx0 + 64);
-#define RR2_STEPC(U, Q)                                                                                              \
+#define RR2_STEPC(U)                                                                                                 \
     do {                                                                                                             \
         const int li_ = bpos + (U);                                                                                  \
         rr2_f2 v_;                                                                                                   \
         RR2_COST(RR_READLANE(cR0, li_), RR_READLANE(cR1, li_), RR_READLANE(cR2, li_), RR_READLANE(cL0, li_),         \
                  RR_READLANE(cL1, li_), RR_READLANE(cL2, li_), v_);                                                  \
-        RR2_PUSH_D(Q, v_);                                                                                           \
-        RR2_EMIT_D(Q);                                                                                               \
+        RR2_PUSH(v_);                                                                                                \
+        RR2_EMIT(pos + (U), w1);                                                                                     \
     } while (0)
             for (; j + RR2_PF <= hi; j += RR2_PF) {
                 RR2_REC_ADVANCE("");
                 RR2_CREC_NEXT("");
-                {
-                    RR2_DECODE4(pos);
-                    RR2_STEPC(0, 0); RR2_STEPC(1, 1); RR2_STEPC(2, 2); RR2_STEPC(3, 3);
-                }
-                {
-                    RR2_DECODE4(pos + 4);
-                    RR2_STEPC(4, 0); RR2_STEPC(5, 1); RR2_STEPC(6, 2); RR2_STEPC(7, 3);
-                }
+                RR2_STEPC(0); RR2_STEPC(1); RR2_STEPC(2); RR2_STEPC(3); RR2_STEPC(4); RR2_STEPC(5); RR2_STEPC(6); RR2_STEPC(7);
                 pos += RR2_PF;
                 bpos += RR2_PF;
             }
@@ -516,29 +434,12 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
             pos += RR2_PF;
             // steady state: younger operations = the reissue step's own store + 2 per younger step = 1 + 2*(RR2_PF-1) = 15;
             // wait for <= 14 (one stricter; the bulk record loads only make it more conservative)
-#define RR2_STEP_D(U, Q, WAITN)                                                                                      \
-    do {                                                                                                             \
-        rr2_f2 v_;                                                                                                   \
-        RR2_WAIT_TAKE(v_, pf[U], WAITN);                                                                             \
-        RR2_VLOAD(pf[U], spn);                                                                                       \
-        spn += fstep;                                                                                                \
-        RR2_PUSH_D(Q, v_);                                                                                           \
-        RR2_EMIT_D(Q); /* exactly one compiler-issued vector-memory operation (a store) */                           \
-    } while (0)
             for (; j + 2 * RR2_PF <= hi; j += RR2_PF) {
                 RR2_REC_ADVANCE("");
-                {
-                    RR2_DECODE4(pos);
-                    RR2_STEP_D(0, 0, 14); RR2_STEP_D(1, 1, 14); RR2_STEP_D(2, 2, 14); RR2_STEP_D(3, 3, 14);
-                }
-                {
-                    RR2_DECODE4(pos + 4);
-                    RR2_STEP_D(4, 0, 14); RR2_STEP_D(5, 1, 14); RR2_STEP_D(6, 2, 14); RR2_STEP_D(7, 3, 14);
-                }
+                RR2_STEP(0, 14); RR2_STEP(1, 14); RR2_STEP(2, 14); RR2_STEP(3, 14); RR2_STEP(4, 14); RR2_STEP(5, 14); RR2_STEP(6, 14); RR2_STEP(7, 14);
                 pos += RR2_PF;
             }
 #undef RR2_STEP
-#undef RR2_STEP_D
             // drain: the RR2_PF entries still in flight are entries j .. j+RR2_PF-1 (all < hi)
             RR2_REC_ADVANCE(RR_WAIT_ALL_STR);
             rr2_f2 df[RR2_PF];
@@ -597,9 +498,6 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
 #undef RR2_SLOT
 #undef RR2_PUSH
 #undef RR2_EMIT
-#undef RR2_DECODE4
-#undef RR2_PUSH_D
-#undef RR2_EMIT_D
 }
 
 // A wave = one CHUNK of the flattened output index space (line-major: line * N + m), chunk_len outputs: one piece when the
