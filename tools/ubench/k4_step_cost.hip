@@ -137,8 +137,9 @@ static void run_mode(const char* name, long long* dcyc, float* dbuf, const uint3
         CK(hipMemcpy(c, dcyc, sizeof(c), hipMemcpyDeviceToHost));
         double s = 0;
         for (int w = 0; w < waves; w++) s += (double)c[w];
-        // s_memtime counts at a constant 100 MHz on gfx9: report in ns and in core cycles at an assumed 2.4 GHz
-        printf("   %d waves/SIMD: %8.1f ns/iter/wave (%6.0f cycles @2.4GHz)", waves / 4, s / waves / n * 10.0, s / waves / n * 10.0 * 2.4);
+        // s_memtime ticks (the shader clock counter on this chip: the first run, which took a tick for 10 ns, printed ten times
+        // these figures as "ns" -- profiles/r4_ubench_k4_step_cost.txt; the whole step of the real kernel takes ~450 ns)
+        printf("   %d waves/SIMD: %8.1f ticks/iter/wave", waves / 4, s / waves / n);
     }
     printf("\n");
 }
@@ -156,7 +157,7 @@ int main()
     CK(hipMalloc(&drec, sizeof(rec)));
     CK(hipMemcpy(drec, rec, sizeof(rec), hipMemcpyHostToDevice));
     const int n = 20000;
-    printf("one workgroup on one CU; s_memtime (100 MHz) -> ns per iteration and wave\n");
+    printf("one workgroup on one CU; s_memtime ticks per iteration and wave\n");
     run_mode<0>("push", dcyc, dbuf, drec, n);
     run_mode<1>("adds14", dcyc, dbuf, drec, n);
     run_mode<2>("adds14_idx", dcyc, dbuf, drec, n);
