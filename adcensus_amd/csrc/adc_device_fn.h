@@ -121,31 +121,6 @@ ADC_HD void adc_so_class_offsets_interior(const uint32_t* rb, int c1byte, int ts
     }
 }
 
-// ---- interpolation with rays as the unit of work (experimental: tools/experiments/interp_ray_refill.patch; CPU emulation in
-// tests/emul/emul.cpp).  The 16 first hits of a target are combined by an order-independent minimum of a key:
-//   mismatch list  (colour-nearest hit, FIRST minimum in ray order, multistep_refiner.cpp:276-289):
-//                  key = (L1 colour distance * 16 + ray) << 32 | bits of the hit's disparity     (distance <= 765)
-//   occlusion list (smallest disparity, :290-296): key = the disparity's bits mapped so that unsigned order == float order
-// "no ray hit" = the initial all-ones key (fill value 0, :246,270-272).
-ADC_HD uint32_t adc_f32_bits(float v) { uint32_t b; __builtin_memcpy(&b, &v, 4); return b; }
-ADC_HD float adc_f32_from_bits(uint32_t b) { float v; __builtin_memcpy(&v, &b, 4); return v; }
-ADC_HD uint32_t adc_f32_ordered(float v)
-{
-    if (v == 0.0f) v = 0.0f; // -0 and +0 compare equal: one key (the sequential scan keeps the first of equal values: same value)
-    const uint32_t b = adc_f32_bits(v);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-ADC_HD float adc_f32_from_ordered(uint32_t k) { return adc_f32_from_bits((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
-ADC_HD uint64_t adc_itp_key(bool mismatch, int dist, int ray, float hit)
-{
-    return mismatch ? (((uint64_t)(uint32_t)(dist * 16 + ray) << 32) | adc_f32_bits(hit)) : (uint64_t)adc_f32_ordered(hit);
-}
-ADC_HD float adc_itp_fill_from_key(bool mismatch, uint64_t key)
-{
-    if (key == ~(uint64_t)0) return 0.0f;
-    return mismatch ? adc_f32_from_bits((uint32_t)key) : adc_f32_from_ordered((uint32_t)key);
-}
-
 // ---- scanline prefetch geometry (k_scanline.hip; checked exhaustively on the CPU: tests/test_emul.py) ----
 // Byte offset into the right-image colour-step map of the VPL bytes the path element at coordinate m needs (m = x on a row
 // path, y on a column path; `path` = the row / column; cl_last = dmin + the lane's LAST disparity index, so xr = x - cl_last is
@@ -305,72 +280,6 @@ ADC_HD float adc_median9(float v0, float v1, float v2, float v3, float v4, float
     const float lo2 = adc_min3(v3, v4, v5), me2 = adc_med3(v3, v4, v5), hi2 = adc_max3(v3, v4, v5);
     const float lo3 = adc_min3(v6, v7, v8), me3 = adc_med3(v6, v7, v8), hi3 = adc_max3(v6, v7, v8);
     return adc_med3(adc_max3(lo1, lo2, lo3), adc_med3(me1, me2, me3), adc_min3(hi1, hi2, hi3));
-}
-
-// One pixel of one local round of the tiled chaotic form of the in-place median (used by the experimental kernel of
-// tools/experiments/median_blocked_jacobi.patch and by its CPU emulation, tests/emul/emul.cpp).  A = current iterate of the
-// snapshot (rows y0 .., columns x0 .. x1-1, pitch pa), U = unfiltered map (rows y0 .. y1, columns x0-1 .. x1, pitch pu; positions
-// outside the image hold anything: they are substituted here).  (ly, lx) = position in the snapshot, w = its width.
-// Pixels on a cut edge of the snapshot (not on the image border) keep their value; elsewhere the window takes the iterate at
-// the four raster-earlier neighbours and the unfiltered map at the other five, a missing side-centre neighbour counting as
-// -inf and a missing corner neighbour as +inf (= the reference's wnd[n/2] of the in-image values, see adc_median9).
-ADC_HD float adc_medj_pixel(const float* A, int pa, const float* U, int pu, int ly, int lx, int w, int y0, int x0, int x1, int W, int H)
-{
-    if ((ly == 0 && y0 > 0) || (lx == 0 && x0 > 0) || (lx == w - 1 && x1 < W)) return A[ly * pa + lx];
-    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
-    const int gy = y0 + ly, gx = x0 + lx;
-    const bool up = gy > 0, dn = gy + 1 < H, lf = gx > 0, rt = gx + 1 < W;
-    const float v0 = (up && lf) ? A[(ly - 1) * pa + lx - 1] : PINF, v1 = up ? A[(ly - 1) * pa + lx] : NINF;
-    const float v2 = (up && rt) ? A[(ly - 1) * pa + lx + 1] : PINF, v3 = lf ? A[ly * pa + lx - 1] : NINF;
-    const float v4 = U[ly * pu + lx + 1], v5 = rt ? U[ly * pu + lx + 2] : NINF; // U's column index is lx + 1
-    const float v6 = (dn && lf) ? U[(ly + 1) * pu + lx] : PINF, v7 = dn ? U[(ly + 1) * pu + lx + 1] : NINF;
-    const float v8 = (dn && rt) ? U[(ly + 1) * pu + lx + 2] : PINF;
-    return adc_median9(v0, v1, v2, v3, v5, v6, v7, v8, v4);
-}
-
-// The same for a snapshot that does not touch the image border (y0 > 0, y1 < H, x0 > 0, x1 < W): every pixel that is not held
-// has all eight neighbours inside the image, no substitutions.
-ADC_HD float adc_medj_pixel_interior(const float* A, int pa, const float* U, int pu, int ly, int lx, int w)
-{
-    if (ly == 0 || lx == 0 || lx == w - 1) return A[ly * pa + lx];
-    const float* a = A + (ly - 1) * pa + lx;
-    const float* u = U + ly * pu + lx + 1; // U's column index is lx + 1
-    return adc_median9(a[-1], a[0], a[1], a[pa - 1], u[1], u[pu - 1], u[pu], u[pu + 1], u[0]);
-}
-
-// ---- second form of the tiled median (experimental: tools/experiments/median_tiles_v2.patch): maps padded by ONE ring ----
-// The maps are stored with one ring of cells around the image (pitch W + 2, H + 2 rows; pixel (x, y) at (x + 1, y + 1)).  The ring
-// holds a pattern of period 3 along each edge -- cell index % 3 == 0: -inf, else +inf -- so that among the three ring neighbours of
-// an edge pixel exactly one counts below and two above every value: the PLAIN median of the nine cells then equals the
-// reference's window rule (a missing side-centre neighbour = -inf, a missing corner neighbour = +inf).  Only the four image
-// corner pixels, which miss five neighbours, keep the explicit rule (adc_medp_corner).  Checked on the CPU for every residue
-// of W and H modulo 3 (tests/test_emul.py, tools/median_rounds.py ring_padded).
-ADC_HD float adc_medp_ring_value(int idx_along_edge) { return (idx_along_edge % 3 == 0) ? -ADC_INVALID_FLOAT : ADC_INVALID_FLOAT; }
-// value of the padded cell (px, py) of a W x H image when it is a ring cell (px == 0, px == W + 1, py == 0 or py == H + 1);
-// the four ring corners belong to the horizontal edges (their value is never used by the plain form: only corner pixels see them)
-ADC_HD float adc_medp_ring_cell(int px, int py, int W, int H)
-{
-    if (py == 0 || py == H + 1) return (px >= 1 && px <= W) ? adc_medp_ring_value(px - 1) : ADC_INVALID_FLOAT;
-    return adc_medp_ring_value(py - 1);
-}
-// plain form: C = iterate, U = unfiltered map, both padded with pitch `pitch`; (lx, ly) addresses the pixel inside the arrays
-ADC_HD float adc_medp_pixel(const float* C, const float* U, int pitch, int ly, int lx)
-{
-    const float* c = C + (ly - 1) * pitch + lx;
-    const float* u = U + ly * pitch + lx;
-    return adc_median9(c[-1], c[0], c[1], c[pitch - 1], u[1], u[pitch - 1], u[pitch], u[pitch + 1], u[0]);
-}
-// the four image corner pixels: explicit substitution (up / lf = the pixel has a row above / a column to its left; a corner
-// pixel misses exactly one of each pair: up XOR dn, lf XOR rt)
-ADC_HD float adc_medp_corner(const float* C, const float* U, int pitch, int ly, int lx, bool up, bool lf)
-{
-    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
-    const bool dn = !up, rt = !lf;
-    const float* c = C + (ly - 1) * pitch + lx;
-    const float* u = U + ly * pitch + lx;
-    const float v0 = (up && lf) ? c[-1] : PINF, v1 = up ? c[0] : NINF, v2 = (up && rt) ? c[1] : PINF, v3 = lf ? c[pitch - 1] : NINF;
-    const float v5 = rt ? u[1] : NINF, v6 = (dn && lf) ? u[pitch - 1] : PINF, v7 = dn ? u[pitch] : NINF, v8 = (dn && rt) ? u[pitch + 1] : PINF;
-    return adc_median9(v0, v1, v2, v3, v5, v6, v7, v8, u[0]);
 }
 
 // Sorts v[0..8] ascending (25 compare-exchanges, optimal-size network for n=9).

@@ -681,127 +681,6 @@ int emul_so_chunk_predicate_check(void)
                         }
     return bad;
 }
-// Tiled chaotic form of the in-place median: one "kernel" = every tile once, in the given order, T local rounds on a snapshot
-// with a halo of T (top, left, right), cores written back in place; src = inp for the first kernel, cur afterwards.  Same loads
-// (clamped reads of the unfiltered map) and the same per-pixel function as the experimental HIP kernel.  Returns the number of
-// core pixels the kernel changed.
-int emul_median_tiles(const float* inp, float* cur, int W, int H, int S, int T, int first, const int* order, int ntiles)
-{
-    const int tw = (W + S - 1) / S;
-    int changed = 0;
-    std::vector<float> A[2], U;
-    for (int t = 0; t < ntiles; t++) {
-        const int tx = (order[t] % tw) * S, ty = (order[t] / tw) * S;
-        const int y0 = ty - T > 0 ? ty - T : 0, x0 = tx - T > 0 ? tx - T : 0;
-        const int y1 = ty + S < H ? ty + S : H, x1 = tx + S + T < W ? tx + S + T : W;
-        const int h = y1 - y0, w = x1 - x0, pa = S + 2 * T + 1, pu = pa + 2;
-        const float* src = first ? inp : cur;
-        A[0].assign((size_t)(S + T) * pa, 0.f);
-        A[1].assign((size_t)(S + T) * pa, 0.f);
-        U.assign((size_t)(S + T + 1) * pu, 0.f);
-        for (int ly = 0; ly < h; ly++)
-            for (int lx = 0; lx < w; lx++) A[0][(size_t)ly * pa + lx] = src[(size_t)(y0 + ly) * W + x0 + lx];
-        for (int ly = 0; ly < h + 1; ly++)
-            for (int lx = 0; lx < w + 2; lx++) {
-                const int gy = y0 + ly < H ? y0 + ly : H - 1, gx0 = x0 - 1 + lx, gx = gx0 < 0 ? 0 : (gx0 < W ? gx0 : W - 1);
-                U[(size_t)ly * pu + lx] = inp[(size_t)gy * W + gx];
-            }
-        int a = 0;
-        const bool inner = y0 > 0 && y1 < H && x0 > 0 && x1 < W; // the snapshot does not touch the image border
-        for (int r = 0; r < T; r++) {
-            for (int ly = 0; ly < h; ly++)
-                for (int lx = 0; lx < w; lx++)
-                    A[a ^ 1][(size_t)ly * pa + lx] = inner ? adc_medj_pixel_interior(A[a].data(), pa, U.data(), pu, ly, lx, w)
-                                                           : adc_medj_pixel(A[a].data(), pa, U.data(), pu, ly, lx, w, y0, x0, x1, W, H);
-            a ^= 1;
-        }
-        for (int cy = 0; cy < S; cy++)
-            for (int cx = 0; cx < S; cx++) {
-                const int gy = ty + cy, gx = tx + cx;
-                if (gy < H && gx < W) {
-                    const float v = A[a][(size_t)(gy - y0) * pa + gx - x0];
-                    const size_t q = (size_t)gy * W + gx;
-                    uint32_t b0, b1;
-                    memcpy(&b0, &v, 4);
-                    memcpy(&b1, &src[q], 4);
-                    changed += b0 != b1;
-                    cur[q] = v;
-                }
-            }
-    }
-    return changed;
-}
-// Second form of the tiled median: maps padded by one ring (adc_medp_*), every tile interior, tiles skipped while their 3x3
-// neighbourhood is quiet.  One call = one kernel: every tile in the given order; a tile runs if first != 0 or one of the 3x3 tiles
-// around it changed in the previous kernel (flags_prev), takes its snapshot from the padded iterate `cur` (kernel 0: from the
-// padded unfiltered map `inp`), runs T local rounds -- the snapshot's first row, first and last column are never computed (a cut
-// edge or the ring) -- and writes its core back in place.  flags_out[t] = the tile changed a value.  Returns changed tiles.
-int emul_median_tiles_padded(const float* inp_p, float* cur_p, int W, int H, int S, int T, int first, const int* order, int ntiles,
-                             const uint8_t* flags_prev, uint8_t* flags_out)
-{
-    const int tw = (W + S - 1) / S, th = (H + S - 1) / S, Wp = W + 2;
-    int nchanged = 0;
-    std::vector<float> A[2], U;
-    for (int t = 0; t < ntiles; t++) flags_out[t] = 0;
-    for (int oi = 0; oi < ntiles; oi++) {
-        const int t = order[oi], txi = t % tw, tyi = t / tw;
-        bool run = first != 0;
-        for (int dy = -1; dy <= 1 && !run; dy++)
-            for (int dx = -1; dx <= 1; dx++) {
-                const int yy = tyi + dy, xx = txi + dx;
-                if (yy >= 0 && yy < th && xx >= 0 && xx < tw && flags_prev[yy * tw + xx]) run = true;
-            }
-        if (!run) continue;
-        const int tx = txi * S, ty = tyi * S;
-        const int py0 = ty + 1 - T > 0 ? ty + 1 - T : 0, px0 = tx + 1 - T > 0 ? tx + 1 - T : 0;
-        const int py1 = ty + 1 + (S < H - ty ? S : H - ty), px1 = tx + 1 + S + T < W + 2 ? tx + 1 + S + T : W + 2; // exclusive
-        const int h = py1 - py0, w = px1 - px0;
-        const float* src = first ? inp_p : cur_p;
-        A[0].assign((size_t)h * w, 0.f);
-        A[1].assign((size_t)h * w, 0.f);
-        U.assign((size_t)(h + 1) * w, 0.f);
-        for (int ly = 0; ly < h; ly++)
-            for (int lx = 0; lx < w; lx++) A[0][(size_t)ly * w + lx] = A[1][(size_t)ly * w + lx] = src[(size_t)(py0 + ly) * Wp + px0 + lx];
-        for (int ly = 0; ly < h + 1; ly++)
-            for (int lx = 0; lx < w; lx++) U[(size_t)ly * w + lx] = inp_p[(size_t)(py0 + ly) * Wp + px0 + lx];
-        int a = 0;
-        for (int r = 0; r < T; r++) {
-            for (int ly = 1; ly < h; ly++)
-                for (int lx = 1; lx < w - 1; lx++) {
-                    const int gx = px0 + lx - 1, gy = py0 + ly - 1; // image coordinates
-                    const bool cx = gx == 0 || gx == W - 1, cy = gy == 0 || gy == H - 1;
-                    A[a ^ 1][(size_t)ly * w + lx] = (cx && cy) ? adc_medp_corner(A[a].data(), U.data(), w, ly, lx, gy > 0, gx > 0)
-                                                               : adc_medp_pixel(A[a].data(), U.data(), w, ly, lx);
-                }
-            a ^= 1;
-        }
-        bool changed = false;
-        for (int cy = 0; cy < S; cy++)
-            for (int cx = 0; cx < S; cx++) {
-                const int gy = ty + cy, gx = tx + cx;
-                if (gy < H && gx < W) {
-                    const float v = A[a][(size_t)(gy + 1 - py0) * w + gx + 1 - px0];
-                    const size_t q = (size_t)(gy + 1) * Wp + gx + 1;
-                    uint32_t b0, b1;
-                    memcpy(&b0, &v, 4);
-                    memcpy(&b1, &src[q], 4);
-                    changed = changed || b0 != b1;
-                    cur_p[q] = v;
-                }
-            }
-        flags_out[t] = changed ? 1 : 0;
-        nchanged += changed ? 1 : 0;
-    }
-    return nchanged;
-}
-// padded copy of a map with the ring pattern (what the pad kernel writes)
-void emul_median_pad(const float* in, float* out_p, int W, int H)
-{
-    for (int py = 0; py < H + 2; py++)
-        for (int px = 0; px < W + 2; px++)
-            out_p[(size_t)py * (W + 2) + px] = (px == 0 || px == W + 1 || py == 0 || py == H + 1) ? adc_medp_ring_cell(px, py, W, H)
-                                                                                              : in[(size_t)(py - 1) * W + px - 1];
-}
 int emul_scanline_pass_chunked(const float* src, float* dst, const uint8_t* cd_left, const uint8_t* cd_right, int W, int H,
                                int dmin, int D, int vert, int dir, int tso, float p1, float p2)
 {
@@ -1126,110 +1005,6 @@ long emul_interpolate_skip(const float* din, float* dout, const uint8_t* label, 
         }
     if (plain_lookups) *plain_lookups = plain;
     return lookups;
-}
-
-// ------------------------------------------------------------------ interpolation with rays as the unit of work
-// A wave = 64 lanes over a contiguous range of ray ids (id = list entry * 16 + ray).  Every round trip the lanes whose ray has
-// ended take the next ids of the range (in lane order, like a ballot + prefix count would hand them out), then every active
-// lane evaluates NS steps with the same skipping as emul_interpolate_skip; a hit goes into the target's accumulator by
-// minimum of adc_itp_key.  `wave_rays` rays per wave; the waves run in the given order (any order gives the same result).
-// Returns the number of wave round trips (the statistic the form is about).
-long emul_interpolate_refill_mode(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
-                                  int max_search, int NS, int wave_rays, unsigned seed, int static_lanes);
-long emul_interpolate_refill(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
-                             int max_search, int NS, int wave_rays, unsigned seed)
-{
-    return emul_interpolate_refill_mode(din, dout, label, img_l, W, H, which, max_search, NS, wave_rays, seed, 0);
-}
-// static_lanes != 0: lane l of a wave walks the rays base + l, base + l + 64, ... of its range (every lane knows its next ray in
-// advance, so its record can be prefetched while the current ray is walked) instead of taking the next free id by ballot
-long emul_interpolate_refill_mode(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
-                                  int max_search, int NS, int wave_rays, unsigned seed, int static_lanes)
-{
-    double sc[32];
-    const float pi = 3.1415926f;
-    double ang = 0.0;
-    for (int s = 0; s < 16; s++) { sc[2 * s] = sin(ang); sc[2 * s + 1] = cos(ang); ang += pi / 16; }
-    const int cw = (W + ADC_ITP_CELL - 1) / ADC_ITP_CELL, ch = (H + ADC_ITP_CELL - 1) / ADC_ITP_CELL;
-    std::vector<uint8_t> cell((size_t)cw * ch), rowd((size_t)cw * ch), cdist((size_t)cw * ch);
-    for (int cy = 0; cy < ch; cy++)
-        for (int cx = 0; cx < cw; cx++) {
-            bool any = false;
-            for (int r = 0; r < ADC_ITP_CELL; r++)
-                for (int q = 0; q < ADC_ITP_CELL; q++) {
-                    const int y = cy * ADC_ITP_CELL + r, x = cx * ADC_ITP_CELL + q;
-                    if (y < H && x < W) any = any || din[(size_t)y * W + x] != ADC_INVALID_FLOAT;
-                }
-            cell[(size_t)cy * cw + cx] = any ? 1 : 0;
-        }
-    for (int c = 0; c < cw * ch; c++) rowd[c] = (uint8_t)adc_itp_rowdist(cell.data(), cw, c % cw, c / cw);
-    for (int c = 0; c < cw * ch; c++) cdist[c] = (uint8_t)adc_itp_coldist(rowd.data(), cw, ch, c % cw, c / cw);
-    const bool mismatch = which == ADC_LABEL_MISMATCH;
-    std::vector<int> list;
-    for (int p = 0; p < W * H; p++) {
-        dout[p] = din[p];
-        if (label[p] == which && din[p] == ADC_INVALID_FLOAT) list.push_back(p);
-    }
-    const long nrays = (long)list.size() * 16;
-    std::vector<uint64_t> acc(list.size(), ~(uint64_t)0);
-    const long nwaves = (nrays + wave_rays - 1) / wave_rays;
-    std::vector<long> order(nwaves);
-    for (long i = 0; i < nwaves; i++) order[i] = i;
-    srand(seed);
-    for (long i = nwaves - 1; i > 0; i--) std::swap(order[i], order[rand() % (i + 1)]);
-    long trips = 0;
-    struct Lane { bool active; long id; int m; };
-    for (long wv = 0; wv < nwaves; wv++) {
-        long next = order[wv] * wave_rays;
-        const long end = std::min(nrays, next + wave_rays);
-        Lane lane[64];
-        for (int l = 0; l < 64; l++) lane[l].active = false;
-        long lane_next[64];
-        for (int l = 0; l < 64; l++) lane_next[l] = next + l;
-        while (true) {
-            for (int l = 0; l < 64; l++) // refill in lane order
-                if (!lane[l].active && (static_lanes ? lane_next[l] < end : next < end)) {
-                    lane[l].active = true;
-                    if (static_lanes) { lane[l].id = lane_next[l]; lane_next[l] += 64; }
-                    else lane[l].id = next++;
-                    const int p = list[lane[l].id >> 4], y = p / W, x = p - y * W;
-                    lane[l].m = 1 + adc_itp_skip(cdist[(size_t)(y / ADC_ITP_CELL) * cw + x / ADC_ITP_CELL]);
-                    if (lane[l].m >= max_search) lane[l].active = false, l--; // (search range exhausted before the first step: next ray)
-                }
-            bool any = false;
-            for (int l = 0; l < 64; l++) any = any || lane[l].active;
-            if (!any) break;
-            trips++;
-            for (int l = 0; l < 64; l++) {
-                if (!lane[l].active) continue;
-                const long e = lane[l].id >> 4;
-                const int s = (int)(lane[l].id & 15), p = list[e], y = p / W, x = p - y * W;
-                const double sina = sc[2 * s], cosa = sc[2 * s + 1];
-                int m = lane[l].m, cl = 0;
-                bool walking = true;
-                for (int j = 0; j < NS && walking; j++) {
-                    if (m + j >= max_search) { walking = false; break; }
-                    const int yy = (int)lround((double)y + (double)(m + j) * sina), xx = (int)lround((double)x + (double)(m + j) * cosa);
-                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) { walking = false; break; }
-                    const float d = din[(size_t)yy * W + xx];
-                    if (d != ADC_INVALID_FLOAT) {
-                        const size_t q = (size_t)yy * W + xx;
-                        const int dist = mismatch ? adc_color_dist_l1(img_l + (size_t)p * 3, img_l + q * 3) : 0;
-                        const uint64_t key = adc_itp_key(mismatch, dist, s, d);
-                        acc[e] = key < acc[e] ? key : acc[e];
-                        walking = false;
-                        break;
-                    }
-                    if (j == NS - 1) cl = cdist[(size_t)(yy / ADC_ITP_CELL) * cw + xx / ADC_ITP_CELL];
-                }
-                m += NS + adc_itp_skip(cl);
-                lane[l].m = m;
-                if (!walking || m >= max_search) lane[l].active = false;
-            }
-        }
-    }
-    for (size_t e = 0; e < list.size(); e++) dout[list[e]] = adc_itp_fill_from_key(mismatch, acc[e]);
-    return trips;
 }
 
 // ------------------------------------------------------------------ k_median_wavefront

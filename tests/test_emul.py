@@ -536,35 +536,6 @@ def test_interpolation_skipping_is_exact(emul, seed, density, ns):
             assert n < 0.6 * plain.value, (n, plain.value)   # the sparse band is crossed in jumps
 
 
-@pytest.mark.parametrize("seed,density,negative", [(1, 0.003, False), (2, 0.02, True), (3, 0.25, False), (6, 0.0, False), (7, 0.05, True)])
-def test_interpolation_with_rays_as_the_unit_of_work(emul, seed, density, negative):
-    """The ray-refill form (adc_itp_key in adc_device_fn.h): lanes take the next ray of the list as soon as theirs has
-    ended, the 16 first hits of a target are combined by an order-independent minimum of a key -- same fills as the plain walk
-    for both rules (colour-nearest with the first minimum in ray order; smallest disparity, also with negative disparities and
-    equal values), for any number of rays per wave and any wave order; and far fewer wave round trips than 4 targets per wave."""
-    rng = np.random.default_rng(seed)
-    w, h, ms = 157, 83, 96
-    valid = rng.random((h, w)) < density
-    valid[:, 100:] |= rng.random((h, w - 100)) < 0.3
-    vals = rng.integers(-40 if negative else 0, 90, (h, w)).astype(np.float32) + (rng.integers(0, 4, (h, w)) / 4).astype(np.float32)
-    disp = np.where(valid, vals, np.float32(np.inf)).astype(np.float32)
-    label = rng.integers(0, 3, (h, w)).astype(np.uint8)
-    img = rng.integers(0, 40, (h, w, 3), dtype=np.uint8)  # few colours: equal colour distances are common (first-minimum rule)
-    emul.emul_interpolate_refill.restype = C.c_long
-    for which in (1, 2):
-        want = np.empty((h, w), np.float32)
-        emul.emul_interpolate(P(disp), P(want), P(label), P(img), w, h, which, ms)
-        trips = {}
-        for wave_rays, sd in ((64, 1), (1024, 2), (4096, 3)):
-            got = np.empty((h, w), np.float32)
-            trips[wave_rays] = emul.emul_interpolate_refill(P(disp), P(got), P(label), P(img), w, h, which, ms, 4, wave_rays, sd)
-            assert same(got, want), (which, wave_rays)
-        n = int(((label == which) & ~valid).sum())
-        if n > 1000 and density <= 0.05:
-            # 64 rays per wave = the present binding of 4 targets to a wave; a long queue per wave needs far fewer trips
-            assert trips[4096] < 0.7 * trips[64], trips
-
-
 def test_voting_packed_halfword_helpers(emul):
     """irv_plan.h: irv_decode_block (eligible / final / invalid-bin / same-bin masks of 8 packed state halfwords by SWAR
     carries) and the change-tile row test (byte masks from a nibble expansion, any-zero-byte trick) agree with per-pixel
@@ -572,96 +543,3 @@ def test_voting_packed_halfword_helpers(emul):
     emul.emul_irv_swar_check.restype = C.c_long
     for seed in (1, 2):
         assert emul.emul_irv_swar_check(seed, C.c_long(1000000)) == 0
-
-
-@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_30x7_d8", "q_9x20_d8", "q_1x40_d8", "q_40x1_d8", "s2_150x100_neg"])
-def test_median_as_asynchronous_blocked_iteration(dumps, name):
-    """The recursive (in-place) 3x3 median is a triangular system: plain Jacobi rounds, and tiles that run T local rounds on a
-    snapshot with a halo of T (top, left, right) and write their cores back in place in ANY order, both end in the reference's
-    in-place result, and a round / kernel that changes nothing proves it (tools/median_rounds.py: the model a tiled median
-    kernel would follow; 1080p noise pair: 55 rounds, 5-8 kernels)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("median_rounds", os.path.join(ROOT, "tools", "median_rounds.py"))
-    mr = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mr)
-    left, right, opt, o = dumps(name)
-    inp, ref = mr.fin(o["disp_after_dda"]), mr.fin(o["disp_final"])
-    if min(inp.shape) < 2:
-        pytest.skip("the median-of-nine form of the window rule needs W, H >= 2 (DESIGN 4.4)")
-    cur, rounds = mr.jacobi(inp)
-    assert np.array_equal(cur, ref) and rounds >= 1
-    for S, T, seed in ((16, 4, 1), (8, 8, 2), (32, 2, 3)):
-        cur, kernels = mr.blocked(inp, S, T, np.random.default_rng(seed))
-        assert np.array_equal(cur, ref), (S, T)
-
-
-@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_30x7_d8", "q_9x20_d8", "q_20x40_d32", "s2_150x100_neg", "cone_crop_d40"])
-def test_median_tiles_device_function(emul, dumps, name):
-    """The per-pixel function of the tiled chaotic median (adc_medj_pixel, the one the experimental kernel calls) with the
-    kernel's loads, tile geometry and write-back, tiles in random order: kernels until one changes nothing, result = the
-    reference's in-place median (with its real +inf "invalid" values)."""
-    left, right, opt, o = dumps(name)
-    inp, ref = np.ascontiguousarray(o["disp_after_dda"]), o["disp_final"]
-    h, w = inp.shape
-    for S, T, seed in ((16, 4, 1), (8, 8, 2), (64, 8, 3)):
-        tw, th = (w + S - 1) // S, (h + S - 1) // S
-        cur = np.zeros_like(inp)
-        rng = np.random.default_rng(seed)
-        kernels = 0
-        while True:
-            order = np.ascontiguousarray(rng.permutation(tw * th).astype(np.int32))
-            ch = emul.emul_median_tiles(P(inp), P(cur), w, h, S, T, 1 if kernels == 0 else 0, P(order), tw * th)
-            kernels += 1
-            assert kernels < 200
-            if ch == 0:
-                break
-        assert same(cur, ref), (S, T, kernels)
-
-
-@pytest.mark.parametrize("shape", [(2, 2), (3, 3), (3, 7), (7, 7), (8, 10), (10, 8), (9, 6), (12, 30), (31, 17), (64, 48), (5, 11)])
-def test_median_ring_padding_reproduces_the_window_rule(shape):
-    """A ring of period-3 values (one -inf, two +inf among any three consecutive cells) around the map lets the PLAIN median of
-    nine reproduce the reference's window rule on the image edges (tools/median_rounds.py ring_padded): what makes every tile of
-    the tiled median an interior tile.  Checked against the explicit substitution rule on random maps incl. invalid (+inf)
-    values, all residues of W and H modulo 3."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("median_rounds", os.path.join(ROOT, "tools", "median_rounds.py"))
-    mr = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mr)
-    h, w = shape
-    rng = np.random.default_rng(h * 100 + w)
-    for trial in range(6):
-        inp = rng.integers(0, 50, (h, w)).astype(np.float32)
-        inp[rng.random((h, w)) < 0.2] = mr.BIG
-        cur = inp.copy()
-        cur[rng.random((h, w)) < 0.5] = np.float32(rng.integers(0, 50))
-        want = mr.F(cur, inp, 0, h, 0, w)
-        got = mr.F_ring(cur, inp)
-        assert np.array_equal(want, got), (shape, trial)
-
-
-@pytest.mark.parametrize("name", ["s2_96x64_d32", "q_30x7_d8", "q_9x20_d8", "q_20x40_d32", "s2_150x100_neg", "cone_crop_d40", "s2_320x180_d128"])
-def test_median_tiles_padded_with_skipping(emul, dumps, name):
-    """Second form of the tiled median (adc_medp_*): ring-padded maps (every tile interior, explicit rule on the four
-    corner pixels only) and tiles that are skipped while their 3x3 neighbourhood was quiet in the previous kernel -- kernels until
-    one changes nothing, result = the reference's in-place median; most tiles are skipped in the later kernels."""
-    left, right, opt, o = dumps(name)
-    inp, ref = np.ascontiguousarray(o["disp_after_dda"]), o["disp_final"]
-    h, w = inp.shape
-    inp_p = np.zeros((h + 2, w + 2), np.float32)
-    emul.emul_median_pad(P(inp), P(inp_p), w, h)
-    for S, T, seed in ((16, 4, 1), (8, 8, 2), (64, 8, 3), (32, 8, 4)):
-        tw, th = (w + S - 1) // S, (h + S - 1) // S
-        cur_p = inp_p.copy()  # (ring in place; the interior is overwritten by kernel 0)
-        rng = np.random.default_rng(seed)
-        flags = [np.zeros(tw * th, np.uint8), np.zeros(tw * th, np.uint8)]
-        kernels, ran = 0, []
-        while True:
-            order = np.ascontiguousarray(rng.permutation(tw * th).astype(np.int32))
-            nch = emul.emul_median_tiles_padded(P(inp_p), P(cur_p), w, h, S, T, 1 if kernels == 0 else 0, P(order), tw * th,
-                                                P(flags[(kernels + 1) & 1]), P(flags[kernels & 1]))
-            kernels += 1
-            assert kernels < 200
-            if nch == 0:
-                break
-        assert same(np.ascontiguousarray(cur_p[1:-1, 1:-1]), ref), (S, T, kernels)

@@ -72,22 +72,6 @@ def main():
         # the fills of this list are written back before the next list is walked (multistep_refiner.cpp:298-303)
         fin = o["disp_after_interp"]
         dmap.ravel()[targets] = fin.ravel()[targets]
-    # the ray-refill form itself (tests/emul/emul.cpp emul_interpolate_refill: lanes take the next ray of their wave's range when
-    # theirs has ended, atomic-minimum combine), both lists, against the reference's map
-    emul_so = os.path.join(ROOT, "tests", "emul", "_build", "libadcensus_emul.so")
-    if os.path.exists(emul_so):
-        emul = C.CDLL(emul_so)
-        emul.emul_interpolate_refill.restype = C.c_long
-        left = np.ascontiguousarray(l)
-        emul.emul_interpolate_refill_mode.restype = C.c_long
-        for rays, static in ((64, 0), (1024, 0), (4096, 0), (4096, 1), (16384, 1)):
-            a, b = o["disp_after_irv"].copy(), np.empty_like(o["disp_after_irv"])
-            t1 = emul.emul_interpolate_refill_mode(P(a), P(b), P(lab), P(left), W, H, 1, D, 4, rays, 1, static)
-            t2 = emul.emul_interpolate_refill_mode(P(b), P(a), P(lab), P(left), W, H, 2, D, 4, rays, 2, static)
-            print("  refill form, %5d rays per wave range, %s%s: wave round trips %d + %d; equals the reference's map: %s"
-                  % (rays, "every lane its own arithmetic sequence of rays (prefetchable)" if static else "next free ray by ballot",
-                     " (= 4 targets bound to a wave, the present kernel)" if rays == 64 else "", t1, t2,
-                     np.array_equal(a.view(np.uint32), o["disp_after_interp"].view(np.uint32))))
 
 
 if __name__ == "__main__":
