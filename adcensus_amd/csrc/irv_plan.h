@@ -15,8 +15,8 @@ enum { IRV_NONE = 0, IRV_BEGIN, IRV_ROUND, IRV_FINAL_WB, IRV_DONE };
 // ctrl layout (int32): state slot s at ctrl[16*s ..]: {did, pass, round, filled_any, n, rounds_total, evals, kdone};
 // accumulator ring at ctrl[IRV_ACC + (k & 63)] (BEGIN: list length; ROUND: "a value changed")
 #define IRV_ACC 64
-// change-count ring at ctrl[IRV_CHG + (k & 63)]: number of values kernel k changed, counted up to IRV_CHG_SAT only (beyond that
-// the exact number does not matter and nobody wants thousands of same-address atomics in a heavy round)
+// change-count ring at ctrl[IRV_CHG + (k & 63)]: number of values kernel k changed (every workgroup adds at most IRV_CHG_SAT:
+// "few or many" is all the plan asks)
 #define IRV_CHG 160
 #define IRV_CHG_SAT 4096
 #define IRV_CTRL_INTS 256

@@ -181,7 +181,7 @@ struct IrvRoundCtx { // wave-uniform values of a ROUND kernel
 // waves round-robin; a vote = cross region as 16-byte row blocks into the wave's LDS histogram, arg-max, ONE 16-bit store.
 // Returns the number of votes this wave evaluated.  (ent = the lane's list entry, mystate = its state word.)
 template <bool SC1>
-__device__ __forceinline__ int irv_pool_and_vote(const IrvRoundCtx& c, bool dirty, int4 ent, uint32_t mystate)
+__device__ __forceinline__ int irv_pool_and_vote(const IrvRoundCtx& c, bool dirty, int4 ent, uint32_t mystate, int& nchg)
 {
     const int wave = c.wave, lane = c.lane, WPB = c.WPB, D = c.D, W = c.W, SP = c.SP, dmin = c.dmin, tpitch = c.tpitch, irv_ts = c.irv_ts;
     const float irv_th = c.irv_th;
@@ -299,9 +299,13 @@ __device__ __forceinline__ int irv_pool_and_vote(const IrvRoundCtx& c, bool dirt
             if (nb != (cur & IRV_BIN_MASK)) {
                 irv_st<SC1>(chg_wr + (uint32_t)((y / IRV_TILE) * tpitch + x / IRV_TILE), (uint8_t)stamp);
                 irv_st<SC1>(acc, 1);
-                // (saturating count of the changes of this kernel: decides whether the NEXT round runs in tail mode; a stale read
-                // only makes the count a little larger)
-                if (__hip_atomic_load(chgcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < IRV_CHG_SAT) atomicAdd(chgcnt, 1);
+                // Count of the changes of this kernel (decides whether the NEXT round runs in tail mode; a TAIL kernel's looks
+                // watch it).  Same-address traffic retires at ~10 ns each: a heavy round changes tens of thousands of values
+                // (the first version counted every change in memory: the structured 1080p chain took 10.5 ms instead of 4.8).
+                // A TAIL kernel changes few values and needs the count at once: one atomic per change.  A regular round counts
+                // per wave in a register; the workgroup adds its total once, at the end of the kernel.
+                if constexpr (SC1) atomicAdd(chgcnt, 1);
+                else nchg++;
             }
         }
     }
@@ -467,7 +471,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     const long B = 64L * NW;
     int32_t* const chgcnt = ctrl + IRV_CHG + (k & 63);
     const IrvRoundCtx rc = {wave, lane, WPB, D, W, SP, dmin, tpitch, irv_ts, irv_th, stamp, hist, pool, pcount, st16, arms32, chg_wr, acc, chgcnt};
-    int evals = 0;
+    __shared__ int wg_changes;
+    if (threadIdx.x == 0) wg_changes = 0; // (ordered before its first use by the barrier of the pool phase)
+    int evals = 0, nchg = 0;
     for (long b0 = 0; b0 < n; b0 += B) {
         const long i = irv_list_index(b0, (int)blockIdx.x, wave, lane, (int)gridDim.x);
         int4 ent = spec;
@@ -491,8 +497,13 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         const bool dirty = i < n && (round == 0 || box) && !(mystate & IRV_FINAL); // final values are never re-evaluated
         IRV_T(2);
         // (a TAIL-mode kernel stores past the L2 from its first round on: the other workgroups' next rounds read those values)
-        if (pl.tail) evals += irv_pool_and_vote<true>(rc, dirty, ent, mystate);
-        else evals += irv_pool_and_vote<false>(rc, dirty, ent, mystate);
+        if (pl.tail) evals += irv_pool_and_vote<true>(rc, dirty, ent, mystate, nchg);
+        else evals += irv_pool_and_vote<false>(rc, dirty, ent, mystate, nchg);
+    }
+    if (!pl.tail) { // the workgroup's changes of a regular round: one atomic (the count saturates: only "few or many" matters)
+        if (lane == 0 && nchg) atomicAdd(&wg_changes, nchg); // (LDS)
+        __syncthreads();
+        if (threadIdx.x == 0 && wg_changes) atomicAdd(chgcnt, adc_imin(wg_changes, IRV_CHG_SAT));
     }
     // TAIL MODE (round 4).  The long tail of a pass is a sequence of rounds in which a handful of values change; as kernels they
     // cost ~8.4 us each (profiles/r4a_irv_chain_structured.txt: 175 of the 350 kernels of a structured 1080p Match) although
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             if (c == seen) break; // (uniform over the workgroup) nothing has changed anywhere since the last look
             seen = c;
             const bool dirty = mine && box && !(st & IRV_FINAL);
-            evals += irv_pool_and_vote<true>(rc, dirty, te, st);
+            evals += irv_pool_and_vote<true>(rc, dirty, te, st, nchg);
         }
     }
     if (lane == 0 && evals) evals_arr[gw] += evals;
