@@ -15,13 +15,9 @@ enum { IRV_NONE = 0, IRV_BEGIN, IRV_ROUND, IRV_FINAL_WB, IRV_DONE };
 // ctrl layout (int32): state slot s at ctrl[16*s ..]: {did, pass, round, filled_any, n, rounds_total, evals, kdone};
 // accumulator ring at ctrl[IRV_ACC + (k & 63)] (BEGIN: list length; ROUND: "a value changed")
 #define IRV_ACC 64
-// change-count ring at ctrl[IRV_CHG + (k & 63)]: number of values kernel k changed (every workgroup adds at most IRV_CHG_SAT:
-// "few or many" is all the plan asks)
-#define IRV_CHG 160
-#define IRV_CHG_SAT 4096
-#define IRV_CTRL_INTS 256
+#define IRV_CTRL_INTS 160
 struct IrvState { int did, pass, round, filled_any, n, rounds, evals, kdone; }; // kdone: index of the kernel that found the chain finished
-struct IrvPlan { int act; IrvState s; int tail; }; // tail: a ROUND in which every workgroup runs further rounds by itself (k_voting.hip)
+struct IrvPlan { int act; IrvState s; };
 
 // One kernel type: kernel k reads the state its predecessor published (slot k & 1) and the predecessor's accumulator.
 //   BEGIN    write the previous pass's fills back, mark the eligible pixels of the next list, build the work list
@@ -29,12 +25,9 @@ struct IrvPlan { int act; IrvState s; int tail; }; // tail: a ROUND in which eve
 //            Change tiles: kernel k stamps (k % 255) + 1 into plane k & 1 and reads the stamps of kernel k-1 in the other
 //            plane -- both known at launch time, so the check can run before the state has arrived.
 //   FINAL_WB write the last pass's fills back (and sum the per-wave evaluation counters into the state's evals)
-// prev_changes: the predecessor's change count (IRV_CHG ring), tail_max: ROUND kernels whose predecessor changed at most this many
-// values run in TAIL mode (0 = never)
-ADC_HD IrvPlan irv_plan_from(IrvState s, int prev, int k, int prev_changes = 0, int tail_max = 0) // s: the published state, prev: the predecessor's accumulator
+ADC_HD IrvPlan irv_plan_from(IrvState s, int prev, int k) // s: the published state, prev: the predecessor's accumulator
 {
     IrvPlan p;
-    p.tail = 0;
     if (s.did == IRV_NONE) {
         p.act = IRV_BEGIN;
         s.pass = 0; s.round = 0; s.filled_any = 0; s.n = 0;
@@ -48,7 +41,6 @@ ADC_HD IrvPlan irv_plan_from(IrvState s, int prev, int k, int prev_changes = 0, 
             p.act = IRV_ROUND;
             s.round++;
             s.filled_any = fa;
-            p.tail = (tail_max > 0 && prev_changes <= tail_max) ? 1 : 0; // few changes: the long tail of the pass
         } else { // a whole round without a change: the pass has converged
             bool fin = false;
             if (s.pass & 1) { // end of an iteration (multistep_refiner.cpp:167-171): nothing filled -> the rest are no-ops
@@ -75,18 +67,11 @@ ADC_HD IrvPlan irv_plan(const int32_t* ctrl, int k)
     const IrvState s = {in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7]};
     return irv_plan_from(s, k > 0 ? ctrl[IRV_ACC + ((k - 1) & 63)] : 0, k);
 }
-ADC_HD IrvPlan irv_plan_tail(const int32_t* ctrl, int k, int tail_max)
-{
-    const int32_t* in = ctrl + 16 * (k & 1);
-    const IrvState s = {in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7]};
-    return irv_plan_from(s, k > 0 ? ctrl[IRV_ACC + ((k - 1) & 63)] : 0, k, k > 0 ? ctrl[IRV_CHG + ((k - 1) & 63)] : 0, tail_max);
-}
 ADC_HD void irv_publish(int32_t* ctrl, int k, const IrvState& s)
 {
     int32_t* out = ctrl + 16 * ((k + 1) & 1);
     out[0] = s.did; out[1] = s.pass; out[2] = s.round; out[3] = s.filled_any; out[4] = s.n; out[5] = s.rounds; out[6] = s.evals; out[7] = s.kdone;
     ctrl[IRV_ACC + ((k + 2) & 63)] = 0;
-    ctrl[IRV_CHG + ((k + 2) & 63)] = 0;
 }
 
 // Work-list layout.  The chain's grid has G workgroups of WPB waves; a batch is B = 64 * WPB * G entries.  Entry i (in the

@@ -76,36 +76,12 @@ __global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arm
     bbox[(size_t)y * W + x] = make_uchar4((unsigned char)ml, (unsigned char)mr, (unsigned char)mla, (unsigned char)mra);
 }
 
-// ------------------------------------------------------------------------------------------- loads / stores of a round
-// SC1 = device-scope accesses (past the non-coherent L2 of the XCD): what a TAIL-mode kernel uses for everything another
-// workgroup may have written DURING this kernel (state map, change tiles, change counter).
-template <bool SC1> __device__ __forceinline__ uint4 irv_ld16(const uint16_t* base, uint32_t off)
-{
-    if constexpr (SC1) {
-        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(base + off);
-        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-    } else {
-        return *reinterpret_cast<const uint4*>(base + off);
-    }
-}
-template <bool SC1> __device__ __forceinline__ uint4 irv_ld16b(const uint8_t* base, uint32_t off) // (16-byte aligned byte offset)
-{
-    return irv_ld16<SC1>(reinterpret_cast<const uint16_t*>(base), off >> 1);
-}
-template <bool SC1, typename T> __device__ __forceinline__ void irv_st(T* p, T v)
-{
-    if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
 // Did a pixel of the tile box [tx0, tx1] x [ty0, ty1] change in the round whose stamp is want4 (replicated byte)?  A
 // tile row of the box = 16 bytes from a dword-aligned column; bytes outside the box are forced non-zero (nk = ~byte
 // mask per dword, from a 16-bit byte-valid mask) before the any-zero-byte test of (word ^ stamp); three tile rows are
 // in flight (rows past ty1 repeat row ty1: harmless duplicates).  One iteration of each loop for arm limits <= 34 and
 // boxes of <= 17 rows.  Not inlined: the round kernel has to stay at 64 VGPRs (8 waves per SIMD, the whole grid
 // co-resident), and inlined the compiler interleaves this with the surrounding code at 80-110.
-template <bool SC1 = false>
 __device__ __forceinline__ bool irv_box_dirty(const uint8_t* __restrict__ chg_rd, int tpitch, int tx0, int tx1, int ty0, int ty1,
                                                         uint32_t want4)
 {
@@ -118,9 +94,9 @@ __device__ __forceinline__ bool irv_box_dirty(const uint8_t* __restrict__ chg_rd
         irv_tile_row_masks(txb, last, nk);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int tyb = ty0; tyb <= ty1; tyb += 3) {
-            const uint4 v0 = irv_ld16b<SC1>(chg_rd, (uint32_t)(adc_imin(tyb + 0, ty1) * tpitch + cb));
-            const uint4 v1 = irv_ld16b<SC1>(chg_rd, (uint32_t)(adc_imin(tyb + 1, ty1) * tpitch + cb));
-            const uint4 v2 = irv_ld16b<SC1>(chg_rd, (uint32_t)(adc_imin(tyb + 2, ty1) * tpitch + cb));
+            const uint4 v0 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 0, ty1) * tpitch + cb));
+            const uint4 v1 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 1, ty1) * tpitch + cb));
+            const uint4 v2 = *reinterpret_cast<const uint4*>(chg_rd + (uint32_t)(adc_imin(tyb + 2, ty1) * tpitch + cb));
             const uint32_t hit = irv_tile_hit(v0.x, nk[0], want4) | irv_tile_hit(v0.y, nk[1], want4) | irv_tile_hit(v0.z, nk[2], want4) |
                                  irv_tile_hit(v0.w, nk[3], want4) | irv_tile_hit(v1.x, nk[0], want4) | irv_tile_hit(v1.y, nk[1], want4) |
                                  irv_tile_hit(v1.z, nk[2], want4) | irv_tile_hit(v1.w, nk[3], want4) | irv_tile_hit(v2.x, nk[0], want4) |
@@ -165,153 +141,6 @@ __device__ __forceinline__ int irv_row_prefix(int v)
 }
 #undef IRV_DPP
 
-struct IrvRoundCtx { // wave-uniform values of a ROUND kernel
-    int wave, lane, WPB, D, W, SP, dmin, tpitch, irv_ts;
-    float irv_th;
-    uint32_t stamp;
-    int* hist;
-    int4* pool;
-    int* pcount;
-    uint16_t* st16;
-    const uint32_t* arms32;
-    uint8_t* chg_wr;
-    int32_t *acc, *chgcnt;
-};
-// Phase 2 + 3 of a round: the dirty entries of the workgroup's waves are pooled in LDS (one barrier) and dealt out to its
-// waves round-robin; a vote = cross region as 16-byte row blocks into the wave's LDS histogram, arg-max, ONE 16-bit store.
-// Returns the number of votes this wave evaluated.  (ent = the lane's list entry, mystate = its state word.)
-template <bool SC1>
-__device__ __forceinline__ int irv_pool_and_vote(const IrvRoundCtx& c, bool dirty, int4 ent, uint32_t mystate, int& nchg)
-{
-    const int wave = c.wave, lane = c.lane, WPB = c.WPB, D = c.D, W = c.W, SP = c.SP, dmin = c.dmin, tpitch = c.tpitch, irv_ts = c.irv_ts;
-    const float irv_th = c.irv_th;
-    const uint32_t stamp = c.stamp;
-    int* const hist = c.hist;
-    int4* const pool = c.pool;
-    int* const pcount = c.pcount;
-    uint16_t* const st16 = c.st16;
-    const uint32_t* const arms32 = c.arms32;
-    uint8_t* const chg_wr = c.chg_wr;
-    int32_t* const acc = c.acc;
-    int32_t* const chgcnt = c.chgcnt;
-    const int sub = lane >> 2, bslot = lane & 3;
-    int evals = 0;
-    // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
-    // consumers find pool item t by a prefix sum over the (<= 16) counts
-    const unsigned long long dm = __ballot(dirty);
-    if (lane == 0) pcount[wave] = __popcll(dm);
-    if (dirty) // {pixel, arms, state | read box << 16, row}
-        pool[wave * 64 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u))] = // (dirty lanes below this one)
-            make_int4(ent.x, ent.y, (int)((mystate & 0xFFFFu) | ((uint32_t)ent.z & 0xFFFF0000u)), ent.w);
-    __syncthreads();
-    const int cnt_l = lane < WPB ? pcount[lane] : 0;
-    const int incl = irv_row_prefix(cnt_l); // inclusive prefix over the first 16 lanes
-    const int excl = incl - cnt_l;
-    const int total = __builtin_amdgcn_readlane(incl, 15);
-    for (int t = wave; t < total; t += WPB) {
-        evals++;
-        const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
-        const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
-        const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
-        const uint32_t pz = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z);
-        const uint32_t cur = pz & 0xFFFFu; // (only this wave writes the entry in this round)
-        const int x = p - y * W;
-        for (int b = lane; b < D; b += 64) hist[b] = 0;
-        bool deps_open = false;
-        const int top = (int)(((uint32_t)armsp >> 16) & 255u), nrows = top + (int)((uint32_t)armsp >> 24) + 1; // region rows y-top .. y+bottom
-        const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
-        // the read box: blocks blkL .. blkR cover the widest row of the region
-        const int blkL = (x - (int)((pz >> 16) & 255u)) >> 3, blkR = (x + (int)(pz >> 24)) >> 3;
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        for (int rbase = 0; rbase < nrows; rbase += 64) {
-            // the H arms of (up to 64) region rows (lane r holds row rbase + r; handed to the row slots with a shuffle) AND
-            // the first 16 rows x 4 blocks of the read box in ONE memory round trip: the arms only decide which pixels of a
-            // block belong to the region (round 4; before, the blocks were requested when the arms had arrived)
-            const int myr = rbase + lane;
-            uint32_t a2 = 0;
-            if (myr < nrows) a2 = arms32[(uint32_t)((y - top + myr) * W + x)];
-            const int rend = adc_imin(nrows - rbase, 64);
-            uint4 vfirst;
-            {
-                const bool in0 = sub < rend && blkL + bslot <= blkR;
-                vfirst = irv_ld16<SC1>(st16, in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own);
-            }
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (int r0 = 0; r0 < rend; r0 += 16) {
-                const int r = r0 + sub;
-                const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
-                const bool rowok = r < rend;
-                const int yt = y - top + rbase + r;
-                const int xl = x - (int)(arm2 & 255u), xr = x + (int)((arm2 >> 8) & 255u);
-                const int b0x = xl >> 3, b1x = xr >> 3;
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (int bo = 0;; bo += 4) { // one iteration unless the read box spans more than 4 blocks
-                    const int blk = blkL + bo + bslot;
-                    const bool use = rowok && blk >= b0x && blk <= b1x;
-                    uint4 v = vfirst;
-                    if (r0 + bo != 0) { // (uniform) loads stay unconditional: masked-out lanes read the entry's own block
-                        const uint32_t addr = rowok && blk <= blkR ? (uint32_t)(yt * SP + blk * 8) : own;
-                        v = irv_ld16<SC1>(st16, addr);
-                    }
-                    // The 8 pixels of the block, decoded as packed halfwords (irv_plan.h: irv_decode_block): which pixels
-                    // count, and do they all fall into ONE bin?
-                    uint32_t okm = 0u;
-                    if (use) {
-                        const IrvBlock bd = irv_decode_block(v.x, v.y, v.z, v.w, blk * 8, xl, xr, yt, y, x);
-                        deps_open = deps_open || bd.open;
-                        okm = bd.okm;
-                        // (same-address LDS atomics serialise: one per lane instead of eight.  Counting the dominant bin in
-                        // registers across the wave was measured too: slower, the extra wave reduction costs more.)
-                        if (okm != 0u && bd.single) {
-                            atomicAdd(&hist[bd.first], __popc(okm));
-                            okm = 0u;
-                        }
-                    }
-                    if (okm != 0u) { // pixels of several bins: one atomic each
-#pragma clang loop unroll(disable)
-                        for (uint32_t m = okm; m != 0u; m &= m - 1u) {
-                            const int q = __ffs((int)m) - 1;
-                            const uint32_t wq = q < 2 ? v.x : (q < 4 ? v.y : (q < 6 ? v.z : v.w));
-                            atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
-                        }
-                    }
-                    if (!__any(rowok && (blkL + bo + 4 <= b1x))) break;
-                }
-            }
-        }
-        // first maximum (lowest bin on ties) and total count (multistep_refiner.cpp:199-209): key = count << 11 | (2047 - bin)
-        int key = 0, cnt = 0;
-        for (int b = lane; b < D; b += 64) {
-            const int hv = hist[b];
-            cnt += hv;
-            key = adc_imax(key, hv > 0 ? ((hv << 11) | (0x7FF - b)) : 0);
-        }
-        key = irv_wave_max(key);
-        cnt = irv_wave_sum(cnt);
-        const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
-        const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-        const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
-        if (lane == 0) {
-            const uint32_t i16 = (uint32_t)(y * SP + x);
-            const uint32_t nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
-            const uint32_t ns = nb | IRV_ELIG | (all_final ? IRV_FINAL : 0u);
-            if (ns != cur) irv_st<SC1>(st16 + i16, (uint16_t)ns); // value and final bit in ONE store
-            if (nb != (cur & IRV_BIN_MASK)) {
-                irv_st<SC1>(chg_wr + (uint32_t)((y / IRV_TILE) * tpitch + x / IRV_TILE), (uint8_t)stamp);
-                irv_st<SC1>(acc, 1);
-                // Count of the changes of this kernel (decides whether the NEXT round runs in tail mode; a TAIL kernel's looks
-                // watch it).  Same-address traffic retires at ~10 ns each: a heavy round changes tens of thousands of values
-                // (the first version counted every change in memory: the structured 1080p chain took 10.5 ms instead of 4.8).
-                // A TAIL kernel changes few values and needs the count at once: one atomic per change.  A regular round counts
-                // per wave in a register; the workgroup adds its total once, at the end of the kernel.
-                if constexpr (SC1) atomicAdd(chgcnt, 1);
-                else nchg++;
-            }
-        }
-    }
-    return evals;
-}
-
 // ------------------------------------------------------------------------------------------- the kernel of the chain
 // Work-list entry: {pixel, arms of the pixel, max left | max right << 8 of its dependency box, row y}.
 // Workgroups of up to 16 waves (blockDim.x = 64 * waves): the dirty entries of a workgroup's waves are
@@ -323,9 +152,8 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                                                 const uint16_t* __restrict__ sup_h, uint16_t* st16, int4* list, uint8_t* chg,
                                                 const uint32_t* __restrict__ bbox32, const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
                                                 int D, int min_region, int chg_bytes, int tpitch, int irv_ts, float irv_th,
-                                                int32_t* __restrict__ evals_arr, int tail_max, int tail_rounds, int tail_t1, int tail_ts)
+                                                int32_t* __restrict__ evals_arr)
 {
-    const long long t_entry = (long long)wall_clock64(); // (s_memrealtime: constant 100 MHz, the same on every XCD -- time base of the tail rounds)
     IRV_TR(8);
     IRV_T(0);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, WPB = blockDim.x >> 6, T = blockDim.x; // (wave: uniform, kept in a scalar register)
@@ -337,7 +165,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     // (The state is fetched with a VECTOR load -- lane l reads word l, lane 8 the accumulator -- because scalar loads return
     // out of order: the kernel-argument loads would wait for it.)
     const int4 spec = list[(size_t)gw * 64 + lane];
-    const int cword = ctrl[lane < 8 ? 16 * (k & 1) + lane : (lane == 8 ? IRV_ACC + ((k + 63) & 63) : IRV_CHG + ((k + 63) & 63))]; // lane 9: changes of kernel k - 1
+    const int cword = ctrl[lane < 8 ? 16 * (k & 1) + lane : IRV_ACC + ((k + 63) & 63)];
     const uint32_t want4 = ((uint32_t)((k + 254) % 255) + 1u) * 0x01010101u; // stamp of kernel k - 1
     const uint32_t stamp = (uint32_t)(k % 255) + 1u;
     const uint8_t* chg_rd = chg + (size_t)((k + 1) & 1) * chg_bytes;
@@ -357,7 +185,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     const IrvState sprev = {__builtin_amdgcn_readlane(cword, 0), __builtin_amdgcn_readlane(cword, 1), __builtin_amdgcn_readlane(cword, 2),
                             __builtin_amdgcn_readlane(cword, 3), __builtin_amdgcn_readlane(cword, 4), __builtin_amdgcn_readlane(cword, 5),
                             __builtin_amdgcn_readlane(cword, 6), __builtin_amdgcn_readlane(cword, 7)};
-    const IrvPlan pl = irv_plan_from(sprev, k > 0 ? __builtin_amdgcn_readlane(cword, 8) : 0, k, k > 0 ? __builtin_amdgcn_readlane(cword, 9) : 0, tail_max);
+    const IrvPlan pl = irv_plan_from(sprev, k > 0 ? __builtin_amdgcn_readlane(cword, 8) : 0, k);
     IRV_T(1);
     if (pl.act != IRV_FINAL_WB && blockIdx.x == 0 && threadIdx.x == 0) irv_publish(ctrl, k, pl.s);
     if (pl.act == IRV_DONE) return;
@@ -468,12 +296,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     int* hist = lds_dyn + wave * D;
     int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * D + 3) & ~3)); // (16-byte aligned whatever D is)
     __shared__ int pcount[IRV_MAXW];
+    const int sub = lane >> 2, bslot = lane & 3;
     const long B = 64L * NW;
-    int32_t* const chgcnt = ctrl + IRV_CHG + (k & 63);
-    const IrvRoundCtx rc = {wave, lane, WPB, D, W, SP, dmin, tpitch, irv_ts, irv_th, stamp, hist, pool, pcount, st16, arms32, chg_wr, acc, chgcnt};
-    __shared__ int wg_changes;
-    if (threadIdx.x == 0) wg_changes = 0; // (ordered before its first use by the barrier of the pool phase)
-    int evals = 0, nchg = 0;
+    int evals = 0;
     for (long b0 = 0; b0 < n; b0 += B) {
         const long i = irv_list_index(b0, (int)blockIdx.x, wave, lane, (int)gridDim.x);
         int4 ent = spec;
@@ -496,63 +321,115 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         if (round == 0 && b0 == 0 && i >= n && ent.x != IRV_LIST_END) list[(size_t)gw * 64 + lane].x = IRV_LIST_END;
         const bool dirty = i < n && (round == 0 || box) && !(mystate & IRV_FINAL); // final values are never re-evaluated
         IRV_T(2);
-        // (a TAIL-mode kernel stores past the L2 from its first round on: the other workgroups' next rounds read those values)
-        if (pl.tail) evals += irv_pool_and_vote<true>(rc, dirty, ent, mystate, nchg);
-        else evals += irv_pool_and_vote<false>(rc, dirty, ent, mystate, nchg);
-    }
-    if (!pl.tail) { // the workgroup's changes of a regular round: one atomic (the count saturates: only "few or many" matters)
-        if (lane == 0 && nchg) atomicAdd(&wg_changes, nchg); // (LDS)
+        // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
+        // consumers find pool item t by a prefix sum over the (<= 16) counts
+        const unsigned long long dm = __ballot(dirty);
+        if (lane == 0) pcount[wave] = __popcll(dm);
+        if (dirty) // {pixel, arms, state | read box << 16, row}
+            pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)((mystate & 0xFFFFu) | ((uint32_t)ent.z & 0xFFFF0000u)), ent.w);
         __syncthreads();
-        if (threadIdx.x == 0 && wg_changes) atomicAdd(chgcnt, adc_imin(wg_changes, IRV_CHG_SAT));
-    }
-    // TAIL MODE (round 4).  The long tail of a pass is a sequence of rounds in which a handful of values change; as kernels they
-    // cost ~8.4 us each (profiles/r4a_irv_chain_structured.txt: 175 of the 350 kernels of a structured 1080p Match) although
-    // there is next to nothing to compute: launch ramp, the entry -> state / tiles -> region chain of memory round trips, the
-    // kernel boundary.  When the previous kernel changed at most tail_max values the plan turns the round into a TAIL kernel:
-    // after its regular round every workgroup goes on BY ITSELF -- on a common time schedule (s_memrealtime), not on a barrier:
-    // at t_entry + t1 + j * ts it looks again at the change tiles THIS kernel has stamped so far (device-scope loads: past the
-    // non-coherent L2), re-evaluates the entries of its own batch whose dependency box holds such a tile, and stores device-
-    // scope.  A workgroup stops when the kernel-wide change counter has not moved since its last look (nothing to propagate),
-    // or after tail_rounds looks.  Exactness does not depend on the schedule: every evaluation is an evaluation "during kernel
-    // k" like those of a plain round -- whatever a workgroup misses because a store had not landed yet carries this kernel's
-    // stamp and is re-evaluated by kernel k + 1, and a pass still ends with a kernel that changes nothing.  The schedule only
-    // decides how many rounds a kernel is worth.  (Entries are kept in registers: single-batch lists only.)
-    if (pl.tail && tail_rounds > 0 && n <= B) {
-        // (the entry is read again -- an L2 hit long before the first look is due -- instead of being kept alive through the
-        // regular round: the kernel has to stay at 64 registers)
-        int4 te = list[(size_t)gw * 64 + lane];
-        if (irv_list_index(0, (int)blockIdx.x, wave, lane, (int)gridDim.x) >= n) te.x = IRV_LIST_END;
-        __shared__ int tail_cnt;
-        int seen = 0;
-        for (int j = 0; j < tail_rounds; j++) {
-            const long long due = t_entry + tail_t1 + (long long)j * tail_ts;
-            while ((long long)wall_clock64() < due) __builtin_amdgcn_s_sleep(4);
-            // (the box of the entry is derived again in every look: four registers less to carry through the votes)
-            asm volatile("" : "+v"(te.x), "+v"(te.y), "+v"(te.z), "+v"(te.w));
-            const bool mine = te.x != IRV_LIST_END;
-            const int p = mine ? te.x : 0, y = mine ? te.w : 0, x = p - y * W;
-            const int top = (int)(((uint32_t)te.y >> 16) & 255u), ml = te.z & 255, mr = (te.z >> 8) & 255;
-            const int tx0 = adc_imax(0, x - ml) / IRV_TILE, tx1 = mine ? adc_imin(W - 1, x + mr) / IRV_TILE : -1;
-            const int ty0 = adc_imax(0, y - top) / IRV_TILE, ty1 = y / IRV_TILE;
-            const uint32_t i16 = (uint32_t)(y * SP + x);
-            // one round trip: the change counter, the entry's own state (another wave of this workgroup may have written it),
-            // the change tiles of this kernel
-            int cnt = 0;
-            if (threadIdx.x == 0) cnt = __hip_atomic_load(chgcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t st = IRV_FINAL;
-            bool box = false;
-            if (__ballot(mine) != 0ull) {
-                const uint32_t w32 = __hip_atomic_load(reinterpret_cast<const uint32_t*>(st16) + (i16 >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                st = mine ? ((w32 >> (16 * (i16 & 1u))) & 0xFFFFu) : IRV_FINAL;
-                box = irv_box_dirty<true>(chg_wr, tpitch, tx0, tx1, ty0, ty1, stamp * 0x01010101u);
+        const int cnt_l = lane < WPB ? pcount[lane] : 0;
+        const int incl = irv_row_prefix(cnt_l); // inclusive prefix over the first 16 lanes
+        const int excl = incl - cnt_l;
+        const int total = __builtin_amdgcn_readlane(incl, 15);
+        IRV_T(3);
+        for (int t = wave; t < total; t += WPB) {
+            evals++;
+            const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
+            const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
+            const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
+            const uint32_t pz = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z);
+            const uint32_t cur = pz & 0xFFFFu; // (only this wave writes the entry in this round)
+            const int x = p - y * W;
+            for (int b = lane; b < D; b += 64) hist[b] = 0;
+            bool deps_open = false;
+            const int top = (int)(((uint32_t)armsp >> 16) & 255u), nrows = top + (int)((uint32_t)armsp >> 24) + 1; // region rows y-top .. y+bottom
+            const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
+            // the read box: blocks blkL .. blkR cover the widest row of the region
+            const int blkL = (x - (int)((pz >> 16) & 255u)) >> 3, blkR = (x + (int)(pz >> 24)) >> 3;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            for (int rbase = 0; rbase < nrows; rbase += 64) {
+                // the H arms of (up to 64) region rows (lane r holds row rbase + r; handed to the row slots with a shuffle) AND
+                // the first 16 rows x 4 blocks of the read box in ONE memory round trip: the arms only decide which pixels of a
+                // block belong to the region (round 4; before, the blocks were requested when the arms had arrived)
+                const int myr = rbase + lane;
+                uint32_t a2 = 0;
+                if (myr < nrows) a2 = arms32[(uint32_t)((y - top + myr) * W + x)];
+                const int rend = adc_imin(nrows - rbase, 64);
+                uint4 vfirst;
+                {
+                    const bool in0 = sub < rend && blkL + bslot <= blkR;
+                    vfirst = *reinterpret_cast<const uint4*>(st16 + (in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own));
+                }
+                IRV_T(4);
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (int r0 = 0; r0 < rend; r0 += 16) {
+                    const int r = r0 + sub;
+                    const uint32_t arm2 = (uint32_t)__shfl((int)a2, r & 63, 64);
+                    const bool rowok = r < rend;
+                    const int yt = y - top + rbase + r;
+                    const int xl = x - (int)(arm2 & 255u), xr = x + (int)((arm2 >> 8) & 255u);
+                    const int b0x = xl >> 3, b1x = xr >> 3;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                    for (int bo = 0;; bo += 4) { // one iteration unless the read box spans more than 4 blocks
+                        const int blk = blkL + bo + bslot;
+                        const bool use = rowok && blk >= b0x && blk <= b1x;
+                        uint4 v = vfirst;
+                        if (r0 + bo != 0) { // (uniform) loads stay unconditional: masked-out lanes read the entry's own block
+                            const uint32_t addr = rowok && blk <= blkR ? (uint32_t)(yt * SP + blk * 8) : own;
+                            v = *reinterpret_cast<const uint4*>(st16 + addr);
+                        }
+                        IRV_T(5);
+                        // The 8 pixels of the block, decoded as packed halfwords (irv_plan.h: irv_decode_block): which pixels
+                        // count, and do they all fall into ONE bin?
+                        uint32_t okm = 0u;
+                        if (use) {
+                            const IrvBlock bd = irv_decode_block(v.x, v.y, v.z, v.w, blk * 8, xl, xr, yt, y, x);
+                            deps_open = deps_open || bd.open;
+                            okm = bd.okm;
+                            // (same-address LDS atomics serialise: one per lane instead of eight.  Counting the dominant bin in
+                            // registers across the wave was measured too: slower, the extra wave reduction costs more.)
+                            if (okm != 0u && bd.single) {
+                                atomicAdd(&hist[bd.first], __popc(okm));
+                                okm = 0u;
+                            }
+                        }
+                        if (okm != 0u) { // pixels of several bins: one atomic each
+#pragma clang loop unroll(disable)
+                            for (uint32_t m = okm; m != 0u; m &= m - 1u) {
+                                const int q = __ffs((int)m) - 1;
+                                const uint32_t wq = q < 2 ? v.x : (q < 4 ? v.y : (q < 6 ? v.z : v.w));
+                                atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
+                            }
+                        }
+                        if (!__any(rowok && (blkL + bo + 4 <= b1x))) break;
+                    }
+                }
             }
-            if (threadIdx.x == 0) tail_cnt = cnt;
-            __syncthreads(); // (the previous pool has been consumed, too)
-            const int c = tail_cnt;
-            if (c == seen) break; // (uniform over the workgroup) nothing has changed anywhere since the last look
-            seen = c;
-            const bool dirty = mine && box && !(st & IRV_FINAL);
-            evals += irv_pool_and_vote<true>(rc, dirty, te, st, nchg);
+            IRV_T(6);
+            // first maximum (lowest bin on ties) and total count (multistep_refiner.cpp:199-209): key = count << 11 | (2047 - bin)
+            int key = 0, cnt = 0;
+            for (int b = lane; b < D; b += 64) {
+                const int hv = hist[b];
+                cnt += hv;
+                key = adc_imax(key, hv > 0 ? ((hv << 11) | (0x7FF - b)) : 0);
+            }
+            key = irv_wave_max(key);
+            cnt = irv_wave_sum(cnt);
+            const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
+            const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
+            const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
+            IRV_T(7);
+            if (lane == 0) {
+                const uint32_t i16 = (uint32_t)(y * SP + x);
+                const uint32_t nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
+                const uint32_t ns = nb | IRV_ELIG | (all_final ? IRV_FINAL : 0u);
+                if (ns != cur) st16[i16] = (uint16_t)ns; // value and final bit in ONE store
+                if (nb != (cur & IRV_BIN_MASK)) {
+                    chg_wr[(uint32_t)((y / IRV_TILE) * tpitch + x / IRV_TILE)] = (uint8_t)stamp;
+                    *acc = 1;
+                }
+            }
         }
     }
     if (lane == 0 && evals) evals_arr[gw] += evals;
@@ -597,19 +474,11 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count)
     const int tpitch = h->chg_pitch, chg_bytes = tpitch * ((p.H + IRV_TILE - 1) / IRV_TILE);
     const int wpb = irv_wpb(p.D);
     const size_t lds = (size_t)((wpb * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
-    // tail mode (see the kernel): ADC_IRV_TAIL = largest change count of the previous kernel that turns a round into a TAIL
-    // kernel (0 = off), ADC_IRV_TAIL_ROUNDS = looks per kernel, ADC_IRV_TAIL_T1 / _TS = time of the first look after kernel
-    // entry / distance of the looks, in ticks of 10 ns
-    static const int tail_max = [] { const char* e = getenv("ADC_IRV_TAIL"); return e ? atoi(e) : 0; }();
-    static const int tail_rounds = [] { const char* e = getenv("ADC_IRV_TAIL_ROUNDS"); return e ? atoi(e) : 12; }();
-    static const int tail_t1 = [] { const char* e = getenv("ADC_IRV_TAIL_T1"); return e ? atoi(e) : 900; }();
-    static const int tail_ts = [] { const char* e = getenv("ADC_IRV_TAIL_TS"); return e ? atoi(e) : 450; }();
     for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(k_irv_u, dim3((unsigned)h->irv_grid), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
                            h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
                            reinterpret_cast<const uint32_t*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
-                           p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr, tail_max, tail_rounds,
-                           tail_t1, tail_ts);
+                           p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr);
     return hipGetLastError();
 }
 

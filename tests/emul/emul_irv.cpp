@@ -10,21 +10,8 @@
 #include <vector>
 #include "../../adcensus_amd/csrc/irv_plan.h"
 
-// tail_max / tail_rounds / miss: TAIL mode of the kernel (a round whose predecessor changed <= tail_max values goes on for up to
-// tail_rounds further looks inside the same kernel; every look re-evaluates the entries whose box holds a tile stamped by THIS
-// kernel).  On the device a look may miss a change whose store has not landed yet: modelled by skipping a dirty entry with
-// probability miss / 256 -- the result must not depend on it.
-extern "C" long emul_irv_chain_tail(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
-                                    int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats,
-                                    int tail_max, int tail_rounds, int miss);
 extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats)
-{
-    return emul_irv_chain_tail(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, out_stats, 0, 0, 0);
-}
-extern "C" long emul_irv_chain_tail(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
-                                    int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats,
-                                    int tail_max, int tail_rounds, int miss)
 {
     const int P = W * H, SP = (W + 7) & ~7, T = IRV_TILE;
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
@@ -53,9 +40,8 @@ extern "C" long emul_irv_chain_tail(float* disp, const uint8_t* label, const uin
     const int32_t* fin = nullptr;
     for (int k = 0;; k++) {
         if (ctrl[16 * (k & 1)] == IRV_DONE) { fin = &ctrl[16 * (k & 1)]; break; } // the state the previous kernel published
-        const IrvPlan pl = irv_plan_tail(ctrl.data(), k, tail_max);
+        const IrvPlan pl = irv_plan(ctrl.data(), k);
         int32_t* acc = &ctrl[IRV_ACC + (k & 63)];
-        int32_t* chgcnt = &ctrl[IRV_CHG + (k & 63)];
         kernels++;
         if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
             const bool have_state = !(pl.act == IRV_BEGIN && pl.s.pass == 0);
@@ -97,32 +83,6 @@ extern "C" long emul_irv_chain_tail(float* disp, const uint8_t* label, const uin
             const int32_t want = ((k + 254) % 255) + 1, stamp = (k % 255) + 1; // stamps and planes go by KERNEL index
             const int32_t* chg_rd = chg.data() + (size_t)((k + 1) & 1) * tiles_x * tiles_y;
             int32_t* chg_wr = chg.data() + (size_t)(k & 1) * tiles_x * tiles_y;
-            auto evaluate = [&](const Ent& e) {
-                const int p = e.p, y = e.y, x = p - y * W;
-                std::fill(hist.begin(), hist.end(), 0);
-                bool deps_open = false;
-                const uint8_t* arm = arms + (size_t)p * 4;
-                for (int dy = -(int)arm[2]; dy <= (int)arm[3]; dy++) {
-                    const int yt = y + dy;
-                    const uint8_t* a2 = arms + ((size_t)yt * W + x) * 4;
-                    for (int px = x - (int)a2[0]; px <= x + (int)a2[1]; px++) {
-                        const uint32_t s = st[(size_t)yt * SP + px];
-                        const bool el = (s & IRV_ELIG) != 0, pre = yt < y || (yt == y && px < x);
-                        const uint32_t bin = s & IRV_BIN_MASK;
-                        if (bin != IRV_BIN_MASK && (!el || pre)) hist[bin]++;
-                        if (el && pre && !(s & IRV_FINAL)) deps_open = true;
-                    }
-                }
-                // the kernel's key: count << 11 | (2047 - bin), maximum = highest count, lowest bin on ties
-                int key = 0, cnt = 0;
-                for (int b = 0; b < D; b++) { cnt += hist[b]; if (hist[b] > 0) key = std::max(key, (hist[b] << 11) | (0x7FF - b)); }
-                const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
-                const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-                const size_t i16 = (size_t)y * SP + x;
-                const uint32_t cur = st[i16], nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
-                st[i16] = (uint16_t)(nb | IRV_ELIG | (deps_open ? 0u : IRV_FINAL));
-                if (nb != (cur & IRV_BIN_MASK)) { chg_wr[(y / T) * tiles_x + x / T] = stamp; *acc = 1; if (*chgcnt < IRV_CHG_SAT) (*chgcnt)++; }
-            };
             std::vector<int> waves(NW);
             for (int w = 0; w < NW; w++) waves[w] = w;
             for (int w = NW; w > 1; w--) std::swap(waves[w - 1], waves[rand() % w]);
@@ -146,39 +106,34 @@ extern "C" long emul_irv_chain_tail(float* disp, const uint8_t* label, const uin
                         if (dirty) todo[nt++] = lane;
                     }
                     total_evals += nt;
-                    for (int t = 0; t < nt; t++) evaluate(list[b0 + (size_t)gw * 64 + todo[t]]);
-                }
-            // TAIL mode: further looks inside the same kernel (single-batch lists), every workgroup by itself: entries whose box
-            // holds a tile THIS kernel has stamped so far are evaluated again; a look that finds the kernel-wide change counter
-            // where the previous look left it ends the kernel.  Workgroups take their looks in a shuffled order, and a dirty
-            // entry is skipped with probability miss / 256 (a store that had not landed yet).
-            if (pl.tail && tail_rounds > 0 && n <= B) {
-                int seen = 0;
-                for (int j = 0; j < tail_rounds; j++) {
-                    const int c = *chgcnt;
-                    if (c == seen) break;
-                    seen = c;
-                    for (int w = NW; w > 1; w--) std::swap(waves[w - 1], waves[rand() % w]);
-                    for (int gw : waves) {
-                        for (int lane = 0; lane < 64; lane++) {
-                            const long i = irv_list_index(0, gw / WPB, gw % WPB, lane, G);
-                            if (i >= n) continue;
-                            const Ent& e = list[(size_t)gw * 64 + lane];
-                            const int p = e.p, y = e.y, x = p - y * W;
-                            if (st[(size_t)y * SP + x] & IRV_FINAL) continue;
-                            const int top = (e.arms >> 16) & 255, ml = e.mlmr & 255, mr = (e.mlmr >> 8) & 255;
-                            const int tx0 = std::max(0, x - ml) / T, tx1 = std::min(W - 1, x + mr) / T;
-                            const int ty0 = std::max(0, y - top) / T, ty1 = y / T;
-                            bool dirty = false;
-                            for (int ty = ty0; ty <= ty1; ty++)
-                                for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_wr[ty * tiles_x + tx] == stamp;
-                            if (!dirty || (miss > 0 && rand() % 256 < miss)) continue;
-                            total_evals++;
-                            evaluate(e);
+                    for (int t = 0; t < nt; t++) {
+                        const Ent& e = list[b0 + (size_t)gw * 64 + todo[t]];
+                        const int p = e.p, y = e.y, x = p - y * W;
+                        std::fill(hist.begin(), hist.end(), 0);
+                        bool deps_open = false;
+                        const uint8_t* arm = arms + (size_t)p * 4;
+                        for (int dy = -(int)arm[2]; dy <= (int)arm[3]; dy++) {
+                            const int yt = y + dy;
+                            const uint8_t* a2 = arms + ((size_t)yt * W + x) * 4;
+                            for (int px = x - (int)a2[0]; px <= x + (int)a2[1]; px++) {
+                                const uint32_t s = st[(size_t)yt * SP + px];
+                                const bool el = (s & IRV_ELIG) != 0, pre = yt < y || (yt == y && px < x);
+                                const uint32_t bin = s & IRV_BIN_MASK;
+                                if (bin != IRV_BIN_MASK && (!el || pre)) hist[bin]++;
+                                if (el && pre && !(s & IRV_FINAL)) deps_open = true;
+                            }
                         }
+                        // the kernel's key: count << 11 | (2047 - bin), maximum = highest count, lowest bin on ties
+                        int key = 0, cnt = 0;
+                        for (int b = 0; b < D; b++) { cnt += hist[b]; if (hist[b] > 0) key = std::max(key, (hist[b] << 11) | (0x7FF - b)); }
+                        const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
+                        const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
+                        const size_t i16 = (size_t)y * SP + x;
+                        const uint32_t cur = st[i16], nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
+                        st[i16] = (uint16_t)(nb | IRV_ELIG | (deps_open ? 0u : IRV_FINAL));
+                        if (nb != (cur & IRV_BIN_MASK)) { chg_wr[(y / T) * tiles_x + x / T] = stamp; *acc = 1; }
                     }
                 }
-            }
         }
         IrvState ps = pl.s;
         if (pl.act == IRV_FINAL_WB) ps.evals = (int)total_evals; // (summed from the per-wave counters by the kernel)

@@ -399,22 +399,6 @@ def test_refiner_parallel_forms(emul, dumps, name):
                                      C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, groups, wpb, stats)
         assert rounds >= 0, rounds
         assert same(d, o["disp_after_irv"])
-    # ... with TAIL-mode kernels (round 4): rounds whose predecessor changed few values go on inside the kernel, every workgroup
-    # by itself, and a look may miss changes (modelled: dirty entries skipped with probability 1/4 and 3/4): same result, fewer kernels
-    emul.emul_irv_chain_tail.restype = C.c_long
-    base_kernels = None
-    for seed, groups, wpb, tail_max, tail_rounds, miss in ((3, 2, 4, 0, 0, 0), (3, 2, 4, 64, 8, 0), (5, 2, 4, 1 << 20, 12, 64), (7, 5, 1, 16, 3, 192)):
-        d = o["disp_after_lr"].copy()
-        stats = (C.c_long * 3)()
-        L = max(0, min(opt.cross_L1, 255))
-        rounds = emul.emul_irv_chain_tail(P(d), P(o["outlier_label"]), P(o["arms"]), P(o["sup_count_h"]), w, h, dmin, D, opt.irv_ts,
-                                          C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, groups, wpb, stats, tail_max, tail_rounds, miss)
-        assert rounds >= 0, rounds
-        assert same(d, o["disp_after_irv"]), (tail_max, tail_rounds, miss)
-        if tail_max == 0:
-            base_kernels = stats[2]
-        elif miss == 0 and groups == 2:
-            assert stats[2] <= base_kernels + 2  # (the shuffled order moves the count by a kernel or so)
     a, b = o["disp_after_irv"].copy(), np.empty((h, w), np.float32)
     ms = max(abs(opt.max_disparity), abs(opt.min_disparity))
     emul.emul_interpolate(P(a), P(b), P(o["outlier_label"]), P(left), w, h, 1, ms)

@@ -404,35 +404,6 @@ def test_scanline_segment_variants(hip, env, expect_redo):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{"ADC_IRV_TAIL": "64"}, {"ADC_IRV_TAIL": "4096", "ADC_IRV_TAIL_ROUNDS": "16"},
-                                 {"ADC_IRV_TAIL": "256", "ADC_IRV_TAIL_T1": "50", "ADC_IRV_TAIL_TS": "20"},
-                                 {"ADC_IRV_TAIL": "256", "ADC_IRV_GRID": "8", "ADC_IRV_WPB": "4"}, {"ADC_IRV_TAIL": "0"}])
-def test_voting_tail_mode_variants(hip, env):
-    """K8 TAIL mode (rounds whose predecessor changed few values go on inside the kernel, every workgroup on a time schedule,
-    device-scope loads / stores): stage-isolated voting (+ the continuation path with a budget of four kernels) and the whole
-    Match stay bit-exact for small and large thresholds, for a schedule so tight that looks run ahead of the other workgroups'
-    stores (T1 = 0.5 us, TS = 0.2 us: changes are missed and picked up by the next kernel), for a tiny grid (multi-batch lists:
-    tail mode must stay off there) and with the mode switched off.  Switches are read once per process: own interpreter."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "from tests import cases, gpu_harness\n"
-            "from oracle import pyoracle\n"
-            "bad = {}\n"
-            "for name in ('s2_320x180_d128', 'cone_crop_d40', 's2_150x100_neg', 's2_200x120_d200', 'noise_160x90_d128_pos'):\n"
-            "    l, r, opt = cases.make_case(name)\n"
-            "    o = pyoracle.load('auto').run(l, r, opt)\n"
-            "    rep = gpu_harness.stage_report(l, r, opt, o)\n"
-            "    print(name, 'voting rounds / evaluations', rep.get('disp_after_irv', {}).get('voting_rounds_evals'))\n"
-            "    bad.update({name + ':' + k: v['bad'] for k, v in gpu_harness.failing(rep).items()})\n"
-            "print('FAILING', bad)\n"
-            "sys.exit(1 if bad else 0)\n") % root
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-
-
 def test_registered_host_buffers(hip, oracle):
     """adc_host_register: images / map inside a page-locked range go by DMA straight from / to the caller's memory (no staging);
     same result, also when only some of the three buffers are registered, and the plain path works again after unregister."""
