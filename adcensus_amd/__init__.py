@@ -22,7 +22,7 @@ STAGES = ["cost", "arms", "aggregate", "scanline", "wta", "refine"]
  BUF_VOLUME_A, BUF_DISP_LEFT, BUF_DISP_RIGHT, BUF_OUTLIER_LABEL) = range(11)
 (RUN_GRAY_CENSUS, RUN_COST, RUN_ARMS, RUN_AGGREGATE, RUN_SCANLINE, RUN_WTA, RUN_LRCHECK, RUN_REGION_VOTING,
  RUN_INTERPOLATION, RUN_DISCONTINUITY, RUN_MEDIAN) = range(11)
-MAX_DISP_RANGE = 1024
+MAX_DISP_RANGE = 2047
 PAPER_CENSUS5X5, PAPER_SO_SUM, PAPER_RIGHT_ARMS = 1, 2, 4  # adc_set_paper_modes (opt-in, not the reference's behaviour)
 
 

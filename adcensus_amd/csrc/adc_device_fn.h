@@ -91,8 +91,9 @@ ADC_HD void adc_so_class_offsets(const uint32_t* rb, int c1byte, int xr_last, in
     for (int k = 0; k < VPL; k++) {
         const int xr = xr_last + (VPL - 1 - k);
         const int j = (xr > 1 ? xr : 1) - a0; // 0 .. VPL-1: which of the fetched bytes is column max(xr, 1)
-        // (VPL <= 4: a single word -- no runtime index, the array must stay in registers)
-        const uint32_t word = VPL <= 4 ? rb[0] : (VPL == 8 ? (j >= 4 ? rb[1] : rb[0]) : (j >= 8 ? (j >= 12 ? rb[3] : rb[2]) : (j >= 4 ? rb[1] : rb[0])));
+        // (VPL <= 4: a single word -- no runtime index, the array must stay in registers: a select tree over the VPL / 4 words)
+        uint32_t word = rb[0];
+        for (int q = 1; q < (VPL + 3) / 4; q++) word = (j >> 2) == q ? rb[q] : word;
         const int byte = (int)((word >> (8 * (j & 3))) & 0xffu);
         const int c2 = byte >= tso ? 8 : 0;
         const bool use_r = row_ok && xr < W - 1;

@@ -122,7 +122,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->rec2_h, P * 8));
     HIP_OK(hipMalloc(&h->rec2_v, P * 8));
     HIP_OK(hipMalloc(&h->agg_sink, 1024 * 64 * sizeof(float)));
-    // + slack: the scanline kernels fetch up to VPL (<= 16) bytes starting at a column <= W-1 (+1 on R->L passes)
+    // + slack: the scanline kernels fetch up to VPL (<= 32) bytes starting at a column <= W-1 (+1 on R->L passes)
     HIP_OK(hipMalloc(&h->cdiff_lh, P + 64));
     HIP_OK(hipMalloc(&h->cdiff_lv, P + 64));
     HIP_OK(hipMalloc(&h->cdiff_rh, P + 64));
@@ -264,7 +264,7 @@ adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int
     h->device = dev;
     h->p.W = width; h->p.H = height;
     h->p.dmin = opt->min_disparity; h->p.dmax = opt->max_disparity; h->p.D = (int)range;
-    h->p.VPL = range <= 64 ? 1 : (range <= 128 ? 2 : (range <= 256 ? 4 : (range <= 512 ? 8 : 16)));
+    h->p.VPL = range <= 64 ? 1 : (range <= 128 ? 2 : (range <= 256 ? 4 : (range <= 512 ? 8 : (range <= 1024 ? 16 : 32))));
     h->p.Dp = 64 * h->p.VPL;
     h->p.opt = *opt;
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;

@@ -164,7 +164,8 @@ hipError_t adc_launch_cost(adc_handle* h, float* vol_out)
     else if (p.VPL == 2) LAUNCH(2);
     else if (p.VPL == 4) LAUNCH(4);
     else if (p.VPL == 8) LAUNCH(8);
-    else LAUNCH(16);
+    else if (p.VPL == 16) LAUNCH(16);
+    else LAUNCH(32);
 #undef LAUNCH
     return hipGetLastError();
 }

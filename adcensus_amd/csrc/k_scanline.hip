@@ -728,7 +728,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
             e.c1 = (int)((c1p[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xffu);
             return e;
         };
-        constexpr int SO_PFV = VPL <= 4 ? SO_PF : (VPL == 8 ? 8 : 4); // register budget: SO_PFV * (VPL + 2) per lane
+        constexpr int SO_PFV = VPL <= 4 ? SO_PF : (VPL == 8 ? 8 : (VPL == 16 ? 4 : 2)); // register budget: SO_PFV * (VPL + 2) per lane
         SoElem<VPL> pre[SO_PFV];
 #pragma unroll
         for (int u = 0; u < SO_PFV; u++) pre[u] = so_load(adc_imin(1 + u, g.plen - 1));
@@ -969,5 +969,6 @@ hipError_t adc_launch_scanline(adc_handle* h, int passes)
     if (h->p.VPL == 2) return run_so<2>(h, passes);
     if (h->p.VPL == 4) return run_so<4>(h, passes);
     if (h->p.VPL == 8) return run_so<8>(h, passes);
-    return run_so<16>(h, passes);
+    if (h->p.VPL == 16) return run_so<16>(h, passes);
+    return run_so<32>(h, passes);
 }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, floa
                                              int D)
 {
     constexpr int Dp = 64 * VPL;
-    constexpr int WTA_PPW = VPL <= 4 ? WTA_PPW_MAX : (VPL == 8 ? 4 : 2); // (register budget: WTA_PPW * VPL costs per lane)
+    constexpr int WTA_PPW = VPL <= 4 ? WTA_PPW_MAX : (VPL == 8 ? 4 : (VPL == 16 ? 2 : 1)); // (register budget: WTA_PPW * VPL costs per lane)
     const int lane = threadIdx.x & 63;
     const long long P = (long long)W * H;
     const long long pix0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * WTA_PPW;
@@ -151,14 +151,15 @@ hipError_t adc_launch_wta_left(adc_handle* h)
 {
     const AdcParams& p = h->p;
     const long long P = (long long)p.W * p.H;
-    const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : 2); // == k_wta's WTA_PPW
+    const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : (p.VPL == 16 ? 2 : 1)); // == k_wta's WTA_PPW
     const unsigned blocks = (unsigned)((P + 4 * wta_ppw - 1) / (4 * wta_ppw));
 #define LAUNCHL(V) hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D)
     if (p.VPL == 1) LAUNCHL(1);
     else if (p.VPL == 2) LAUNCHL(2);
     else if (p.VPL == 4) LAUNCHL(4);
     else if (p.VPL == 8) LAUNCHL(8);
-    else LAUNCHL(16);
+    else if (p.VPL == 16) LAUNCHL(16);
+    else LAUNCHL(32);
 #undef LAUNCHL
     return hipGetLastError();
 }
@@ -167,7 +168,7 @@ hipError_t adc_launch_wta(adc_handle* h)
 {
     const AdcParams& p = h->p;
     const long long P = (long long)p.W * p.H;
-    const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : 2); // == k_wta's WTA_PPW
+    const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : (p.VPL == 16 ? 2 : 1)); // == k_wta's WTA_PPW
     const unsigned blocks = (unsigned)((P + 4 * wta_ppw - 1) / (4 * wta_ppw));
     static const bool band = [] { const char* e = getenv("ADC_WTA_BAND"); return e ? atoi(e) != 0 : true; }();
     const bool left = !h->wta_left_done; // the last scanline pass of the pipeline already produced the left view
@@ -185,7 +186,8 @@ hipError_t adc_launch_wta(adc_handle* h)
     else if (p.VPL == 2) LAUNCH(2);
     else if (p.VPL == 4) LAUNCH(4);
     else if (p.VPL == 8) LAUNCH(8);
-    else LAUNCH(16);
+    else if (p.VPL == 16) LAUNCH(16);
+    else LAUNCH(32);
 #undef LAUNCH
     return hipGetLastError();
 }

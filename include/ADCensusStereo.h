@@ -25,7 +25,7 @@ public:
     ADCensusStereo& operator=(const ADCensusStereo&) = delete;
 
     /** Allocates all device buffers once. false: width/height <= 0, empty disparity range
-     *  (ADCensusStereo.cpp:31-40), range > ADC_MAX_DISP_RANGE (1024), W*H > 2^30, or a HIP failure. */
+     *  (ADCensusStereo.cpp:31-40), range > ADC_MAX_DISP_RANGE (2047), W*H > 2^30, or a HIP failure. */
     bool Initialize(const sint32& width, const sint32& height, const ADCensusOption& option);
 
     /** Left-view sub-pixel disparity map of the pair (uint8 [H][W][3] BGR each) into the caller's

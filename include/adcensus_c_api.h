@@ -72,10 +72,11 @@ const char* adc_last_error(void);
  * Initialize.  Returns NULL when the reference's Initialize returns false
  * (width<=0 || height<=0, ADCensusStereo.cpp:31-33; max_disparity-min_disparity<=0, :38-40),
  * on a HIP failure (including out of memory), or when the disparity range exceeds ADC_MAX_DISP_RANGE
- * (1024 = 16 disparities per lane; the reference accepts any positive range, larger ones return NULL here).
+ * (2047 = 32 disparities per lane and the 11-bit histogram bins of the voting state map; the reference accepts any positive range
+ * its host memory holds -- at 2047 a 1080p cost volume is 17 GB --, larger ones return NULL here).
  * device < 0 means "current device".  All device scratch is allocated here, once.
  */
-#define ADC_MAX_DISP_RANGE 1024
+#define ADC_MAX_DISP_RANGE 2047
 adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int device);
 void adc_destroy(adc_handle* h);
 

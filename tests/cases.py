@@ -76,6 +76,9 @@ _CASES = {
     # the largest range the product accepts (ADC_MAX_DISP_RANGE = 1024: 16 disparities per lane; the voting chain falls back
     # to 8 waves per workgroup because 16 histograms of 1024 bins do not fit into 64 KB of LDS)
     "s2_72x48_d1024": (lambda: workloads.structured_pair(72, 48, 40, seed=32), dict(min_disparity=-512, max_disparity=512)),
+    # round 4: ranges above 1024 -- 32 disparities per lane, up to ADC_MAX_DISP_RANGE = 2047 (the 11-bit bins of the voting state map)
+    "noise_64x24_d1100": (lambda: workloads.noise_pair(64, 24, seed=33), dict(min_disparity=-40, max_disparity=1060)),
+    "s2_80x20_d2047": (lambda: workloads.structured_pair(80, 20, 48, seed=34), dict(min_disparity=-1000, max_disparity=1047)),
     # discontinuity adjustment with min_disparity != 0: the reference indexes the cost row with the ABSOLUTE
     # disparity (multistep_refiner.cpp:331-339), i.e. it reads the neighbouring pixel's costs
     "cone_crop_dda_neg": (lambda: _crop(cone_pair(), 100, 231, 120, 377), dict(min_disparity=-6, max_disparity=40, do_discontinuity_adjustment=1)),
@@ -90,7 +93,7 @@ GOLDEN_CASES = list(_CASES.keys())
 FAST_CASES = ["cone_crop_d40", "s2_96x64_d32", "q_257x131_d64", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8",
               "q_40x1_d8", "q_3x3_d2", "noise_128x72_d64", "s2_150x100_neg", "s2_200x120_d200", "noise_160x90_d128",
               "q_40x30_pos_wltd", "noise_160x90_d128_pos", "s2_150x100_pos", "s2_200x120_d160", "noise_96x50_d160_neg",
-              "s2_360x60_d300", "noise_80x40_d520", "s2_72x48_d1024", "cone_crop_dda_neg", "cone_crop_dda_pos"]
+              "s2_360x60_d300", "noise_80x40_d520", "s2_72x48_d1024", "noise_64x24_d1100", "s2_80x20_d2047", "cone_crop_dda_neg", "cone_crop_dda_pos"]
 
 
 def canonical(stage, arr, opt):

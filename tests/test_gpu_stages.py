@@ -9,9 +9,10 @@ pytestmark = pytest.mark.gpu
 STAGE_CASES = ["s2_96x64_d32", "q_257x131_d64", "q_20x40_d32", "q_9x20_d8", "q_30x7_d8", "q_1x40_d8", "q_40x1_d8",
                "q_3x3_d2", "noise_128x72_d64", "noise_160x90_d128", "noise_150x40_d256", "s2_150x100_neg", "s2_320x180_d128", "s2_200x120_d200", "cone_crop_d40", "cone_crop_L40",
                "cone", "cone_neg", "cone_d16", "cone_nolr", "cone_nofill", "cone_dda", "cone_params",
-               # min_disparity > 0, 128 < D < 192 (all-padding chunk), D > 256 up to the maximum of 1024, discontinuity adjustment with dmin != 0
+               # min_disparity > 0, 128 < D < 192 (all-padding chunk), D > 256 up to the maximum of 2047, discontinuity adjustment with dmin != 0
                "cone_pos", "q_40x30_pos_wltd", "noise_160x90_d128_pos", "s2_150x100_pos", "s2_200x120_d160",
-               "noise_96x50_d160_neg", "s2_360x60_d300", "noise_80x40_d520", "s2_72x48_d1024", "cone_crop_dda_neg", "cone_crop_dda_pos"]
+               "noise_96x50_d160_neg", "s2_360x60_d300", "noise_80x40_d520", "s2_72x48_d1024", "noise_64x24_d1100", "s2_80x20_d2047",
+               "cone_crop_dda_neg", "cone_crop_dda_pos"]
 
 
 @pytest.mark.parametrize("name", STAGE_CASES)
