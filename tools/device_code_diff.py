@@ -23,6 +23,16 @@ def isa(root, stem, out):
     return "\n".join(l for l in t.split("\n") if not re.match(r"\s*(;|\.file|\.ident|\.loc)", l))
 
 
+def functions(text):
+    """{mangled name: body} of the functions of an assembly listing (label line up to its .Lfunc_end)."""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
+        body = re.sub(r"\.L(BB|tmp|func_end|func_begin)[0-9_]+", ".L", m.group(2))  # (label numbers shift when functions are added)
+        body = "\n".join(re.sub(r"\s*;.*$", "", l) for l in body.split("\n"))       # (... and so do the block numbers in trailing comments)
+        out[m.group(1)] = body
+    return out
+
+
 def main():
     commit = sys.argv[1]
     tmp = tempfile.mkdtemp()
@@ -32,12 +42,24 @@ def main():
     try:
         for s in SRCS:
             a, b = isa(other, s, os.path.join(tmp, "a_%s.s" % s)), isa(ROOT, s, os.path.join(tmp, "b_%s.s" % s))
-            print("%-12s %s" % (s, "identical" if a == b else "DIFFERENT"))
-            same &= a == b
+            if a == b:
+                print("%-12s identical" % s)
+                continue
+            # per function: a unit that only GAINED kernels (new template instantiations) leaves the old ones untouched -- or not
+            fa, fb = functions(a), functions(b)
+            changed = [n for n in fa if n in fb and fa[n] != fb[n]]
+            gone, added = [n for n in fa if n not in fb], [n for n in fb if n not in fa]
+            print("%-12s %s: %d functions identical, %d changed, %d removed, %d new" % (s, "DIFFERENT" if changed or gone else "old functions identical",
+                                                                                     len([n for n in fa if n in fb]) - len(changed), len(changed), len(gone), len(added)))
+            for n in changed[:8]:
+                print("             changed:", n[:110])
+            for n in added[:8]:
+                print("             new:    ", n[:110])
+            same &= not changed and not gone
     finally:
         subprocess.run(["git", "-C", ROOT, "worktree", "remove", "--force", other])
         subprocess.run(["git", "-C", ROOT, "worktree", "prune"])
-    print("device code identical to %s: %s" % (commit, same))
+    print("device code of every function that exists at %s unchanged: %s" % (commit, same))
     sys.exit(0 if same else 1)
 
 
