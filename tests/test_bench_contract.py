@@ -37,7 +37,7 @@ def test_committed_bench_lines_follow_the_contract(name):
         assert k in o and isinstance(o[k], t), k
     assert "vs_baseline" in o and o["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
     assert o["unit"] == "pairs/s" and o["higher_is_better"] is True and o["scaling"] in ("weak", "strong") and o["dtype"] == "f32"
-    if not name.startswith("r3_"):
+    if not name.startswith(("r3_", "r4_")):
         assert o["scaling"] == "weak"
     assert "workload" in o["config"] and "model" not in o["config"]
     _check_roofline(o["roofline"])
@@ -46,7 +46,7 @@ def test_committed_bench_lines_follow_the_contract(name):
     if "cpu_baseline" in o:
         c = o["cpu_baseline"]
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("reference", "port") and c["cores"] == 1
-    if name.startswith("r3_"):  # round-3 lines: frac = REAL HBM bytes / time / peak (<= 1), the SURVEY 8d figure is algorithmic_frac
+    if name.startswith(("r3_", "r4_")):  # lines of rounds 3 and 4: frac = REAL HBM bytes / time / peak (<= 1), the SURVEY 8d figure is algorithmic_frac
         r = o["roofline"]
         assert r["frac"] <= 1.0 and r["algorithmic_frac"] >= r["frac"] - 1e-9 and r["passes_per_launch"] >= 1.0
         assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
