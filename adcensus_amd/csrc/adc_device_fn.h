@@ -216,6 +216,49 @@ ADC_HD float adc_subpixel(int best, float c1, float c2, float cmin)
     return (float)best;
 }
 
+// ---- right-view WTA marching along a row (k_wta.hip: k_wta_right_march; ADCensusStereo.cpp:245-310) ----
+// A workgroup marches along a row of the volume in steps of 64 pixel vectors, which it keeps in an LDS ring of ADC_WTAM_RING
+// vectors; the right pixel xr needs the vectors xr + dmin .. xr + dmin + D - 1, so the group of 64 right pixels that starts at
+// vector g * 64 is complete when step g + lag has been written.
+#define ADC_WTAM_RING 256
+ADC_HD int adc_wtam_lag(int D) { return (D + 62) / 64; }
+// The launch: one unit per workgroup, one workgroup per CU (the ring takes most of the LDS).  The first rows_full rows (a multiple
+// of the CU count) are whole-row units; the remaining H - rows_full rows would leave most CUs idle in the last round, so they are
+// cut into nseg segments of segw pixels (a multiple of 64) each -- a segment re-reads D - 1 vectors of its neighbour.
+struct AdcWtamPlan { int rows_full, nseg, segw, units; };
+ADC_HD AdcWtamPlan adc_wtam_plan(int W, int H, int D, int ncu, int force_nseg = 0) // (force_nseg: tests)
+{
+    AdcWtamPlan pl;
+    ncu = adc_imax(1, ncu);
+    pl.rows_full = (H / ncu) * ncu;
+    const int rem = H - pl.rows_full;
+    pl.nseg = 1;
+    pl.segw = ((W + 63) / 64) * 64;
+    if (rem > 0) {
+        long best = -1;
+        for (int n = force_nseg > 0 ? force_nseg : 1; n <= (force_nseg > 0 ? force_nseg : 8); n++) {
+            const int sw = (((W + n - 1) / n + 63) / 64) * 64; // pixels per segment
+            const int ns = (W + sw - 1) / sw;                  // segments that hold pixels
+            const long rounds = ((long)rem * ns + ncu - 1) / ncu;
+            const long cost = rounds * (sw + D + 127);         // vectors a workgroup walks per unit + the fill of its pipeline
+            if (best < 0 || cost < best) { best = cost; pl.nseg = ns; pl.segw = sw; }
+        }
+    }
+    pl.units = pl.rows_full + rem * pl.nseg;
+    return pl;
+}
+struct AdcWtamUnit { int y, x0, x1; };
+ADC_HD AdcWtamUnit adc_wtam_unit(int u, int W, int rows_full, int nseg, int segw)
+{
+    AdcWtamUnit un;
+    if (u < rows_full) { un.y = u; un.x0 = 0; un.x1 = W; return un; }
+    const int r = u - rows_full, s = r % nseg;
+    un.y = rows_full + r / nseg;
+    un.x0 = s * segw;
+    un.x1 = adc_imin(W, un.x0 + segw);
+    return un;
+}
+
 // ---- region voting decision (multistep_refiner.cpp:199-214) ----
 // returns the filled disparity or +inf
 ADC_HD float adc_vote_decide(int best_bin, int max_ht, int count, int dmin, int irv_ts, float irv_th)

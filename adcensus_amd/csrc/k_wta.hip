@@ -7,6 +7,7 @@
 //        neighbour); at the range ends the INTEGER best is stored (no invalidation).
 // One wave per pixel, lanes = disparities; lexicographic (cost, d) wave arg-min.
 #include "adc_internal.h"
+#include <mutex>
 #include "adc_device_fn.h"
 
 __device__ __forceinline__ void wave_argmin(float& c, int& d)
@@ -147,6 +148,126 @@ __global__ __launch_bounds__(256) void k_wta_right_band(const float* __restrict_
     disp[(size_t)y * W + x] = out;
 }
 
+// ------------------------------------------------------------------------------ right view, marching along a row
+// The band kernel above reads every 512-byte pixel vector as two unaligned 256-byte pieces from two different waves (0.29 ms at
+// 1080p = 3.6 TB/s).  Here a workgroup of 8 waves marches along a row and reads WHOLE pixel vectors, 64 per step, in full lines --
+// every element of the volume once (segments: adc_wtam_plan) -- into an LDS ring of 256 vectors with a pitch of Dp + 1 floats:
+// lane d writes element d of a vector (consecutive banks), and the scan of right pixel xr walks the diagonal (xr + d, d), which
+// for the 64 pixels of a group (lane = pixel) is 64 addresses at a stride of Dp + 1 floats: consecutive banks again.  The loads
+// of steps s + 1 and s + 2 are in flight (registers) while step s is written and group s - lag is scanned: wave q scans the
+// disparities [q * Dp / 8, (q + 1) * Dp / 8) of the group's 64 pixels with the reference's strict '<' (lowest d wins inside a
+// part), one wave combines the 8 parts in increasing d (strict '<' again: the first minimum overall), fetches the two
+// neighbours of the winner from the ring and stores 64 disparities.  Step s + 1 goes into the ring slot that group s - lag no
+// longer needs (4 slots of 64 vectors, lag <= 2), so the combining wave can still read while the others write.  D <= 128.
+#ifndef WTAM_WAVES
+#define WTAM_WAVES 8 // waves per workgroup (8 or 16)
+#endif
+template <int VPL>
+__global__ __launch_bounds__(64 * WTAM_WAVES) void k_wta_right_march(const float* __restrict__ vol, float* __restrict__ disp, int W, int H, int dmin, int D,
+                                                         int rows_full, int nseg, int segw)
+{
+    constexpr int Dp = 64 * VPL, P = Dp + 1, NW = WTAM_WAVES, VPW = 64 / NW, Dq = Dp / NW;
+    extern __shared__ float wring[]; // [ADC_WTAM_RING][P], then the parts' results: float pmin[NW][64], int pbest[NW][64]
+    float (*pmin)[64] = reinterpret_cast<float (*)[64]>(wring + ADC_WTAM_RING * P);
+    int (*pbest)[64] = reinterpret_cast<int (*)[64]>(wring + ADC_WTAM_RING * P + NW * 64);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const AdcWtamUnit un = adc_wtam_unit((int)blockIdx.x, W, rows_full, nseg, segw);
+    if (un.x0 >= un.x1) return;
+    const int G = (un.x1 - un.x0 + 63) >> 6, lag = adc_wtam_lag(D), last = G - 1 + lag;
+    const float* row = vol + (size_t)un.y * W * Dp;
+    const int di0 = wave * Dq;
+#ifndef WTAM_DEPTH
+#define WTAM_DEPTH 2 // steps whose loads are in flight while a step is taken over (2 or 3)
+#endif
+    float bufA[VPW][VPL], bufB[VPW][VPL], cur[VPW][VPL];
+#if WTAM_DEPTH == 3
+    float bufC[VPW][VPL];
+#endif
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    // vector i of the unit is the image column un.x0 + dmin + i; columns outside the image count as Large_Float (:281-283) --
+    // their loads are clamped (and so are the loads of the steps behind the last one)
+// The loads are issued from inline asm and taken over behind ONE hand-counted wait per step (the compiler's own vmcnt
+    // bookkeeping drains the queue at the loop's back edge: built first, it waited for the loads it had just issued): when step s is
+    // taken over, the 8 * VPL loads of step s + 1 are the only younger ones of the wave that may still be outstanding (the store of a
+    // combining wave can only make the wait stronger); proven on the generated code by tools/check_async_loads.py.
+#define WTAM_ISSUE(buf, s)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                                   \
+        const int c = un.x0 + dmin + (s) * 64 + wave * VPW + j;                                                         \
+        const float* vp = row + (size_t)(c < 0 ? 0 : (c >= W ? W - 1 : c)) * Dp;                                        \
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(buf[j][0]) : "v"(lane4), "s"(vp) : "memory");                \
+        if constexpr (VPL == 2) asm volatile("global_load_dword %0, %1, %2 offset:256" : "=v"(buf[j][1]) : "v"(lane4), "s"(vp) : "memory"); \
+    }
+#define WTAM_TAKE(buf)                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WTAM_DEPTH - 1) * VPW * VPL) : "memory");                                                  \
+    _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                                   \
+        asm volatile("v_mov_b32 %0, %1" : "=v"(cur[j][0]) : "v"(buf[j][0]));                                            \
+        if constexpr (VPL == 2) asm volatile("v_mov_b32 %0, %1" : "=v"(cur[j][1]) : "v"(buf[j][1]));                    \
+    }
+#define WTAM_STEP(buf, s)                                                                                               \
+    {                                                                                                                   \
+        WTAM_TAKE(buf)                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                               \
+            const int i = (s) * 64 + wave * VPW + j, c = un.x0 + dmin + i;                                              \
+            const bool in_img = c >= 0 && c < W;                                                                        \
+            _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                             \
+                wring[(i & (ADC_WTAM_RING - 1)) * P + lane + 64 * k] = in_img ? cur[j][k] : ADC_LARGE_FLOAT;            \
+        }                                                                                                               \
+        WTAM_ISSUE(buf, (s) + WTAM_DEPTH)                                                                                     \
+        __syncthreads();                                                                                                \
+        const int g = (s) - lag, b = g * 64 + lane;                                                                     \
+        if (g >= 0 && g < G) {                                                                                          \
+            float mc = ADC_LARGE_FLOAT;                                                                                 \
+            int mb = -1;                                                                                                \
+            _Pragma("unroll") for (int t = 0; t < Dq; t++) { /* (all reads of the part first; padding disparities never win) */ \
+                const int di = di0 + t;                                                                                 \
+                const float v = wring[((b + di) & (ADC_WTAM_RING - 1)) * P + di];                                       \
+                const float cost = di < D ? v : ADC_LARGE_FLOAT;                                                        \
+                if (cost < mc) { mc = cost; mb = di; }                                                                  \
+            }                                                                                                           \
+            pmin[wave][lane] = mc;                                                                                      \
+            pbest[wave][lane] = mb;                                                                                     \
+        }                                                                                                               \
+        __syncthreads();                                                                                                \
+        if (g >= 0 && g < G && wave == (g & (NW - 1))) {                                                                       \
+            float minc = ADC_LARGE_FLOAT;                                                                               \
+            int bi = -1;                                                                                                \
+            _Pragma("unroll") for (int q = 0; q < NW; q++) {                                                             \
+                const float m = pmin[q][lane];                                                                          \
+                const int mbq = pbest[q][lane];                                                                         \
+                if (m < minc) { minc = m; bi = mbq; }                                                                   \
+            }                                                                                                           \
+            const int x = un.x0 + b;                                                                                    \
+            if (x < un.x1) {                                                                                            \
+                const int best = bi < 0 ? 0 : bi + dmin; /* best_disparity keeps its initial 0 when nothing is below Large_Float */ \
+                const int i1 = best - 1 - dmin, i2 = best + 1 - dmin;                                                   \
+                float out = (float)best; /* the integer at the range ends (:296-300) */                                 \
+                if (best != dmin && best != dmin + D - 1 && i1 >= 0 && i2 < D) {                                        \
+                    const float c1 = wring[((b + i1) & (ADC_WTAM_RING - 1)) * P + i1];                                  \
+                    const float c2 = wring[((b + i2) & (ADC_WTAM_RING - 1)) * P + i2];                                  \
+                    out = adc_subpixel(best, c1, c2, minc);                                                             \
+                }                                                                                                       \
+                disp[(size_t)un.y * W + x] = out;                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+    WTAM_ISSUE(bufA, 0)
+    WTAM_ISSUE(bufB, 1)
+#if WTAM_DEPTH == 3
+    WTAM_ISSUE(bufC, 2)
+#endif
+#pragma clang loop unroll(disable)
+    for (int s = 0; s <= last; s += WTAM_DEPTH) { // (the last round may add empty steps: their groups lie behind the unit, g >= G)
+        WTAM_STEP(bufA, s)
+        WTAM_STEP(bufB, s + 1)
+#if WTAM_DEPTH == 3
+        WTAM_STEP(bufC, s + 2)
+#endif
+    }
+#undef WTAM_STEP
+#undef WTAM_TAKE
+#undef WTAM_ISSUE
+}
+
 hipError_t adc_launch_wta_left(adc_handle* h)
 {
     const AdcParams& p = h->p;
@@ -171,8 +292,48 @@ hipError_t adc_launch_wta(adc_handle* h)
     const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : (p.VPL == 16 ? 2 : 1)); // == k_wta's WTA_PPW
     const unsigned blocks = (unsigned)((P + 4 * wta_ppw - 1) / (4 * wta_ppw));
     static const bool band = [] { const char* e = getenv("ADC_WTA_BAND"); return e ? atoi(e) != 0 : true; }();
+    // marching form of the right view (D <= 128): ADC_WTA_MARCH=0 selects the band kernel, ADC_WTA_NCU overrides the number of
+    // workgroups the plan assumes to run at a time, ADC_WTA_NSEG the segments per row of the remainder rows (tests: segments on
+    // small images)
+    static const bool march_on = [] { const char* e = getenv("ADC_WTA_MARCH"); return e ? atoi(e) != 0 : true; }();
+    static const int ncu_env = [] { const char* e = getenv("ADC_WTA_NCU"); return e ? atoi(e) : 0; }();
+    static const int nseg_env = [] { const char* e = getenv("ADC_WTA_NSEG"); return e ? atoi(e) : 0; }();
     const bool left = !h->wta_left_done; // the last scanline pass of the pipeline already produced the left view
     h->wta_left_done = 0;
+    if (march_on && band && p.VPL <= 2) {
+        static std::mutex attr_mu; // (per-DEVICE function attribute and CU count: see adc_launch_aggregate)
+        static bool attr_set[64] = {false};
+        static int ncu_dev[64];
+        const int dv = (h->device >= 0 && h->device < 64) ? h->device : 0;
+        {
+            std::lock_guard<std::mutex> lk(attr_mu);
+            if (!attr_set[dv]) {
+                hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wta_right_march<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (ea == hipSuccess)
+                    ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wta_right_march<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (ea != hipSuccess) return ea;
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dv) != hipSuccess || n <= 0) n = 256;
+                ncu_dev[dv] = n;
+                attr_set[dv] = true;
+            }
+        }
+        const AdcWtamPlan pl = adc_wtam_plan(p.W, p.H, p.D, ncu_env > 0 ? ncu_env : ncu_dev[dv], nseg_env);
+        const size_t lds = ((size_t)ADC_WTAM_RING * (p.Dp + 1) + 2 * WTAM_WAVES * 64) * sizeof(float); // ring + the parts' results
+        if (left) {
+            const int wl = p.VPL <= 4 ? WTA_PPW_MAX : 1;
+            const unsigned bl = (unsigned)((P + 4 * wl - 1) / (4 * wl));
+            if (p.VPL == 1) hipLaunchKernelGGL((k_wta<1, false>), dim3(bl), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D);
+            else hipLaunchKernelGGL((k_wta<2, false>), dim3(bl), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D);
+        }
+        if (p.VPL == 1)
+            hipLaunchKernelGGL((k_wta_right_march<1>), dim3((unsigned)pl.units), dim3(64 * WTAM_WAVES), lds, h->heavy, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D,
+                               pl.rows_full, pl.nseg, pl.segw);
+        else
+            hipLaunchKernelGGL((k_wta_right_march<2>), dim3((unsigned)pl.units), dim3(64 * WTAM_WAVES), lds, h->heavy, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D,
+                               pl.rows_full, pl.nseg, pl.segw);
+        return hipGetLastError();
+    }
 #define LAUNCH(V)                                                                                                       \
     do {                                                                                                                \
         if (left) hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \

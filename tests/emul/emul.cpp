@@ -727,6 +727,68 @@ void emul_wta_right_band(const float* vol, float* disp, int W, int H, int dmin, 
             }
 }
 
+// ------------------------------------------------------------------ k_wta_right_march
+// The launch plan (adc_wtam_plan / adc_wtam_unit: whole rows, the remainder cut into segments), the ring of 256 pixel vectors
+// with a pitch of Dp + 1, steps of 64 vectors written by 8 "waves" of 8 vectors each, group s - lag scanned in 8 parts of
+// Dp / 8 disparities (strict '<' inside a part), the parts combined in increasing d (strict '<'), the winner's neighbours read
+// from the ring.  vol has a pitch of D floats per pixel (the oracle's layout).  Returns the number of units, -1 for D > 128.
+long emul_wta_right_march(const float* vol, float* disp, int W, int H, int dmin, int D, int ncu, int force_nseg)
+{
+    if (D > 128) return -1;
+    const int Dp = D <= 64 ? 64 : 128, P = Dp + 1, Dq = Dp / 8, R = ADC_WTAM_RING;
+    const AdcWtamPlan pl = adc_wtam_plan(W, H, D, ncu, force_nseg);
+    std::vector<float> ring((size_t)R * P);
+    std::vector<char> covered((size_t)W * H, 0);
+    for (int u = 0; u < pl.units; u++) {
+        const AdcWtamUnit un = adc_wtam_unit(u, W, pl.rows_full, pl.nseg, pl.segw);
+        if (un.x0 >= un.x1) continue;
+        const int G = (un.x1 - un.x0 + 63) >> 6, lag = adc_wtam_lag(D), last = G - 1 + lag;
+        std::fill(ring.begin(), ring.end(), -12345.0f); // (what was never written must never decide)
+        for (int s = 0; s <= (last | 1); s++) {
+            for (int wave = 0; wave < 8; wave++)
+                for (int j = 0; j < 8; j++) {
+                    const int i = s * 64 + wave * 8 + j, c = un.x0 + dmin + i;
+                    for (int d = 0; d < Dp; d++)
+                        ring[(size_t)(i & (R - 1)) * P + d] = (c >= 0 && c < W) ? (d < D ? vol[((size_t)un.y * W + c) * D + d] : 7.0f) : ADC_LARGE_FLOAT;
+                }
+            const int g = s - lag;
+            if (g < 0 || g >= G) continue;
+            for (int lane = 0; lane < 64; lane++) {
+                const int b = g * 64 + lane;
+                float pmin[8];
+                int pbest[8];
+                for (int wave = 0; wave < 8; wave++) {
+                    float mc = ADC_LARGE_FLOAT;
+                    int mb = -1;
+                    for (int t = 0; t < Dq; t++) {
+                        const int di = wave * Dq + t;
+                        const float v = ring[(size_t)((b + di) & (R - 1)) * P + di];
+                        const float cost = di < D ? v : ADC_LARGE_FLOAT;
+                        if (cost < mc) { mc = cost; mb = di; }
+                    }
+                    pmin[wave] = mc;
+                    pbest[wave] = mb;
+                }
+                float minc = ADC_LARGE_FLOAT;
+                int bi = -1;
+                for (int q = 0; q < 8; q++)
+                    if (pmin[q] < minc) { minc = pmin[q]; bi = pbest[q]; }
+                const int x = un.x0 + b;
+                if (x >= un.x1) continue;
+                const int best = bi < 0 ? 0 : bi + dmin, i1 = best - 1 - dmin, i2 = best + 1 - dmin;
+                float out = (float)best;
+                if (best != dmin && best != dmin + D - 1 && i1 >= 0 && i2 < D)
+                    out = adc_subpixel(best, ring[(size_t)((b + i1) & (R - 1)) * P + i1], ring[(size_t)((b + i2) & (R - 1)) * P + i2], minc);
+                disp[(size_t)un.y * W + x] = out;
+                covered[(size_t)un.y * W + x]++;
+            }
+        }
+    }
+    for (char c : covered)
+        if (c != 1) return -2; // every right pixel exactly once
+    return pl.units;
+}
+
 // ------------------------------------------------------------------ k_wta
 void emul_wta(const float* vol, float* disp, int W, int H, int dmin, int D, int right)
 {

@@ -73,6 +73,24 @@ def test_median_window_prefetch(device_asm):
     assert seen["k_median_bandedILb1E"] == 1 and seen["k_median_bandedILb0E"] == 1, seen
 
 
+def test_right_wta_march_prefetch(device_asm):
+    """K6 marching kernel: the pixel vectors of the next two steps are in flight; ONE hand-counted wait per step (vmcnt = the
+    loads of one step) takes a step over.  A wait one load too weak must be reported."""
+    res, seen = _check(device_asm("k_wta"), ["k_wta_right_marchILi1E", "k_wta_right_marchILi2E"])
+    assert seen == {"k_wta_right_marchILi1E": 1, "k_wta_right_marchILi2E": 1}, seen
+    assert sorted(r["asm_loads"] for r in res.values()) == [32, 64]  # two steps before the loop + two in it, 8 * VPL loads each
+    text = open(device_asm("k_wta")).read()
+    for pat, old, new in (("k_wta_right_marchILi1E", "vmcnt(8)", "vmcnt(9)"), ("k_wta_right_marchILi2E", "vmcnt(16)", "vmcnt(17)")):
+        for name, body in cal.functions(text):
+            if pat in name:
+                weak = [ln.replace(old, new) for ln in body]
+                assert weak != body and cal.analyse(weak)["bad"], (name, old)
+        # no scratch, and few enough registers for a workgroup of 8 waves
+        m = re.search(r"\.amdhsa_kernel _Z\d+" + pat + r"\w*\n(.*?)\.end_amdhsa_kernel", text, re.S)
+        assert m and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", m.group(1)), pat
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(1)).group(1)) <= 128, pat
+
+
 def test_aggregation_prefetch_and_record_blocks(device_asm):
     res, seen = _check(device_asm("k_aggregate"), ["k_agg_march", "k_agg_rr2I", "k_agg_rr2_cost", "k_agg_regringI", "k_agg_regring_cost",
                                                    "k_agg_regring_pair"])

@@ -370,6 +370,16 @@ def test_wta(emul, dumps, name):
     if dmin > 0:
         mask[:, w - dmin:] = False  # reference reads out of bounds there (documented, tests/gpu_harness.py)
     assert same(db[mask], o["disp_right_wta"][mask])
+    # marching form (k_wta_right_march, D <= 128): whole rows, and the plan's segments for several "CU counts"
+    if D <= 128:
+        emul.emul_wta_right_march.restype = C.c_long
+        for ncu, nseg in ((256, 0), (7, 0), (3, 0), (1, 0), (h + 1, 2), (h + 1, 3), (5, 8)):
+            dm = np.full((h, w), -7.0, np.float32)
+            units = emul.emul_wta_right_march(P(o["cost_so"]), P(dm), w, h, dmin, D, ncu, nseg)
+            assert units >= h, (ncu, nseg, units)
+            if nseg and ncu > h:
+                assert units == h * min(nseg, (w + 63) // 64), (ncu, nseg, units)
+            assert same(dm[mask], o["disp_right_wta"][mask]), (ncu, nseg)
 
 
 @pytest.mark.parametrize("name", EMUL_CASES)

@@ -404,6 +404,32 @@ def test_scanline_segment_variants(hip, env, expect_redo):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{"ADC_WTA_MARCH": "0"}, {"ADC_WTA_NCU": "1000", "ADC_WTA_NSEG": "2"}, {"ADC_WTA_NCU": "1000", "ADC_WTA_NSEG": "5"},
+                                 {"ADC_WTA_NCU": "7"}, {"ADC_WTA_NCU": "64", "ADC_WTA_NSEG": "3"}])
+def test_right_wta_variants(hip, env):
+    """K6: the band kernel (ADC_WTA_MARCH=0) and the marching kernel with forced launch plans (every row cut into 2 / 5 segments;
+    7 or 64 workgroups at a time: whole rows + a segmented remainder) give the oracle's right-view map stage by stage
+    (oracle cost_so in), for positive / negative min_disparity, D < 64, D = 128 and ranges the marching kernel does not take.
+    Switches are read once per process: own interpreter per variant."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests import cases, gpu_harness\n"
+            "from oracle import pyoracle\n"
+            "bad = {}\n"
+            "for name in ('s2_320x180_d128', 'noise_160x90_d128_pos', 's2_360x60_d300', 'cone_crop_d40', 's2_150x100_neg', 'q_1x40_d8', 'q_40x1_d8', 'q_257x131_d64'):\n"
+            "    l, r, opt = cases.make_case(name)\n"
+            "    o = pyoracle.load('auto').run(l, r, opt)\n"
+            "    rep = gpu_harness.stage_report(l, r, opt, o)\n"
+            "    bad.update({name + ':' + k: v['bad'] for k, v in gpu_harness.failing(rep).items()})\n"
+            "print('FAILING', bad)\n"
+            "sys.exit(1 if bad else 0)\n") % (root,)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_registered_host_buffers(hip, oracle):
     """adc_host_register: images / map inside a page-locked range go by DMA straight from / to the caller's memory (no staging);
     same result, also when only some of the three buffers are registered, and the plain path works again after unregister."""
