@@ -5,7 +5,7 @@
 # 1080p workloads, the voting-chain trace.  Summaries -> gpurun_out/r4_*, copied into profiles/ afterwards.
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
 REPO="$GRAFT_REPO_ROOT"; O=gpurun_out
-timeout 560 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -16 > $O/r4_gpu_pytest.log; cat $O/r4_gpu_pytest.log
+timeout 700 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -16 > $O/r4_gpu_pytest.log; cat $O/r4_gpu_pytest.log
 grep -q " passed" $O/r4_gpu_pytest.log && ! grep -q "failed\|error" $O/r4_gpu_pytest.log || { echo "TESTS NOT GREEN -- stopping"; exit 1; }
 timeout 300 python bench.py > $O/r4_bench_default.json 2> $O/r4_bench_default.err; echo "default rc=$?"; cut -c1-300 $O/r4_bench_default.json
 timeout 300 python bench.py --workload structured --steps 10 --cpu-baseline-structured > $O/r4_bench_structured.json 2> $O/r4_bench_structured.err; echo "structured rc=$?"; cut -c1-200 $O/r4_bench_structured.json
