@@ -237,6 +237,14 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
     const long long pix_step = VERT ? (long long)W : 1LL;
     const long long pix0 = VERT ? (long long)fixed : (long long)fixed * W;
     const long long fstep = pix_step * Dp; // floats per step
+#ifdef RR2_FAKE_MEM // (timing experiment only: 1 = every steady-state load AND store of a wave goes to ONE address, 2 = the loads, 3 = the
+                    // stores -- the results are garbage; profiles/r4_k4_fake_mem.txt)
+#define RR2_MSTEP_LD (RR2_FAKE_MEM == 3 ? fstep : 0)
+#define RR2_MSTEP_ST (RR2_FAKE_MEM == 2 ? fstep : 0)
+#else
+#define RR2_MSTEP_LD fstep
+#define RR2_MSTEP_ST fstep
+#endif
     const float* sp = src + pix0 * Dp + chunk * 128 + 2 * lane;
     float* dpn = dst + pix0 * Dp + chunk * 128 + 2 * lane + (long long)m0 * fstep; // outputs leave in increasing order from m0
     const uint2* rl = rec + (long long)fixed * N;                                  // records of this line
@@ -345,7 +353,7 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
             acc_ = rr2_make(rr_divide(acc_.x, cf_, y_), rr_divide(acc_.y, cf_, y_)); /* cross_aggregator.cpp:389 */  \
         }                                                                                                            \
         *reinterpret_cast<rr2_f2*>(dpn) = acc_;                                                                      \
-        dpn += fstep;                                                                                                \
+        dpn += RR2_MSTEP_ST;                                                                                         \
     } while (0)
 
     // ---- phase A: entries lo .. jB-1 precede the first output's look-ahead (no output yet)
@@ -415,7 +423,7 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
 #pragma unroll
             for (int u = 0; u < RR2_PF; u++) {
                 RR2_VLOAD(pf[u], spn);
-                spn += fstep;
+                spn += RR2_MSTEP_LD;
             }
 // one step; WAITN = vector-memory operations younger than slot U's load that may stay in flight
 #define RR2_STEP(U, WAITN)                                                                                           \
@@ -423,7 +431,7 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
         rr2_f2 v_;                                                                                                   \
         RR2_WAIT_TAKE(v_, pf[U], WAITN);                                                                             \
         RR2_VLOAD(pf[U], spn);                                                                                       \
-        spn += fstep;                                                                                                \
+        spn += RR2_MSTEP_LD;                                                                                         \
         RR2_PUSH(v_);                                                                                                \
         RR2_EMIT(pos + (U), w1); /* exactly one compiler-issued vector-memory operation (a store) */                 \
     } while (0)
