@@ -128,9 +128,22 @@ ADC_HD uint32_t irv_tile_hit(uint32_t word, uint32_t nk, uint32_t want4)
 struct IrvBlock {
     uint32_t okm;   // pixels that count in the vote (bit q = pixel px0 + q)
     uint32_t first; // bin of the lowest counted pixel
+    uint32_t same;  // the counted pixels that fall into `first` (== okm when single)
     bool single;    // all counted pixels fall into `first`
     bool open;      // an eligible predecessor of p in this block is not final yet
 };
+// The pixels of `rem` (a non-empty subset of a block's counted pixels) that share the bin of the lowest one; *bin = that bin.
+ADC_HD uint32_t irv_same_bin_mask(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t vw, uint32_t rem, uint32_t* bin)
+{
+    const uint32_t b0 = vx & 0x07FF07FFu, b1 = vy & 0x07FF07FFu, b2 = vz & 0x07FF07FFu, b3 = vw & 0x07FF07FFu;
+    const int q0 = __builtin_ffs((int)rem) - 1;
+    const uint32_t wsel = q0 < 2 ? b0 : (q0 < 4 ? b1 : (q0 < 6 ? b2 : b3));
+    const uint32_t f = (wsel >> (16 * (q0 & 1))) & IRV_BIN_MASK, f2 = f * 0x00010001u;
+    // halfwords that differ from that bin: (d + 0x7FF) carries into bit 11 iff d != 0
+    const uint32_t difm = irv_gather8((b0 ^ f2) + 0x07FF07FFu, (b1 ^ f2) + 0x07FF07FFu, (b2 ^ f2) + 0x07FF07FFu, (b3 ^ f2) + 0x07FF07FFu, 11);
+    *bin = f;
+    return rem & ~difm;
+}
 // Block of 8 pixels px0 .. px0 + 7 of region row yt, of which [xl, xr] belong to the region of p = (x, y).
 ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t vw, int px0, int xl, int xr, int yt, int y, int x)
 {
@@ -149,6 +162,7 @@ ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t
     // an eligible predecessor that is not final yet: this vote may still change
     r.open = (inm & elm & prem & ~finm) != 0u;
     r.first = 0u;
+    r.same = 0u;
     r.single = false;
     if (r.okm != 0u) {
         const int q0 = __builtin_ffs((int)r.okm) - 1;
@@ -157,7 +171,8 @@ ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t
         const uint32_t f2 = r.first * 0x00010001u;
         // halfwords that differ from the first counted bin: (d + 0x7FF) carries into bit 11 iff d != 0
         const uint32_t difm = irv_gather8((b0 ^ f2) + 0x07FF07FFu, (b1 ^ f2) + 0x07FF07FFu, (b2 ^ f2) + 0x07FF07FFu, (b3 ^ f2) + 0x07FF07FFu, 11);
-        r.single = (difm & r.okm) == 0u;
+        r.same = r.okm & ~difm;
+        r.single = r.same == r.okm;
     }
     return r;
 }

@@ -381,19 +381,40 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                         }
                         IRV_T(5);
                         // The 8 pixels of the block, decoded as packed halfwords (irv_plan.h: irv_decode_block): which pixels
-                        // count, and do they all fall into ONE bin?
+                        // count, and which of them share the first one's bin?
                         uint32_t okm = 0u;
                         if (use) {
                             const IrvBlock bd = irv_decode_block(v.x, v.y, v.z, v.w, blk * 8, xl, xr, yt, y, x);
                             deps_open = deps_open || bd.open;
                             okm = bd.okm;
-                            // (same-address LDS atomics serialise: one per lane instead of eight.  Counting the dominant bin in
-                            // registers across the wave was measured too: slower, the extra wave reduction costs more.)
+                            // One LDS atomic per DISTINCT bin of the block (same-address LDS atomics serialise: never one per pixel).  The
+                            // pixels of the first bin come with the decode; a region row that straddles a disparity edge holds a second
+                            // surface (24-27 % of the blocks of a natural image hold several bins, tools/irv_block_stats.py), rarely a
+                            // third: the loop takes the lowest remaining pixel's bin and all pixels that share it.  Round 4: before, every
+                            // pixel of a block with several bins was counted by its own atomic, the wave running as many trips as its worst
+                            // lane had pixels (2.7-4.4 trips per vote; refine stage of the structured pair 4.75 -> 4.28 ms,
+                            // profiles/r4_ab_k8_merge_bins.txt; IRV_PER_PIXEL_ATOMICS restores that form for the A/B).  (Counting the
+                            // dominant bin in registers across the wave was measured too: slower, the extra wave reduction costs more.)
+#ifdef IRV_PER_PIXEL_ATOMICS
                             if (okm != 0u && bd.single) {
                                 atomicAdd(&hist[bd.first], __popc(okm));
                                 okm = 0u;
                             }
+#else
+                            if (okm != 0u) {
+                                atomicAdd(&hist[bd.first], __popc(bd.same));
+                                okm &= ~bd.same;
+                            }
+#pragma clang loop unroll(disable)
+                            while (okm != 0u) {
+                                uint32_t bin2;
+                                const uint32_t same2 = irv_same_bin_mask(v.x, v.y, v.z, v.w, okm, &bin2);
+                                atomicAdd(&hist[bin2], __popc(same2));
+                                okm &= ~same2;
+                            }
+#endif
                         }
+#ifdef IRV_PER_PIXEL_ATOMICS
                         if (okm != 0u) { // pixels of several bins: one atomic each
 #pragma clang loop unroll(disable)
                             for (uint32_t m = okm; m != 0u; m &= m - 1u) {
@@ -402,6 +423,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                                 atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
                             }
                         }
+#endif
                         if (!__any(rowok && (blkL + bo + 4 <= b1x))) break;
                     }
                 }

@@ -186,6 +186,22 @@ extern "C" long emul_irv_swar_check(unsigned seed, long trials)
         }
         if (got.okm != okm || got.open != open) bad++;
         else if (okm && (got.first != first || got.single != single)) bad++;
+        else if (okm) { // the pixels of the first bin, and -- on what is left -- the pixels that share the bin of the lowest one
+            uint32_t same = 0;
+            for (int q = 0; q < 8; q++)
+                if (((okm >> q) & 1u) && (s16[q] & IRV_BIN_MASK) == first) same |= 1u << q;
+            if (got.same != same) bad++;
+            uint32_t rem = okm & ~same;
+            while (rem) {
+                uint32_t bin = 0xFFFFu, want_mask = 0;
+                const uint32_t got_mask = irv_same_bin_mask(w[0], w[1], w[2], w[3], rem, &bin);
+                const uint32_t b = s16[__builtin_ctz(rem)] & IRV_BIN_MASK;
+                for (int q = 0; q < 8; q++)
+                    if (((rem >> q) & 1u) && (s16[q] & IRV_BIN_MASK) == b) want_mask |= 1u << q;
+                if (bin != b || got_mask != want_mask || !got_mask) { bad++; break; }
+                rem &= ~got_mask;
+            }
+        }
         // ---- change-tile row
         uint8_t tb[16];
         const uint32_t stamp = 1 + rand() % 255;
