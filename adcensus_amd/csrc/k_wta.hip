@@ -190,65 +190,65 @@ __global__ __launch_bounds__(64 * WTAM_WAVES) void k_wta_right_march(const float
     // bookkeeping drains the queue at the loop's back edge: built first, it waited for the loads it had just issued): when step s is
     // taken over, the 8 * VPL loads of step s + 1 are the only younger ones of the wave that may still be outstanding (the store of a
     // combining wave can only make the wait stronger); proven on the generated code by tools/check_async_loads.py.
-#define WTAM_ISSUE(buf, s)                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                                   \
-        const int c = un.x0 + dmin + (s) * 64 + wave * VPW + j;                                                         \
-        const float* vp = row + (size_t)(c < 0 ? 0 : (c >= W ? W - 1 : c)) * Dp;                                        \
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(buf[j][0]) : "v"(lane4), "s"(vp) : "memory");                \
+#define WTAM_ISSUE(buf, s)                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                                 \
+        const int c = un.x0 + dmin + (s) * 64 + wave * VPW + j;                                                       \
+        const float* vp = row + (size_t)(c < 0 ? 0 : (c >= W ? W - 1 : c)) * Dp;                                      \
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(buf[j][0]) : "v"(lane4), "s"(vp) : "memory");              \
         if constexpr (VPL == 2) asm volatile("global_load_dword %0, %1, %2 offset:256" : "=v"(buf[j][1]) : "v"(lane4), "s"(vp) : "memory"); \
     }
-#define WTAM_TAKE(buf)                                                                                                  \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WTAM_DEPTH - 1) * VPW * VPL) : "memory");                                                  \
-    _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                                   \
-        asm volatile("v_mov_b32 %0, %1" : "=v"(cur[j][0]) : "v"(buf[j][0]));                                            \
-        if constexpr (VPL == 2) asm volatile("v_mov_b32 %0, %1" : "=v"(cur[j][1]) : "v"(buf[j][1]));                    \
+#define WTAM_TAKE(buf)                                                                                                \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WTAM_DEPTH - 1) * VPW * VPL) : "memory");                               \
+    _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                                 \
+        asm volatile("v_mov_b32 %0, %1" : "=v"(cur[j][0]) : "v"(buf[j][0]));                                          \
+        if constexpr (VPL == 2) asm volatile("v_mov_b32 %0, %1" : "=v"(cur[j][1]) : "v"(buf[j][1]));                  \
     }
-#define WTAM_STEP(buf, s)                                                                                               \
-    {                                                                                                                   \
-        WTAM_TAKE(buf)                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                               \
-            const int i = (s) * 64 + wave * VPW + j, c = un.x0 + dmin + i;                                              \
-            const bool in_img = c >= 0 && c < W;                                                                        \
-            _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                             \
-                wring[(i & (ADC_WTAM_RING - 1)) * P + lane + 64 * k] = in_img ? cur[j][k] : ADC_LARGE_FLOAT;            \
-        }                                                                                                               \
-        WTAM_ISSUE(buf, (s) + WTAM_DEPTH)                                                                                     \
-        __syncthreads();                                                                                                \
-        const int g = (s) - lag, b = g * 64 + lane;                                                                     \
-        if (g >= 0 && g < G) {                                                                                          \
-            float mc = ADC_LARGE_FLOAT;                                                                                 \
-            int mb = -1;                                                                                                \
+#define WTAM_STEP(buf, s)                                                                                             \
+    {                                                                                                                 \
+        WTAM_TAKE(buf)                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                             \
+            const int i = (s) * 64 + wave * VPW + j, c = un.x0 + dmin + i;                                            \
+            const bool in_img = c >= 0 && c < W;                                                                      \
+            _Pragma("unroll") for (int k = 0; k < VPL; k++)                                                           \
+                wring[(i & (ADC_WTAM_RING - 1)) * P + lane + 64 * k] = in_img ? cur[j][k] : ADC_LARGE_FLOAT;          \
+        }                                                                                                             \
+        WTAM_ISSUE(buf, (s) + WTAM_DEPTH)                                                                             \
+        __syncthreads();                                                                                              \
+        const int g = (s) - lag, b = g * 64 + lane;                                                                   \
+        if (g >= 0 && g < G) {                                                                                        \
+            float mc = ADC_LARGE_FLOAT;                                                                               \
+            int mb = -1;                                                                                              \
             _Pragma("unroll") for (int t = 0; t < Dq; t++) { /* (all reads of the part first; padding disparities never win) */ \
-                const int di = di0 + t;                                                                                 \
-                const float v = wring[((b + di) & (ADC_WTAM_RING - 1)) * P + di];                                       \
-                const float cost = di < D ? v : ADC_LARGE_FLOAT;                                                        \
-                if (cost < mc) { mc = cost; mb = di; }                                                                  \
-            }                                                                                                           \
-            pmin[wave][lane] = mc;                                                                                      \
-            pbest[wave][lane] = mb;                                                                                     \
-        }                                                                                                               \
-        __syncthreads();                                                                                                \
-        if (g >= 0 && g < G && wave == (g & (NW - 1))) {                                                                       \
-            float minc = ADC_LARGE_FLOAT;                                                                               \
-            int bi = -1;                                                                                                \
-            _Pragma("unroll") for (int q = 0; q < NW; q++) {                                                             \
-                const float m = pmin[q][lane];                                                                          \
-                const int mbq = pbest[q][lane];                                                                         \
-                if (m < minc) { minc = m; bi = mbq; }                                                                   \
-            }                                                                                                           \
-            const int x = un.x0 + b;                                                                                    \
-            if (x < un.x1) {                                                                                            \
+                const int di = di0 + t;                                                                               \
+                const float v = wring[((b + di) & (ADC_WTAM_RING - 1)) * P + di];                                     \
+                const float cost = di < D ? v : ADC_LARGE_FLOAT;                                                      \
+                if (cost < mc) { mc = cost; mb = di; }                                                                \
+            }                                                                                                         \
+            pmin[wave][lane] = mc;                                                                                    \
+            pbest[wave][lane] = mb;                                                                                   \
+        }                                                                                                             \
+        __syncthreads();                                                                                              \
+        if (g >= 0 && g < G && wave == (g & (NW - 1))) {                                                              \
+            float minc = ADC_LARGE_FLOAT;                                                                             \
+            int bi = -1;                                                                                              \
+            _Pragma("unroll") for (int q = 0; q < NW; q++) {                                                          \
+                const float m = pmin[q][lane];                                                                        \
+                const int mbq = pbest[q][lane];                                                                       \
+                if (m < minc) { minc = m; bi = mbq; }                                                                 \
+            }                                                                                                         \
+            const int x = un.x0 + b;                                                                                  \
+            if (x < un.x1) {                                                                                          \
                 const int best = bi < 0 ? 0 : bi + dmin; /* best_disparity keeps its initial 0 when nothing is below Large_Float */ \
-                const int i1 = best - 1 - dmin, i2 = best + 1 - dmin;                                                   \
-                float out = (float)best; /* the integer at the range ends (:296-300) */                                 \
-                if (best != dmin && best != dmin + D - 1 && i1 >= 0 && i2 < D) {                                        \
-                    const float c1 = wring[((b + i1) & (ADC_WTAM_RING - 1)) * P + i1];                                  \
-                    const float c2 = wring[((b + i2) & (ADC_WTAM_RING - 1)) * P + i2];                                  \
-                    out = adc_subpixel(best, c1, c2, minc);                                                             \
-                }                                                                                                       \
-                disp[(size_t)un.y * W + x] = out;                                                                       \
-            }                                                                                                           \
-        }                                                                                                               \
+                const int i1 = best - 1 - dmin, i2 = best + 1 - dmin;                                                 \
+                float out = (float)best; /* the integer at the range ends (:296-300) */                               \
+                if (best != dmin && best != dmin + D - 1 && i1 >= 0 && i2 < D) {                                      \
+                    const float c1 = wring[((b + i1) & (ADC_WTAM_RING - 1)) * P + i1];                                \
+                    const float c2 = wring[((b + i2) & (ADC_WTAM_RING - 1)) * P + i2];                                \
+                    out = adc_subpixel(best, c1, c2, minc);                                                           \
+                }                                                                                                     \
+                disp[(size_t)un.y * W + x] = out;                                                                     \
+            }                                                                                                         \
+        }                                                                                                             \
     }
     WTAM_ISSUE(bufA, 0)
     WTAM_ISSUE(bufB, 1)
