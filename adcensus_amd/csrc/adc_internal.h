@@ -85,6 +85,17 @@ struct adc_handle {
                           // raise armmax[3]; adc_wait then redoes the Match), 3 unknown in the pipeline: full ring (always valid)
     int arm_known;        // armmax_host holds the maxima of the previous Match
     int arm_redos;        // how often the assumption was wrong
+    // Streams that alternate between short-arm and long-arm images: instead of assuming ONE ring depth and redoing the
+    // Match when it is wrong, the aggregation is enqueued as TWO plans (assumed small rings + pass pairs | full ring) and the
+    // kernels decide on the device which plan works (agg_gate_skip, k_aggregate_rr.h).
+    int agg_dual;         // > 0: enqueue both plans (set to 64 whenever consecutive Matches needed different plans, counts down)
+    int agg_dual_last;    // the last aggregation run enqueued both plans (per-launch timings are then not separable)
+    int agg_last_plan;    // plan the previous Match's image needed: 0 none yet, 1 small rings, 2 full ring
+    int agg_switches;     // how often consecutive Matches needed different plans
+    int agg_dual_runs;    // Matches whose aggregation was enqueued as two plans
+    int armmax_small[2];  // arm maxima of the last image that fitted the small rings (0 = none seen)
+    int agg_gate, agg_gate_thr; // set while a plan of a two-plan run is being enqueued: gate code (3 / 4) and packed depths
+    int redo_partial;     // redos that restarted at the aggregation instead of the whole Match
     int fuse_cost;        // set by the pipeline: the first aggregation pass computes the matching cost itself
     int agg_first_fused;  // the last aggregation run did so (pass timings: the regular passes are 1..)
     int fuse_wta;         // set by the pipeline: the last scanline pass also writes the left-view disparity map

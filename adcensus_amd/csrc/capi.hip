@@ -349,7 +349,10 @@ static bool heavy_exclusive()
     return v;
 }
 
-static hipError_t run_heavy(adc_handle* h)
+// from_aggregation: a redo by adc_wait that keeps what the stages in front of the aggregation produced (gray / census, the pixel
+// records of the fused cost, arms, support counts, aggregation records: none of them is touched by the later stages) and
+// restarts at the first aggregation pass -- possible whenever that pass computes the matching cost itself (no input volume).
+static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
 {
     const bool prof = h->profiling != 0;
 #define MARK(i, s) do { if (prof) HIP_OK(hipEventRecord(h->ev[i], s)); } while (0)
@@ -358,11 +361,17 @@ static hipError_t run_heavy(adc_handle* h)
         HIP_OK(hipStreamWaitEvent(h->heavy, h->ev_in, 0));
     }
     MARK(0, h->heavy);
+    static const bool fuse_cost = [] { const char* e = getenv("ADC_FUSE_COST"); return e ? atoi(e) != 0 : true; }();
+    const bool fuse_cost_now = fuse_cost && !(h->paper & ADC_PAPER_RIGHT_ARMS); // (paper mode: plain kernels on a stored cost volume)
+    if (from_aggregation) {
+        MARK(1, h->heavy);
+        MARK(2, h->heavy);
+        HIP_OK(hipMemsetAsync(h->armmax + 2, 0, 2 * sizeof(int), h->heavy)); // failed seams, "assumed ring too shallow" flag
+        h->armmax_valid = 3; // the full ring: valid for every image
+    } else {
     HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
     // ADC_FUSE_COST (default on): the cost volume is never written -- the first aggregation pass computes each cost
     // in registers from packed pixel records (k_agg_march<.., COSTIN>); otherwise K2 writes it and pass 1 reads it back
-    static const bool fuse_cost = [] { const char* e = getenv("ADC_FUSE_COST"); return e ? atoi(e) != 0 : true; }();
-    const bool fuse_cost_now = fuse_cost && !(h->paper & ADC_PAPER_RIGHT_ARMS); // (paper mode: plain kernels on a stored cost volume)
     if (fuse_cost_now) HIP_OK(adc_launch_cost_records(h));
     else HIP_OK(adc_launch_cost(h, h->vol_a));
     MARK(1, h->heavy);
@@ -386,6 +395,7 @@ static hipError_t run_heavy(adc_handle* h)
         }
     }
     HIP_OK(adc_launch_records(h));
+    } // (!from_aggregation)
     h->fuse_cost = fuse_cost_now ? 1 : 0;
     {
         const hipError_t e_ = adc_launch_aggregate(h, 4); // aggregator_.Aggregate(4), :164
@@ -412,15 +422,15 @@ static hipError_t run_heavy(adc_handle* h)
     return hipSuccess;
 }
 
-static hipError_t run_pipeline(adc_handle* h)
+static hipError_t run_pipeline(adc_handle* h, bool from_aggregation = false)
 {
     if (heavy_exclusive()) {
         // the uploads of this pair (already queued on the object's stream) run before the lock is taken
         std::lock_guard<std::mutex> lk(heavy_lock(h->device));
-        HIP_OK(run_heavy(h));
+        HIP_OK(run_heavy(h, from_aggregation));
         HIP_OK(hipEventSynchronize(h->ev_heavy_done)); // hold the lane until the streaming phase has drained
     } else {
-        HIP_OK(run_heavy(h));
+        HIP_OK(run_heavy(h, from_aggregation));
     }
     HIP_OK(run_refine(h));                       // MultiStepRefine, :117 (object stream)
     if (h->profiling) HIP_OK(hipEventRecord(h->ev[6], h->stream));
@@ -440,7 +450,8 @@ static void collect_timings(adc_handle* h)
     float tot = 0.f;
     // average duration of a REGULAR aggregation pass (read V + write V); a fused first pass (write-only) is left out
     const int first = h->agg_first_fused ? 1 : 0;
-    if (h->agg_launches > first && hipEventElapsedTime(&tot, h->ev_agg[first], h->ev_agg[h->agg_launches]) == hipSuccess)
+    if (h->agg_dual_last) h->agg_pass_ms = 0.f; // (two plans were enqueued: the marks bracket launches that may have been skipped)
+    else if (h->agg_launches > first && hipEventElapsedTime(&tot, h->ev_agg[first], h->ev_agg[h->agg_launches]) == hipSuccess)
         h->agg_pass_ms = tot / (float)(h->agg_launches - first);
     if (h->verbose) { // the reference's stage lines (ADCensusStereo.cpp:88-129)
         printf("computing cost! timing :	%lf s\n", (h->stage_ms[0]) / 1000.0);
@@ -545,22 +556,40 @@ int adc_wait(adc_handle* h)
     hipSetDevice(h->device);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("adc_wait", hipGetLastError()); return 2; }
     // (1) the aggregation assumed the arm maxima of the previous Match; a longer arm raised the flag and the pass was
-    //     skipped: redo the whole Match with the full ring (valid for every image).  The inputs are still in HBM.
+    //     skipped: redo with the full ring (valid for every image).
+    // (1b) a row of the scanline passes was cut into segments and a segment's warm-up did not reach the state of the full
+    //     pass (pin_flags[6] = seams that failed): redo with whole rows, and keep them for the next Matches.
+    //     Both redos restart at the aggregation when its first pass computes the matching cost itself (the default): the
+    //     pixel records, arms and aggregation records of this pair are still in HBM; otherwise the whole Match runs again
+    //     (the inputs are still there).  EVERY redo runs whole scanline rows: its volume differs from the first run's when the
+    //     aggregation was skipped, so a seam could fail there that did not fail before (round-4 advisor finding) -- and the
+    //     seam count is looked at again behind the redo.
     if (h->pin_flags) {
-        // (1b) a row of the scanline passes was cut into segments and a segment's warm-up did not reach the state of the full
-        //     pass (pin_flags[6] = seams that failed): redo the Match with whole rows, and keep them for the next Matches
-        if (h->pin_flags[7] != 0 || h->pin_flags[6] != 0) {
+        for (int attempt = 0; attempt < 2 && (h->pin_flags[7] != 0 || h->pin_flags[6] != 0); attempt++) {
             if (h->pin_flags[7] != 0) { h->arm_redos++; h->arm_known = 0; }
             if (h->pin_flags[6] != 0) { h->so_seam_redos++; h->so_seg_off = 64; }
-            hipError_t e = run_pipeline(h);
+            if (h->so_seg_off < 1) h->so_seg_off = 1; // whole rows in every redo
+            const bool partial = h->agg_first_fused != 0 && !(h->paper & ADC_PAPER_RIGHT_ARMS);
+            if (partial) h->redo_partial++;
+            hipError_t e = run_pipeline(h, partial);
             if (e == hipSuccess) e = enqueue_output(h);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { set_error("adc_wait: redo with the full aggregation ring", e); return 2; }
+            if (e != hipSuccess) { set_error("adc_wait: redo (full aggregation ring / whole scanline rows)", e); return 2; }
         }
+        if (h->pin_flags[7] != 0 || h->pin_flags[6] != 0) { g_last_error = "adc_wait: redo did not clear the speculation flags"; return 2; }
         h->armmax_host[0] = h->pin_flags[4];
         h->armmax_host[1] = h->pin_flags[5];
         h->arm_known = 1;
-        if (h->so_seg_off > 0 && h->pin_flags[6] == 0) h->so_seg_off--; // (whole rows for a while after a failed seam)
+        if (h->so_seg_off > 0) h->so_seg_off--; // (whole rows for a while after a failed seam)
+        {   // which plan did this image need?  Consecutive Matches that need different plans = a mixed stream: the next 64
+            // Matches enqueue both plans and let the device choose (k_aggregate.hip) instead of assuming and redoing
+            const int small_L = adc_agg_small_L(h);
+            const int plan = (h->pin_flags[4] <= small_L && h->pin_flags[5] <= small_L) ? 1 : 2;
+            if (plan == 1) { h->armmax_small[0] = h->pin_flags[4] > 0 ? h->pin_flags[4] : 1; h->armmax_small[1] = h->pin_flags[5] > 0 ? h->pin_flags[5] : 1; }
+            if (h->agg_last_plan != 0 && plan != h->agg_last_plan) { h->agg_switches++; h->agg_dual = 64; }
+            else if (h->agg_dual > 0) h->agg_dual--;
+            h->agg_last_plan = plan;
+        }
     }
     // (2) the voting chain ran out of its launch budget before it converged: continue it, redo the stages behind it
     int continued = 0;
@@ -940,6 +969,10 @@ int64_t adc_debug_counter(adc_handle* h, int which)
     case 0: return h->median_fallbacks;
     case 1: return h->irv_overflows;
     case 2: return h->arm_redos;
+    case 9: return h->agg_switches;   // consecutive Matches that needed different aggregation plans
+    case 10: return h->agg_dual_runs; // Matches whose aggregation was enqueued as two plans (the device chose)
+    case 11: return h->redo_partial;  // redos that restarted at the aggregation (not the whole Match)
+    case 12: return h->agg_dual;      // > 0: the next Match enqueues both plans
     case 3: return h->irv_budget;
     case 7: return h->med_spec_fails;
     case 8: return h->med_spec_last;

@@ -225,15 +225,8 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
     // small_variant == 2: the host ASSUMED (from the previous Match of the handle) that no arm of this direction exceeds
     // small_L = the ring depth of this launch; when the assumption is wrong the pass is skipped and armmax[3] raised --
     // adc_wait then redoes the Match with the full ring.
-    if (small_variant >= 0) {
-        const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
-        if (small_variant == 2) {
-            if (!fits_small) {
-                if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<int*>(armmax)[3] = 1;
-                return;
-            }
-        } else if ((small_variant != 0) != fits_small) return;
-    }
+    // small_variant 3 / 4: two plans enqueued back to back, exactly one of them works (agg_gate_skip, k_aggregate_rr.h)
+    if (agg_gate_skip(armmax, small_variant, small_L, VERT)) return;
     extern __shared__ __attribute__((aligned(16))) float ring_all[];
     const int R = 2 * L + 1;
     const int lane = threadIdx.x;
@@ -720,6 +713,16 @@ static int pick_chunk(long long nlines, int N, int L, int slots)
     return best;
 }
 
+// Ring depth of a small-ring launch along one direction when the host works with arm maxima (armmax_host): the longest arm,
+// plus one entry of margin when the maxima are ASSUMED from an earlier Match of the handle (armmax_valid == 2; the next image of a
+// similar stream may have a longest arm of 3 after 2, and a wrong depth costs a redo or the full-ring plan: ADC_AGG_ASSUME_MARGIN).
+static int agg_assumed_depth(const adc_handle* h, bool vert)
+{
+    const int assume_margin = env_int("ADC_AGG_ASSUME_MARGIN", 1); // (read per call: the tests vary it within one process)
+    const int Lknown = adc_imax(1, h->armmax_host[vert ? 1 : 0]) + (h->armmax_valid == 2 ? assume_margin : 0);
+    return adc_imin(adc_agg_small_L(h), Lknown);
+}
+
 // which: 0 = the host does not know the arms: launch the full-ring and the small-ring variant, the kernel decides;
 //        1 = small ring only, 2 = full ring only (the host has read armmax).  PAIR needs which == 1.
 template <bool VERT, bool DIVIDE, bool COSTIN = false, bool PAIR = false>
@@ -742,11 +745,7 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         if (variant == 1 && (small_L <= 0 || small_L >= L)) break;
         if ((which == 1 && variant == 0 && small_L > 0 && small_L < L) || (which == 2 && variant == 1)) continue;
         // the ring only has to be as deep as the longest arm of this direction when the host knows it (which == 1)
-        // armmax_valid == 2: the depth is ASSUMED from the previous Match of the handle -- one entry of margin, so that the
-        // next image of a similar stream (a longest arm of 3 after 2) does not force a redo (ADC_AGG_ASSUME_MARGIN)
-        static const int assume_margin = env_int("ADC_AGG_ASSUME_MARGIN", 1);
-        const int Lknown = adc_imax(1, h->armmax_host[VERT ? 1 : 0]) + (h->armmax_valid == 2 ? assume_margin : 0);
-        const int Lv = variant ? ((which == 1 && h->armmax_valid) ? adc_imin(small_L, Lknown) : small_L) : L;
+        const int Lv = variant ? ((which == 1 && h->armmax_valid) ? agg_assumed_depth(h, VERT) : small_L) : L;
         // the fused-cost variant keeps the two cost tables (768 + 64 floats) behind the ring, the pair variant a second
         // ring and a record ring
         // full ring of a plain pass: in registers when it fits (ADC_AGG_REGRING=0: LDS ring)
@@ -770,7 +769,8 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
         const int per_xcd = (int)((waves + 7) / 8);
         const bool both = which == 0 && small_L > 0 && small_L < L;
         const bool verify = variant == 1 && which == 1 && h->armmax_valid == 2; // ring depth assumed from the previous Match
-        const int sv = both ? variant : (verify ? 2 : -1), sl = both ? small_L : (verify ? Lv : 0x7fffffff);
+        int sv = both ? variant : (verify ? 2 : -1), sl = both ? small_L : (verify ? Lv : 0x7fffffff);
+        if (h->agg_gate) { sv = h->agg_gate; sl = h->agg_gate_thr; } // one of two plans enqueued back to back (adc_launch_aggregate)
         AggCostIn ci;
         ci.rrec = reinterpret_cast<const uint4*>(h->cost_rrec);
         ci.lrec = reinterpret_cast<const uint4*>(h->cost_lrec);
@@ -823,10 +823,14 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
     return hipGetLastError();
 }
 
-// vol_a -> (H,V | V,H alternating) -> vol_a.  Every iteration is two launches: a -> b -> a.
-hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
+// One plan of the aggregation: the launch sequence for the ring choice (which_h, which_v) the handle's state implies.
+//   dry            only count (no launch, no event, nothing of the handle changes)
+//   first_into_cur the first launch writes the volume it would have READ (only with the fused cost, which has no input volume):
+//                  flips which of the two volumes the plan ends in
+//   marks          record the profiling events / launch statistics of this plan
+struct AggSeq { int launches, passes; float* result; bool first_fused; };
+static hipError_t agg_sequence(adc_handle* h, int iterations, bool dry, bool first_into_cur, bool marks, AggSeq* out)
 {
-    if ((h->paper & ADC_PAPER_RIGHT_ARMS) && h->arms_r) return adc_paper_aggregate(h, iterations); // opt-in paper mode (k_paper.hip)
     static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
     static const bool pair_env = env_int("ADC_AGG_PAIR", 1) != 0;
     // pairs with the full ring: 0 (default) = never, 1 = when both rings fit into registers (k_agg_regring_pair), 2 = also
@@ -837,29 +841,12 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     // 3x slower.  The single pass itself now runs at the device copy rate.
     static const int pair_full = env_int("ADC_AGG_PAIR_FULL", 0);
     static const bool regring_on = env_int("ADC_AGG_REGRING", 1) != 0;
-    {   // allow > 64 KiB dynamic LDS for the ring (large cross_L1): a per-DEVICE function attribute -- set once for every
-        // device this process drives (a farm on device 1 after one on device 0), under a lock (handles on several threads)
-        static std::mutex attr_mu;
-        static bool attr_set[64] = {false};
-        std::lock_guard<std::mutex> lk(attr_mu);
-        const int dv = (h->device >= 0 && h->device < 64) ? h->device : 0;
-        if (!attr_set[dv]) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set[dv] = true;
-        }
-    }
     hipError_t e = hipSuccess;
     const int Lfull = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
     const bool regring_fits = regring_on && Lfull >= 1 && 2 * Lfull + 1 <= AGG_RING_REGS;
     const bool lds_fits = (size_t)(2 * Lfull + 1) * 64 * sizeof(float) + (768 + 64) * sizeof(float) <= 150 * 1024;
     const bool marching = !direct && (size_t)(2 * Lfull + 1) * 64 * sizeof(float) <= 150 * 1024;
-    h->agg_first_fused = 0;
+    const bool prof = marks && !dry && h->profiling;
     // armmax_host (valid when the pipeline / caller read the maximum arms back): pick the ring on the host
     const int small_L = adc_agg_small_L(h);
     const bool small_ok = small_L > 0 && small_L < Lfull;
@@ -879,36 +866,42 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     int launch = 0;
     int passes = 0; // algorithmic passes (cross_aggregator.cpp: 2 per iteration) covered by the launches so far
     bool second_done = false; // the first pass of this iteration was already computed by the previous pair launch
+    bool first_fused = false;
     for (int k = 0; k < iterations && e == hipSuccess; k++) {
         const bool hf = horizontal_first;
         if (!second_done) {
-            if (h->profiling && launch < 2) hipEventRecord(h->ev_agg[launch], h->heavy); // (only the marks adc_wait reads: start of the first / first regular launch)
+            if (prof && launch < 2) hipEventRecord(h->ev_agg[launch], h->heavy); // (only the marks adc_wait reads: start of the first / first regular launch)
+            bool swap = true;
             if (hf) {
                 // first pass of the pipeline: the matching cost is computed inside the pass (no input volume)
                 const bool fused = k == 0 && h->fuse_cost && !direct && lds_fits;
-                if (k == 0) h->agg_first_fused = fused ? 1 : 0;
-                if (fused) e = launch_pass<false, false, true>(h, cur, oth, direct, which_h);
-                else e = launch_pass<false, false>(h, cur, oth, direct, which_h);
-            } else {
+                if (k == 0) first_fused = fused;
+                if (fused) {
+                    swap = !first_into_cur;
+                    if (!dry) e = launch_pass<false, false, true>(h, cur, swap ? oth : cur, direct, which_h);
+                } else if (!dry) e = launch_pass<false, false>(h, cur, oth, direct, which_h);
+            } else if (!dry) {
                 e = launch_pass<true, false>(h, cur, oth, direct, which_v);
             }
-            { float* t = cur; cur = oth; oth = t; }
+            if (swap) { float* t = cur; cur = oth; oth = t; }
             launch++;
             passes++;
         }
         second_done = false;
         if (e != hipSuccess) break;
-        if (h->profiling && launch < 2) hipEventRecord(h->ev_agg[launch], h->heavy); // (only the marks adc_wait reads: start of the first / first regular launch)
+        if (prof && launch < 2) hipEventRecord(h->ev_agg[launch], h->heavy); // (only the marks adc_wait reads: start of the first / first regular launch)
         // second pass of the iteration (dividing): vertical after a horizontal first pass and vice versa
         const int wsec = hf ? which_v : which_h;
         const bool pair = pair_env && marching && k + 1 < iterations &&
                           (wsec == 1 || (wsec == 2 && (pair_full >= 2 || (pair_full == 1 && regring_fits))));
-        if (hf) {
-            if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, direct, wsec);
-            else e = launch_pass<true, true>(h, cur, oth, direct, which_v); // / sup_h
-        } else {
-            if (pair) e = launch_pass<false, true, false, true>(h, cur, oth, direct, wsec);
-            else e = launch_pass<false, true>(h, cur, oth, direct, which_h); // / sup_v
+        if (!dry) {
+            if (hf) {
+                if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, direct, wsec);
+                else e = launch_pass<true, true>(h, cur, oth, direct, which_v); // / sup_h
+            } else {
+                if (pair) e = launch_pass<false, true, false, true>(h, cur, oth, direct, wsec);
+                else e = launch_pass<false, true>(h, cur, oth, direct, which_h); // / sup_v
+            }
         }
         { float* t = cur; cur = oth; oth = t; }
         launch++;
@@ -916,10 +909,79 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
         second_done = pair;
         horizontal_first = !horizontal_first;
     }
-    if (h->profiling) hipEventRecord(h->ev_agg[launch < 8 ? launch : 8], h->heavy);
-    h->agg_launches = launch < 8 ? launch : 8;
-    h->agg_passes = passes;
+    if (prof) hipEventRecord(h->ev_agg[launch < 8 ? launch : 8], h->heavy);
+    if (marks && !dry) {
+        h->agg_first_fused = first_fused ? 1 : 0;
+        h->agg_launches = launch < 8 ? launch : 8;
+        h->agg_passes = passes;
+    }
+    if (out) { out->launches = launch; out->passes = passes; out->result = cur; out->first_fused = first_fused; }
+    return e;
+}
+
+// vol_a -> (H,V | V,H alternating) -> vol_a.  Every iteration is two launches: a -> b -> a.
+hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
+{
+    if ((h->paper & ADC_PAPER_RIGHT_ARMS) && h->arms_r) return adc_paper_aggregate(h, iterations); // opt-in paper mode (k_paper.hip)
+    {   // allow > 64 KiB dynamic LDS for the ring (large cross_L1): a per-DEVICE function attribute -- set once for every
+        // device this process drives (a farm on device 1 after one on device 0), under a lock (handles on several threads)
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {false};
+        std::lock_guard<std::mutex> lk(attr_mu);
+        const int dv = (h->device >= 0 && h->device < 64) ? h->device : 0;
+        if (!attr_set[dv]) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, false, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<true, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_agg_march<false, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set[dv] = true;
+        }
+    }
+    h->agg_first_fused = 0;
+    h->agg_dual_last = 0;
+    hipError_t e = hipSuccess;
+    AggSeq seq;
+    // Two plans (a stream that alternates between short-arm and long-arm images, h->agg_dual > 0; pipeline only: the arm maxima
+    // are not known on the host): plan S = small rings of the depth the last short-arm image needed (+ margin) with pass pairs,
+    // plan F = the full ring; every kernel of S runs iff both directions fit the assumed depths, every kernel of F iff not
+    // (agg_gate_skip).  Needs the fused cost: its first pass has no input volume, so plan F can start by writing vol_a
+    // instead of vol_b when that makes both plans END in the same volume (S: 5 launches, F: 8).
+    const bool dual_env = env_int("ADC_AGG_DUAL", 1) != 0; // (read per call: the tests switch it within one process)
+    const int small_L = adc_agg_small_L(h);
+    const int Lfull = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
+    if (dual_env && h->agg_dual > 0 && h->armmax_valid >= 2 && h->fuse_cost && iterations >= 1 && small_L > 0 && small_L < Lfull) {
+        const int keep_host[2] = {h->armmax_host[0], h->armmax_host[1]}, keep_valid = h->armmax_valid;
+        h->armmax_host[0] = h->armmax_small[0] > 0 ? h->armmax_small[0] : small_L;
+        h->armmax_host[1] = h->armmax_small[1] > 0 ? h->armmax_small[1] : small_L;
+        h->armmax_valid = 2;
+        AggSeq s_dry, f_dry;
+        e = agg_sequence(h, iterations, true, false, false, &s_dry);
+        h->armmax_valid = 3;
+        if (e == hipSuccess) e = agg_sequence(h, iterations, true, false, false, &f_dry);
+        const bool usable = e == hipSuccess && s_dry.first_fused && f_dry.first_fused;
+        if (usable) {
+            h->armmax_valid = 2;
+            h->agg_gate_thr = agg_assumed_depth(h, false) | (agg_assumed_depth(h, true) << 16);
+            h->agg_gate = 3;
+            e = agg_sequence(h, iterations, false, false, true, &seq);
+            h->armmax_valid = 3;
+            h->agg_gate = 4;
+            AggSeq f;
+            if (e == hipSuccess) e = agg_sequence(h, iterations, false, f_dry.result != s_dry.result, false, &f);
+            if (e == hipSuccess && f.result != seq.result) e = hipErrorUnknown; // (cannot happen: the flip above aligns them)
+            h->agg_gate = 0;
+            h->agg_dual_last = 1;
+            h->agg_dual_runs++;
+        }
+        h->armmax_host[0] = keep_host[0]; h->armmax_host[1] = keep_host[1]; h->armmax_valid = keep_valid;
+        if (!usable && e == hipSuccess) e = agg_sequence(h, iterations, false, false, true, &seq);
+    } else {
+        e = agg_sequence(h, iterations, false, false, true, &seq);
+    }
     // the result must be in vol_a (cost_aggr_): swap the two volume pointers if it ended up in the other one
-    if (cur != h->vol_a) { h->vol_b = h->vol_a; h->vol_a = cur; }
+    if (e == hipSuccess && seq.result != h->vol_a) { h->vol_b = h->vol_a; h->vol_a = seq.result; }
     return e;
 }

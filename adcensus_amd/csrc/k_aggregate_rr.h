@@ -277,6 +277,36 @@ RR_FN float rr_divide(float x, float cf, float y)
     return __builtin_fmaf(r, y, q0);
 }
 
+// Which launches of a pass do any work -- the launch gate shared by every marching body (agg_march_body, agg_rr_body,
+// agg_rr2_body).  armmax[0] / [1] = longest horizontal / vertical arm of the image (k_build_arms), written before the
+// aggregation starts and not changed by it.
+//   small_variant < 0   the host launched exactly the variant that applies: run.
+//   0 / 1               debug surface, two launches per pass: the full-ring (0) / small-ring (1) variant runs when the arms
+//                       of THIS direction do not / do fit small_L.
+//   2                   ring depth assumed from the previous Match of the handle: a longer arm skips the pass and raises
+//                       armmax[3]; adc_wait redoes the aggregation and what follows with the full ring.
+//   3 / 4               TWO PLANS enqueued back to back (streams that alternate between short-arm and long-arm images): every
+//                       launch of the assumed-depth plan (3) runs when BOTH directions fit their assumed depths
+//                       (small_L = depth_h | depth_v << 16; 0x7fff = that direction runs the full ring anyway), every launch
+//                       of the full-ring plan (4) when they do not -- exactly one of the two plans does the work, no host
+//                       round trip, no redo.
+RR_FN bool agg_gate_skip(const int* armmax, int small_variant, int small_L, bool vert)
+{
+    if (small_variant < 0) return false;
+    if (small_variant >= 3) {
+        const bool fits = armmax[0] <= (small_L & 0xffff) && armmax[1] <= ((small_L >> 16) & 0xffff);
+        return (small_variant == 3) != fits;
+    }
+    const bool fits_small = armmax[vert ? 1 : 0] <= small_L;
+    if (small_variant == 2) {
+#ifndef RR_EMUL
+        if (!fits_small && RR_BLOCK == 0 && RR_LANE == 0) const_cast<int*>(armmax)[3] = 1;
+#endif
+        return !fits_small;
+    }
+    return (small_variant != 0) != fits_small;
+}
+
 template <bool VERT, bool DIVIDE, bool PAIR>
 RR_FN void agg_rr_body(const float* __restrict__ src, float* __restrict__ dst,
                        const uint2* __restrict__ rec, // {lob | span<<8 | count<<16, RN(1/count)}, line-major
@@ -284,10 +314,7 @@ RR_FN void agg_rr_body(const float* __restrict__ src, float* __restrict__ dst,
                        const int* __restrict__ armmax, int small_variant, int small_L, float* __restrict__ sink)
 {
     static_assert(!PAIR || DIVIDE, "a pair = dividing pass + the following non-dividing pass");
-    if (small_variant >= 0) { // the host does not know the arms (debug path): see agg_march_body
-        const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
-        if ((small_variant != 0) != fits_small) return;
-    }
+    if (agg_gate_skip(armmax, small_variant, small_L, VERT)) return;
     const int R = 2 * L + 1;
     const int lane = RR_LANE;
     const int chunks = Dp / 64;

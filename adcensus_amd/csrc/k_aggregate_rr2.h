@@ -519,10 +519,7 @@ RR_FN void agg_rr2_body(const float* __restrict__ src, float* __restrict__ dst, 
                         const AggCostIn& ci)
 {
     static_assert(!COSTIN || (!VERT && !DIVIDE), "the fused cost is for the first (row, non-dividing) pass");
-    if (small_variant >= 0) { // the host does not know the arms (debug path): see agg_march_body
-        const bool fits_small = armmax[VERT ? 1 : 0] <= small_L;
-        if ((small_variant != 0) != fits_small) return;
-    }
+    if (agg_gate_skip(armmax, small_variant, small_L, VERT)) return;
     const int chunks = Dp / 128;
     const int N = VERT ? H : W;
     const long long total = (long long)(VERT ? W : H) * chunks * N;

@@ -271,11 +271,14 @@ def gather_digests(local, dist=None):
     return out
 
 
-def cross_check(primary, recheck, reference=None):
+def cross_check(primary, recheck, reference=None, selfcheck=None):
     """primary / recheck: lists (one dict per rank) of {pair id: digest}: `primary` = the timed batch (every pair exactly
-    once over all ranks), `recheck` = each rank's untimed recomputation of ANOTHER rank's pairs.  reference: optional
-    {pair id: digest} table of 1-GPU outputs of THIS product committed earlier (tests/golden/farm_digests.json -- a
-    repeatability / cross-box table, not the CPU reference; the reference itself is compared in tests/).  Returns a report dict; report["mismatches"] lists offending pair ids."""
+    once over all ranks), `recheck` = each rank's untimed recomputation of ANOTHER rank's pairs.
+    reference: optional {pair id: digest} table of the REFERENCE CPU program's outputs for these pairs
+    (tests/golden/farm_ref_digests.json, made by tools/make_farm_ref_digests.py from the reference build: the parity claim of the
+    batch).  selfcheck: optional table of 1-GPU outputs of THIS product committed earlier
+    (tests/golden/farm_selfcheck_digests.json: repeatability across boxes and rounds for pair ids the reference table does not
+    cover -- not a parity claim).  Returns a report dict; report["mismatches"] lists offending pair ids."""
     first = {}
     dup = []
     for d in primary:
@@ -290,16 +293,44 @@ def cross_check(primary, recheck, reference=None):
                 checked += 1
                 if first[k] != v:
                     mism.append(k)
-    ref_checked, ref_mism = 0, []
-    if reference:
-        for k, v in first.items():
-            r = reference.get(str(k), reference.get(k))
-            if r is not None:
-                ref_checked += 1
-                if r != v:
-                    ref_mism.append(k)
+
+    def against(table):
+        n, bad = 0, []
+        if table:
+            for k, v in first.items():
+                r = table.get(str(k), table.get(k))
+                if r is not None:
+                    n += 1
+                    if r != v:
+                        bad.append(k)
+        return n, sorted(bad)
+    ref_checked, ref_mism = against(reference)
+    self_checked, self_mism = against(selfcheck)
     return {"pairs": len(first), "duplicates": sorted(dup), "cross_checked": checked, "mismatches": sorted(set(mism)),
-            "committed_1gpu_checked": ref_checked, "committed_1gpu_mismatches": sorted(ref_mism)}
+            "reference_checked": ref_checked, "reference_mismatches": ref_mism,
+            "selfcheck_1gpu_checked": self_checked, "selfcheck_1gpu_mismatches": self_mism}
+
+
+def load_digest_tables(root, workload, size):
+    """(reference table, self-check table) for a workload at `size` = [W, H, D]; None where there is none."""
+    import json
+    import os
+    ref = selfc = None
+    try:
+        with open(os.path.join(root, "tests", "golden", "farm_ref_digests.json")) as f:
+            t = json.load(f)
+        if t.get("size") == list(size):
+            ref = t.get(workload) or None
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(os.path.join(root, "tests", "golden", "farm_selfcheck_digests.json")) as f:
+            t = json.load(f)
+        if t.get("workload") == workload and t.get("size") == list(size):
+            selfc = t["digests"]
+    except (OSError, ValueError):
+        pass
+    return ref, selfc
 
 
 def neighbour_pairs(n_items, world, rank):

@@ -14,7 +14,7 @@ SURVEY.md 8d config 5), pair i = the seeded synthetic pair 12345 + i:
 timings for the roofline), 2 for several.  There is no data-path collective: RCCL carries the barriers, the MAX over ranks
 of the elapsed time, the SUM of the done counter and an all-gather of one SHA-256 per pair.  After the timed region every
 output of the batch is recomputed on another GPU (N = 1: a second time) and the digests compared; they are also compared
-with the committed table of 1-GPU outputs of this product (tests/golden/farm_digests.json) when the size matches.
+with the digests of the REFERENCE CPU program's maps for the same pairs (tests/golden/farm_ref_digests.json) when the size matches.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU).
@@ -90,6 +90,9 @@ def parse():
     ap.add_argument("--no-host-leg", action="store_true", help="N > 1: skip the second timed region fed from host buffers (adc_farm_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the structured / host-inclusive / throughput legs")
+    ap.add_argument("--no-mixed-leg", action="store_true", help="skip the alternating structured / noise stream leg")
+    ap.add_argument("--check-pairs", type=int, default=10,
+                    help="distinct pairs of the second-workload leg, each checked against the reference digest table (structured pairs take seconds to generate)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample strip (0 = the whole frame, ~20 s)")
     ap.add_argument("--cpu-baseline-structured", action="store_true",
                     help="also time the reference on the structured pair (SURVEY 8d S2; ~35 s on one host core) -> structured.cpu_baseline")
@@ -338,11 +341,13 @@ def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair
     if queue_factory is not None:  # the units really processed: this rank's share of the batch, SUMmed over the ranks
         total = farm.done_counter(len(m.mine), dist, tensor_device)
     keep = max(1, (steps + inflight - 1) // inflight)
-    m.fallbacks = {"median_handoff": 0, "voting_continuations": 0, "aggregation_redos": 0, "scanline_seam_redos": 0, "matches": warmup + steps}
+    m.fallbacks = {"median_handoff": 0, "voting_continuations": 0, "aggregation_redos": 0, "scanline_seam_redos": 0,
+                   "median_spec_seam_failures": 0, "aggregation_two_plan_matches": 0, "matches": warmup + steps}
     if host_pairs is None:
         # how often adc_wait had to complete an assumption of the asynchronous pipeline (warm-up + timed region, all pipelines)
         for st in m.handles:
-            for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2), ("scanline_seam_redos", 4)):
+            for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2), ("scanline_seam_redos", 4),
+                               ("median_spec_seam_failures", 7), ("aggregation_two_plan_matches", 10)):
                 m.fallbacks[key] += int(st.debug_counter(which))
             m.fallbacks["scanline_segments_per_row"] = int(m.handles[0].debug_counter(5))
             m.fallbacks["voting_chain_budget"] = int(m.handles[0].debug_counter(3))
@@ -468,19 +473,14 @@ def main():
 
     out = None
     if rank == 0:
-        ref_table = None
-        ref_path = os.path.join(ROOT, "tests", "golden", "farm_digests.json")
-        if os.path.exists(ref_path):
-            with open(ref_path) as f:
-                t = json.load(f)
-            if t.get("workload") == a.workload and t.get("size") == [W, H, D]:
-                ref_table = t["digests"]
-        check = farm.cross_check(all_primary, all_recheck, ref_table)
+        ref_table, self_table = farm.load_digest_tables(ROOT, a.workload, [W, H, D])
+        check = farm.cross_check(all_primary, all_recheck, ref_table, self_table)
+        check["reference"] = "tests/golden/farm_ref_digests.json: SHA-256 of the reference CPU program's maps (oracle/_ref, tools/make_farm_ref_digests.py)"
         check["done_counter"] = done
         check["retired_ranks"] = retired
         check["pairs_per_rank"] = [len(d) for d in all_primary]
         check["ok"] = (done == batch and check["pairs"] == batch and not check["duplicates"] and not check["mismatches"]
-                       and not check["committed_1gpu_mismatches"])
+                       and not check["reference_mismatches"] and not check["selfcheck_1gpu_mismatches"])
         if a.write_digests and world == 1:
             with open(a.write_digests, "w") as f:
                 json.dump({"workload": a.workload, "size": [W, H, D], "generator": "python bench.py --steps %d --write-digests ... (1 GPU)" % a.steps,
@@ -546,12 +546,24 @@ def main():
         other = "structured" if a.workload == "noise" else "noise"
         # ---- second workload (one pair: generating structured pairs costs seconds each), one pipeline
         n2 = max(5, min(10, a.steps))
-        m2, e2, t2, st2, pf2 = measure_workload(A, local_rank, W, H, D, other, n2, 2, 1, [0])
+        ref2, _ = farm.load_digest_tables(ROOT, other, [W, H, D])
+        ids2 = list(range(min(n2, len(ref2)))) if (ref2 and a.check_pairs > 0) else [0]
+        ids2 = ids2[:max(1, a.check_pairs)]
+        m2, e2, t2, st2, pf2 = measure_workload(A, local_rank, W, H, D, other, n2, 2, 1, ids2)
         s2 = mean_stages(st2)
         out[other] = {"value": round(t2 / e2, 4), "unit": "pairs/s", "ms_per_step": round(1000.0 * e2 / n2, 4), "steps": n2,
-                      "workload": "%s %dx%d D=%d (one pair repeated)" % (other, W, H, D), "stage_ms": s2,
+                      "workload": "%s %dx%d D=%d (%d distinct pairs, seeds %d+i)" % (other, W, H, D, len(ids2), 777 if other == "structured" else 12345),
+                      "stage_ms": s2,
                       "roofline": k4_roofline(pf2, W, H, D, lib, other, m2.handles[0].aggregate_kernel(), 1),
                       "stage_roofline": stage_roofline(s2, 1000.0 * e2 / n2, W, H, D), "async_fallbacks": m2.fallbacks}
+        if ref2:  # every output of the leg against the reference CPU program's map of the same pair
+            got2 = {pid: farm.digest(m2.output(pid).tobytes()) for pid in ids2}
+            out[other]["reference_check"] = {"pairs": len(got2), "reference_checked": sum(1 for k in got2 if str(k) in ref2),
+                                             "reference_mismatches": sorted(k for k, v in got2.items() if str(k) in ref2 and ref2[str(k)] != v)}
+        # ---- mixed stream: the two workloads alternating through 3 pipelines (what a real image stream looks like to the
+        #      history-dependent parts of the pipeline: assumed ring depth, voting launch budget); device-resident
+        if not a.no_mixed_leg:
+            out["mixed_stream"] = mixed_stream_leg(A, local_rank, W, H, D, m2, other, ids2[:6], a.workload, max(12, min(36, 2 * a.steps)))
         m2.release()
         # ---- the drop-in entry point with pageable host buffers
         out["host_inclusive"] = host_inclusive_leg(A, local_rank, W, H, D, a.workload, max(5, min(10, a.steps)))
@@ -582,6 +594,56 @@ def main():
         os.dup2(2, 1)  # (anything printed during teardown must not follow the JSON line)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def mixed_stream_leg(A, device, W, H, D, m_other, other, other_ids, workload, n):
+    """`n` Matches alternating between the two workloads (pairs of `other` already resident in m_other's buffers, pairs 0..5 of
+    `workload` uploaded here) through THREE pipelines in flight; every output compared with the reference table."""
+    from adcensus_amd import farm
+    ref = {w: farm.load_digest_tables(ROOT, w, [W, H, D])[0] or {} for w in (workload, other)}
+    m = Matcher(A, device, W, H, D, 3)
+    own_ids = list(range(min(6, max(1, len(other_ids)))))
+    for pid in own_ids:
+        l, r = make_pair(workload, W, H, D, pid)
+        m.upload(("w", pid), l, r)
+    for pid in other_ids:
+        m.buf[("o", pid)] = m_other.buf[pid]  # (borrowed: freed by m_other)
+    seq = []
+    for k in range(n):
+        seq.append(("o", other_ids[(k // 2) % len(other_ids)]) if k % 2 == 0 else ("w", own_ids[(k // 2) % len(own_ids)]))
+    bad, checked = [], [0]
+
+    def wait(slot):
+        m.wait(slot)
+        key = wait.pending.pop(slot)
+        table = ref[other if key[0] == "o" else workload]
+        if str(key[1]) in table:
+            checked[0] += 1
+            if farm.digest(m.output(key).tobytes()) != table[str(key[1])]:
+                bad.append("%s %d" % (other if key[0] == "o" else workload, key[1]))
+    wait.pending = {}
+
+    def submit(slot, key):
+        m.submit(slot, key)
+        wait.pending[slot] = key
+    farm.run_pairs(seq[:6], submit, wait, 3)  # warm-up: every pipeline has seen both kinds
+    A.lib().adc_device_synchronize()
+    t0 = time.perf_counter()
+    farm.run_pairs(seq, m.submit, m.wait, 3)
+    A.lib().adc_device_synchronize()
+    dt = time.perf_counter() - t0
+    farm.run_pairs(seq[:12], submit, wait, 3)  # untimed: outputs against the reference digests (the read-back costs 8 MB per pair)
+    counters = {name: [int(st.debug_counter(c)) for st in m.handles] for name, c in
+                (("aggregation_redos", 2), ("scanline_seam_redos", 4), ("voting_continuations", 1), ("median_handoff", 0),
+                 ("plan_switches", 9), ("two_plan_matches", 10))}
+    for key in list(m.buf):
+        if key[0] == "o":
+            m.buf.pop(key)
+    m.release()
+    return {"value": round(n / dt, 4), "unit": "pairs/s", "steps": n, "in_flight_per_gpu": 3,
+            "workload": "alternating %s / %s pairs, %dx%d D=%d, device-resident" % (other, workload, W, H, D),
+            "per_pipeline": counters, "reference_checked": checked[0], "reference_mismatches": bad,
+            "note": "aggregation of a mixed stream: both ring plans are enqueued and the kernels choose on the device (no redo)"}
 
 
 def host_inclusive_leg(A, device, W, H, D, workload, n, registered=False):

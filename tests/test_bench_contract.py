@@ -51,7 +51,7 @@ def test_committed_bench_lines_follow_the_contract(name):
         assert r["frac"] <= 1.0 and r["algorithmic_frac"] >= r["frac"] - 1e-9 and r["passes_per_launch"] >= 1.0
         assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
         assert o["farm_check"]["ok"] is True and o["farm_check"]["done_counter"] == (o["steps"] if o["scaling"] == "strong" else o["steps"] * o["n_gpus"])
-        assert "committed_1gpu_checked" in o["farm_check"] and "reference_checked" not in o["farm_check"]
+        assert "committed_1gpu_checked" in o["farm_check"] and "reference_checked" not in o["farm_check"]  # (rounds 3 / 4: the product's own table)
         for k, v in o["stage_roofline"].items():
             if isinstance(v, dict) and k != "aggregate_K4_stage_algorithmic":
                 assert v["frac"] <= 1.0, (k, v)
@@ -71,6 +71,27 @@ def test_committed_bench_lines_follow_the_contract(name):
         if o["n_gpus"] == 1 and "host_inclusive" in o:
             assert o["host_inclusive"]["value"] < o["value"] * 1.05  # the host path cannot beat the resident one
             assert set(("cpu_model", "build", "host_cores")) <= set(o["cpu_baseline"])
+
+
+def test_reference_digest_table_of_the_bench_batches():
+    """tests/golden/farm_ref_digests.json (reference CPU program, tools/make_farm_ref_digests.py) covers the 20 noise pairs of the
+    headline batch and 10 structured pairs; where it overlaps with the older table of the product's own 1-GPU outputs
+    (farm_selfcheck_digests.json, noise pairs 0..159) the two agree -- the product's outputs ARE the reference's."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gold, "farm_ref_digests.json")) as f:
+        ref = json.load(f)
+    assert ref["size"] == [1920, 1080, 128] and "oracle/_ref" in ref["_oracle"]
+    assert sorted(int(k) for k in ref["noise"]) == list(range(20)) and sorted(int(k) for k in ref["structured"]) == list(range(10))
+    assert all(len(v) == 64 and int(v, 16) >= 0 for w in ("noise", "structured") for v in ref[w].values())
+    with open(os.path.join(gold, "farm_selfcheck_digests.json")) as f:
+        own = json.load(f)
+    assert own["workload"] == "noise" and own["size"] == ref["size"]
+    assert all(own["digests"][k] == v for k, v in ref["noise"].items())
+    from adcensus_amd import farm
+    r, s_ = farm.load_digest_tables(ROOT, "noise", [1920, 1080, 128])
+    assert r == ref["noise"] and s_ == own["digests"]
+    assert farm.load_digest_tables(ROOT, "structured", [1920, 1080, 128]) == (ref["structured"], None)
+    assert farm.load_digest_tables(ROOT, "noise", [640, 480, 64]) == (None, None)
 
 
 def test_round2_sample_is_committed():

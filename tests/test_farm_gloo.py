@@ -85,15 +85,15 @@ def test_farm_two_ranks_gloo():
     assert f0 == f1 == 2                  # two pipelines in flight
     assert d0 == d1 == 10                 # completion counter == batch
     for rep in (rep0, rep1):
-        assert rep["pairs"] == 10 and rep["cross_checked"] == 10 and rep["committed_1gpu_checked"] == 10
-        assert not rep["duplicates"] and not rep["mismatches"] and not rep["committed_1gpu_mismatches"]
+        assert rep["pairs"] == 10 and rep["cross_checked"] == 10 and rep["reference_checked"] == 10
+        assert not rep["duplicates"] and not rep["mismatches"] and not rep["reference_mismatches"]
 
 
 def test_farm_cross_check_catches_a_wrong_output():
     res = _run(corrupt=(1, 3))  # rank 1 delivers a corrupted map for pair 3 (its own pair: 3 % 2 == 1)
     for r in res:
         rep = r[6]
-        assert rep["mismatches"] == [3] and rep["committed_1gpu_mismatches"] == [3]
+        assert rep["mismatches"] == [3] and rep["reference_mismatches"] == [3]
 
 
 def test_partition_properties():

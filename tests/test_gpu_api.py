@@ -166,7 +166,7 @@ def test_median_band_variants(hip, env):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_async_pipeline_assumptions_and_budgets(hip, oracle):
+def test_async_pipeline_assumptions_and_budgets(hip, oracle, monkeypatch):
     """Match never waits for the device in mid-pipeline: the aggregation ASSUMES the arm maxima of the previous Match of the
     handle and the voting chain has a launch BUDGET adapted from the previous Match.  Both are verified / completed by
     adc_wait -- wrong assumptions cost time, never correctness.  Sequence on ONE handle: structured pair (long arms, many
@@ -186,6 +186,7 @@ def test_async_pipeline_assumptions_and_budgets(hip, oracle):
 
     def same(a, b):
         return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    monkeypatch.setenv("ADC_AGG_DUAL", "0")          # (the one-plan form first: assume, verify on the device, redo)
     assert same(st.match(*s_pair), want_s)           # first Match: full ring, default budget
     redo0, over0 = st.debug_counter(2), st.debug_counter(1)
     assert same(st.match(*s_pair), want_s)           # same image again: assumptions hold
@@ -195,8 +196,10 @@ def test_async_pipeline_assumptions_and_budgets(hip, oracle):
     kept_budget = st.debug_counter(3)
     assert same(st.match(*n_pair), want_n)           # now the small ring is assumed (and right)
     assert st.debug_counter(2) == redo0
+    part0 = st.debug_counter(11)
     assert same(st.match(*s_pair), want_s)           # long arms while the small ring is assumed: detected on the device, redone
     assert st.debug_counter(2) == redo0 + 1
+    assert st.debug_counter(11) == part0 + 1         # ... from the aggregation on (cost records / arms of the pair were kept)
     # the voting budget remembers the longest chain of the last 8 Matches: the structured pair after two noise pairs does NOT
     # overrun it (it did while the budget followed the previous Match alone)
     assert st.debug_counter(1) == over0 and st.debug_counter(3) == kept_budget
@@ -207,6 +210,34 @@ def test_async_pipeline_assumptions_and_budgets(hip, oracle):
     assert st.debug_counter(1) >= over0 + 1 and st.debug_counter(3) >= kept_budget
     assert same(st.match(*s_pair), want_s)
     st.Release()
+
+
+def test_mixed_stream_two_aggregation_plans(hip, oracle, monkeypatch):
+    """A stream that alternates between long-arm and short-arm images on ONE handle: after the first change of the plan an
+    image needs, the aggregation is enqueued as two plans (small rings + pass pairs | full ring) and the kernels choose on the
+    device (agg_gate_skip) -- no redo, every result bit-exact, also with three different short-arm depths and with the
+    margin of the assumed depth switched off (an image whose arms exceed the assumed depth by one then takes the full-ring plan)."""
+    A = hip
+    from oracle import pyoracle
+    from adcensus_amd import workloads
+    w, h = 256, 160
+
+    def same(a, b):
+        return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for d, margin in ((64, "1"), (128, "0")):  # (one / two disparities per lane: the two kernel families of both plans)
+        opt = pyoracle.Option(max_disparity=d)
+        pairs = {"s": workloads.structured_pair(w, h, d, seed=51), "n": workloads.noise_pair(w, h, seed=52),
+                 "q": workloads.quantized_noise_pair(w, h, d, seed=53, levels=32), "s2": workloads.structured_pair(w, h, d, seed=54)}
+        want = {k: oracle.run(v[0], v[1], opt, stages=["disp_final"])["disp_final"] for k, v in pairs.items()}
+        monkeypatch.setenv("ADC_AGG_ASSUME_MARGIN", margin)
+        st = A.ADCensusStereo(device=0)
+        assert st.Initialize(w, h, cases.to_product_option(opt))
+        seq = ["s", "n", "s", "n", "q", "s2", "n", "n", "q", "s", "s", "q", "n", "s2"]
+        for i, k in enumerate(seq):
+            assert same(st.match(*pairs[k]), want[k]), "pair %d (%s) of the mixed stream, D = %d, margin %s" % (i, k, d, margin)
+        assert st.debug_counter(2) == 0, "no redo: the first change of plan (long -> short arms) runs on the always-valid full ring"
+        assert st.debug_counter(9) >= 6 and st.debug_counter(10) == len(seq) - 2 and st.debug_counter(12) > 0
+        st.Release()
 
 
 def test_pair_farm_host_buffers(hip, oracle):

@@ -37,6 +37,39 @@ def test_full_size_match_equals_reference(hip, oracle, workload, seed):
     st.Release()
 
 
+def _ref_table():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "farm_ref_digests.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("workload", ["noise", "structured"])
+def test_bench_batches_equal_reference_digests(hip, workload):
+    """EVERY pair of the two batches bench.py measures on (noise seeds 12345 + i, i < 20 = the headline batch; structured
+    seeds 777 + i, i < 10) against the SHA-256 of the reference CPU program's map for that pair
+    (tests/golden/farm_ref_digests.json, made by tools/make_farm_ref_digests.py from oracle/_ref: ~55 s of one core per pair,
+    so the table is committed instead of recomputed here).  One handle takes the whole batch in order, like the farm does: the
+    speculative forms (scanline row segments, median bands, assumed ring depth / voting budget) see 20 different images."""
+    import hashlib
+    A = hip
+    t = _ref_table()
+    assert t["size"] == [W, H, D] and len(t["noise"]) >= 20 and len(t["structured"]) >= 10
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(W, H, A.ADCensusOption(max_disparity=D))
+    got = np.zeros((H, W), np.float32)
+    bad = []
+    for pid in sorted(int(k) for k in t[workload]):
+        left, right = (workloads.noise_pair(W, H, 12345 + pid) if workload == "noise"
+                       else workloads.structured_pair(W, H, D, seed=777 + pid))
+        got[:] = -1.0
+        assert st.Match(left, right, got)
+        if hashlib.sha256(got.tobytes()).hexdigest() != t[workload][str(pid)]:
+            bad.append(pid)
+    st.Release()
+    assert not bad, "%s pairs %s differ from the reference CPU program's maps" % (workload, bad)
+
+
 @pytest.mark.parametrize("workload", ["noise", "structured"])
 def test_kitti_size_match_equals_reference(hip, oracle, workload):
     """BASELINE.json configs[2]: KITTI-size 1242x375, D=128 (odd width, 375 rows = 5.9 median bands, 375 scanline rows)."""

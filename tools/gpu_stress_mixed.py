@@ -53,8 +53,9 @@ for s0, n0 in inflight:
         bad += 1; print("MISMATCH", n0, flush=True)
 dt = time.perf_counter() - t0
 print("pairs %d in %.2f s (%.1f pairs/s, host buffers, 3 in flight, alternating structured / noise), mismatches %d" % (len(seq), dt, len(seq) / dt, bad))
-print("per pipeline [median fallbacks, voting continuations, aggregation redos, next voting budget, scanline seam redos, median seam failures]:",
-      [[int(st.debug_counter(c)) for c in (0, 1, 2, 3, 4, 7)] for st in hs])
+print("per pipeline [median fallbacks, voting continuations, aggregation redos, next voting budget, scanline seam redos, median seam failures, "
+      "plan switches, two-plan Matches, partial redos]:",
+      [[int(st.debug_counter(c)) for c in (0, 1, 2, 3, 4, 7, 9, 10, 11)] for st in hs])
 for st in hs:
     st.Release()
 sys.exit(1 if bad else 0)
