@@ -67,7 +67,7 @@ struct adc_handle {
     // disparity maps and refinement state
     float *disp_l, *disp_r, *disp_tmp;
     uint8_t* label;
-    uint8_t* elig;       // region voting: eligible mask of the current pass
+    uint8_t* elig;       // scratch: invalid mask of the LR check (byte per pixel), then the voting chain's bitmap of the pixels on its work list
     uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
     int32_t* vote_list;  // work list of the voting pass: int4 entries (k_voting.hip)
     int32_t* vote_evals_arr; // evaluation counter per wave of the chain's grid (statistics)
@@ -176,8 +176,8 @@ hipError_t adc_paper_accumulate(adc_handle* h, float* acc, const float* src, int
 hipError_t adc_launch_lrcheck(adc_handle* h);
 size_t adc_itp_cell_bytes(int W, int H);       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
 int adc_irv_grid(size_t pixels);                // workgroups of the voting chain for an image of this size
-size_t adc_irv_waves(int grid);                // waves of the voting chain's grid (upper bound)
-size_t adc_irv_list_entries(size_t pixels, int D, int grid);    // capacity of the voting work list (whole batches)
+size_t adc_irv_waves(int grid);                // ints of the chain's statistics block (per-wave counters + per-workgroup segment lengths)
+size_t adc_irv_list_entries(int W, int H, int D, int grid);     // capacity of the voting work list (one segment per workgroup)
 hipError_t adc_run_region_voting(adc_handle* h); // enqueue only (device-driven chain with a launch budget)
 hipError_t adc_voting_finish(adc_handle* h, int* continued); // after a sync: continue the chain if the budget was too small
 hipError_t adc_launch_interpolation(adc_handle* h);

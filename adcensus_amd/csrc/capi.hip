@@ -141,23 +141,25 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMemset(h->disp_l + P, 0, 1024));
     HIP_OK(hipMemset(h->disp_tmp + P, 0, 1024));
     HIP_OK(hipMalloc(&h->label, P));
-    HIP_OK(hipMalloc(&h->elig, P));
+    HIP_OK(hipMalloc(&h->elig, P + 64)); // (LR check: invalid mask, 1 byte per pixel; then the voting chain's bitmap of listed pixels, whole 64-bit words)
     HIP_OK(hipMalloc(&h->irv_bbox, P * 4));
     h->irv_grid = adc_irv_grid(P);
-    HIP_OK(hipMalloc(&h->vote_list, adc_irv_list_entries(P, p.D, h->irv_grid) * 16)); // int4 per entry, whole batches (irv_plan.h: irv_list_slot)
-    HIP_OK(hipMemset(h->vote_list, 0xFF, adc_irv_list_entries(P, p.D, h->irv_grid) * 16)); // every slot = IRV_LIST_END
+    HIP_OK(hipMalloc(&h->vote_list, adc_irv_list_entries(p.W, p.H, p.D, h->irv_grid) * 16)); // int4 per entry, one segment per workgroup (irv_plan.h)
+    HIP_OK(hipMemset(h->vote_list, 0xFF, adc_irv_list_entries(p.W, p.H, p.D, h->irv_grid) * 16)); // every slot = IRV_LIST_END
     HIP_OK(hipMalloc(&h->vote_evals_arr, adc_irv_waves(h->irv_grid) * sizeof(int32_t)));
+    HIP_OK(hipMemset(h->vote_evals_arr, 0, adc_irv_waves(h->irv_grid) * sizeof(int32_t)));
     HIP_OK(hipMalloc(&h->interp_list, P * 4));
     HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));
     HIP_OK(hipMalloc(&h->itp_cells, adc_itp_cell_bytes(p.W, p.H)));
     h->st16_pitch = (p.W + 7) & ~7;
-    HIP_OK(hipMalloc(&h->st16, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t)));
+    HIP_OK(hipMalloc(&h->st16, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // (an uncached allocation -- visible across XCDs inside a kernel -- measured equal)
     HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin
     HIP_OK(hipMalloc(&h->disp_vote, P * 4));
     HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
-    // voting chain budget of the FIRST Match of a handle (later ones adapt: kernels used + 12 % + 4): a natural 1080p image needs
-    // ~350 kernels; kernels past the end of the chain are no-ops of ~2.5 us, an exhausted budget costs a synchronous continuation
-    h->irv_budget = 384;
+    // voting chain budget of the FIRST Match of a handle (later ones adapt: kernels used + 25 % + 8): a natural 1080p image needs
+    // ~50-75 kernels (round 5: all passes iterate at once; ~350 before); kernels past the end of the chain are no-ops of ~4 us, an
+    // exhausted budget costs a synchronous continuation
+    h->irv_budget = 256;
     // change-tile map of the voting rounds: one BYTE per 8x8 tile, rows padded to a multiple of 4 (+16: a 16-byte load
     // may start at the last dword of a row)
     h->chg_pitch = (((p.W + 7) / 8 + 3) & ~3) + 16;

@@ -6,25 +6,45 @@
 #include "adc_device_fn.h"
 
 #define IRV_TILE 8
+// 16-bit state of a pixel: bin (11 bits; 0x7FF = invalid, never counted) | fill iteration f (3 bits) | list (2 bits: 0 = not on a
+// list, 1 = mismatch, 2 = occlusion == the outlier label).  bits 0..13 = the KEY f << 11 | bin.
 #define IRV_BIN_MASK 0x7FFu
-#define IRV_FINAL 0x4000u
-#define IRV_ELIG 0x8000u
+#define IRV_F_SHIFT 11
+#define IRV_KEY_MASK 0x3FFFu
+#define IRV_LIST_SHIFT 14
+#define IRV_LEVELS 5 // iterations of the reference (multistep_refiner.cpp:166)
 #define IRV_PPT 4 // pixels per thread and block iteration of the BEGIN phase (one list-length atomic per 4 x blockDim pixels)
 
-enum { IRV_NONE = 0, IRV_BEGIN, IRV_ROUND, IRV_FINAL_WB, IRV_DONE };
-// ctrl layout (int32): state slot s at ctrl[16*s ..]: {did, pass, round, filled_any, n, rounds_total, evals, kdone};
-// accumulator ring at ctrl[IRV_ACC + (k & 63)] (BEGIN: list length; ROUND: "a value changed")
+// THE FORMULATION (round 5).  The reference runs 5 iterations x {mismatches, occlusions}, every pass in place in raster order
+// (multistep_refiner.cpp:153-227).  A filled pixel stays filled, so the value of a listed pixel over the five iterations is
+// INVALID, .., INVALID, b, .., b: ONE state (f, b) = (iteration of the fill, bin) per pixel.  Region pixel q counts in the vote of p
+// at iteration `it` iff it >= t(q):
+//     q not on a list           t = 0                (its LR-checked value)
+//     same list, before p       t = f_q              (the in-place scan has already passed q in this iteration)
+//     same list, behind p       t = f_q + 1          (... passes it later: p sees the previous iteration's value)
+//     other list                t = f_q + 1 for a mismatch p (the mismatch pass of an iteration runs first), f_q for an occlusion p
+// and the state of p is (first iteration whose vote passes, its bin) -- the five votes of a pixel are the five CUMULATIVE
+// histograms of one gather of its region.  This is a system of equations that is triangular in the order (iteration, list,
+// raster position): any chaotic in-place iteration converges to its unique solution = the sequential result, and a whole
+// round without a change proves the fixed point.  Rounds 1-4 iterated the ten passes one after the other (~255 rounds at 1080p:
+// every pass has a long tail of rounds that are latency chains); iterating all of them at once lets the tails overlap:
+// tools/irv_joint_rounds.py, 960x540 structured pair: 58 rounds instead of 195, 1.2x the evaluations.
+enum { IRV_NONE = 0, IRV_BEGIN, IRV_ROUND, IRV_FINAL_WB, IRV_DONE, IRV_BEGIN2 };
+// ctrl layout (int32): state slot s at ctrl[16*s ..]: {did, -, round, -, n, rounds_total, evals, kdone};
+// accumulator ring at ctrl[IRV_ACC + (k & 63)] (BEGIN2: list length; ROUND: "a state changed")
 #define IRV_ACC 64
 #define IRV_CTRL_INTS 160
-struct IrvState { int did, pass, round, filled_any, n, rounds, evals, kdone; }; // kdone: index of the kernel that found the chain finished
+struct IrvState { int did, pass, round, filled_any, n, rounds, evals, kdone; }; // kdone: index of the kernel that found the chain finished (pass / filled_any: unused since round 5)
 struct IrvPlan { int act; IrvState s; };
 
 // One kernel type: kernel k reads the state its predecessor published (slot k & 1) and the predecessor's accumulator.
-//   BEGIN    write the previous pass's fills back, mark the eligible pixels of the next list, build the work list
-//   ROUND    round r of the pass: every open entry whose dependency box changed in round r-1 (round 0: every entry) votes.
+//   BEGIN    seed the working copy of the map, build the state map and the bitmap of the pixels that go on the work list (every
+//            listed pixel whose region is large enough to ever pass a vote): one coalesced pass over the image
+//   BEGIN2   every workgroup compacts the listed pixels of ITS tiles into its segment of the work list, in evaluation order
+//   ROUND    every entry whose region saw a change in round r-1 (round 0: every entry) is evaluated.
 //            Change tiles: kernel k stamps (k % 255) + 1 into plane k & 1 and reads the stamps of kernel k-1 in the other
 //            plane -- both known at launch time, so the check can run before the state has arrived.
-//   FINAL_WB write the last pass's fills back (and sum the per-wave evaluation counters into the state's evals)
+//   FINAL_WB write the fills back (and sum the per-wave evaluation counters into the state's evals)
 ADC_HD IrvPlan irv_plan_from(IrvState s, int prev, int k) // s: the published state, prev: the predecessor's accumulator
 {
     IrvPlan p;
@@ -32,25 +52,17 @@ ADC_HD IrvPlan irv_plan_from(IrvState s, int prev, int k) // s: the published st
         p.act = IRV_BEGIN;
         s.pass = 0; s.round = 0; s.filled_any = 0; s.n = 0;
     } else if (s.did == IRV_BEGIN) {
+        p.act = IRV_BEGIN2;
+    } else if (s.did == IRV_BEGIN2) {
         p.act = IRV_ROUND;
         s.n = prev; // list length
         s.round = 0;
     } else if (s.did == IRV_ROUND) {
-        int fa = s.filled_any | ((s.round == 0 && prev != 0) ? 1 : 0); // a pass that fills anything does so in round 0
         if (prev != 0) { // the round changed something: next round
             p.act = IRV_ROUND;
             s.round++;
-            s.filled_any = fa;
-        } else { // a whole round without a change: the pass has converged
-            bool fin = false;
-            if (s.pass & 1) { // end of an iteration (multistep_refiner.cpp:167-171): nothing filled -> the rest are no-ops
-                if (!fa) fin = true;
-                fa = 0;
-            }
-            s.pass++;
-            if (s.pass >= 10) fin = true;
-            p.act = fin ? IRV_FINAL_WB : IRV_BEGIN;
-            s.round = 0; s.filled_any = fa; s.n = 0;
+        } else { // a whole round without a change: the fixed point
+            p.act = IRV_FINAL_WB;
         }
     } else {
         p.act = IRV_DONE;
@@ -74,28 +86,62 @@ ADC_HD void irv_publish(int32_t* ctrl, int k, const IrvState& s)
     ctrl[IRV_ACC + ((k + 2) & 63)] = 0;
 }
 
-// Work-list layout.  The chain's grid has G workgroups of WPB waves; a batch is B = 64 * WPB * G entries.  Entry i (in the
-// order the BEGIN phase compacts them: raster order inside chunks of pixels) belongs to WORKGROUP (i % B) % G: consecutive
-// entries -- which tend to be dirty in the same rounds (a fill front is a few hundred adjacent pixels) -- land in different
-// workgroups, so every workgroup's pool of dirty entries holds about dirty / G of them.  INSIDE the workgroup the entries
-// are packed densely: t = (i % B) / G sits in wave t / 64, lane t % 64 (round 4; before: wave t % WPB, lane t / WPB).  A
-// list of n entries then occupies the first ceil(n / G / 64) waves of every workgroup with all 64 lanes, and the other waves
-// find nothing but end markers (IRV_LIST_END, written over the unused slots by the first round of a pass and by the FINAL
-// kernel) and skip the state / change-tile phase altogether: in the long tail of a pass, where a round is a chain of memory
-// round trips plus the instruction issue of 8192 waves each checking a handful of lanes, a quarter (pass 0) to a tenth
-// (later passes) of the waves do the checking.  The votes are dealt out over ALL waves of the workgroup from the LDS pool.
+// Work-list layout and evaluation ORDER (round 5).  A fill front moves down the image: most inputs of a vote lie in the rows
+// above the pixel (and the votes of later iterations need the earlier iterations' values of the pixels below).  Evaluated all at
+// once (one Jacobi round per kernel) a front advances one row per kernel and every entry near it is evaluated again and again
+// (measured: 12 evaluations per entry); evaluated top-down IN PLACE it runs through in a few sweeps.  So the image is cut into
+// BANDS of IRV_BAND rows and tiles of IRV_BAND x IRV_TCOLS pixels; the tiles of a band are dealt out over the workgroups of ONE
+// XCD (irv_wg_tile below; neighbouring tiles -- which tend to be busy in the same rounds -- land in different workgroups: with
+// tiles 32 columns wide the busiest workgroup of a round held 3x the average and set the round's time, measured), and a
+// workgroup's segment of the list holds the entries of ITS tiles sorted by (row inside the band, tile, column).  The workgroup works through its segment in that order (its waves
+// take consecutive dirty entries), all workgroups side by side: at any time the chip evaluates about the same row of every band,
+// with the rows above it already settled in this very kernel (as far as they belong to the same band).  Nothing depends on that pace -- the iteration converges to the same
+// fixed point under any schedule (irv_plan.h, top) -- only the number of rounds does (tools/irv_joint_rounds.py, 960x540: 19
+// rounds and 0.38 M evaluations with bands of 16 rows against 58 rounds / 0.84 M all at once, 195 / 0.61 M pass after pass).
+// Segment of workgroup g: list[g * cap ..], cap = irv_seg_cap (whole batches of 64 * WPB entries); n_g entries, then
+// IRV_LIST_END up to the end of the batch.
 #define IRV_LIST_END (-1)
-ADC_HD long irv_list_slot(long i, int G, int WPB)
+#ifndef IRV_BAND
+#define IRV_BAND 8 // (measured at 1080p, refine stage of two structured pairs: 4 rows 3.61 / 4.10 ms, 8: 3.43 / 3.76, 16: 3.76 / 4.25, 32: 4.34 / 5.16)
+#endif
+#ifndef IRV_TCOLS
+#define IRV_TCOLS 1
+#endif
+ADC_HD int irv_tiles_x(int W) { return (W + IRV_TCOLS - 1) / IRV_TCOLS; }
+ADC_HD int irv_bands(int H) { return (H + IRV_BAND - 1) / IRV_BAND; }
+// Which workgroup owns which tiles.  A vote sees what other workgroups have written IN THE SAME KERNEL only through the L2 of its
+// own XCD (the L2s of different XCDs are not coherent inside a kernel), and workgroup g runs on XCD g % 8: so a whole BAND belongs
+// to one XCD -- band b to XCD b % 8 -- and its tiles are dealt out over the G / 8 workgroups of that XCD.  (G % 8 != 0: plain
+// round-robin; still exact, the sweep just sees less of itself.)
+//   tile index inside the XCD:  u = (b / 8) * tiles_x + tx;   workgroup = (b % 8) + 8 * (u % (G / 8))
+ADC_HD int irv_xcd_units(int W, int H, int xcd) { return ((irv_bands(H) - xcd + 7) / 8) * irv_tiles_x(W); } // tiles of the bands b % 8 == xcd
+ADC_HD int irv_wg_tiles(int W, int H, int G, int g, int xcd)
 {
-    const long B = 64L * WPB * G, r = i % B;
-    const long blk = r % G, t = r / G;
-    return (i / B) * B + blk * (64L * WPB) + t;
+    if (!xcd || G % 8 != 0) { const int n = irv_tiles_x(W) * irv_bands(H); return g < n ? (n - g + G - 1) / G : 0; }
+    const int per = G / 8, m = g / 8, n = irv_xcd_units(W, H, g % 8);
+    return m < n ? (n - m + per - 1) / per : 0;
 }
-// the list index held by lane `lane` of wave `wave` of workgroup `blk` in the batch that starts at b0 (inverse of irv_list_slot)
-ADC_HD long irv_list_index(long b0, int blk, int wave, int lane, int G) { return b0 + (long)(wave * 64 + lane) * G + blk; }
-// Entry = {pixel, arms of the pixel (left | right << 8 | top << 16 | bottom << 24), boxes, row}; boxes = max left | max right << 8
-// over the rows y - top .. y (the dependency box: only pixels that precede p can influence its vote) | max left << 16 |
-// max right << 24 over ALL region rows (the rectangle a vote starts to read before the row arms have arrived).
+// the k-th tile of workgroup g: *band, *tx
+ADC_HD void irv_wg_tile(int W, int H, int G, int g, int k, int xcd, int* band, int* tx)
+{
+    const int tiles_x = irv_tiles_x(W);
+    if (!xcd || G % 8 != 0) { const int t = g + k * G; *band = t / tiles_x; *tx = t % tiles_x; return; }
+    const int u = g / 8 + k * (G / 8);
+    *band = (u / tiles_x) * 8 + g % 8;
+    *tx = u % tiles_x;
+    (void)H;
+}
+ADC_HD long irv_seg_cap(int W, int H, int G, int WPB, int xcd)
+{
+    const long most = (!xcd || G % 8 != 0) ? ((long)irv_tiles_x(W) * irv_bands(H) + G - 1) / G
+                                 : ((long)((irv_bands(H) + 7) / 8) * irv_tiles_x(W) + G / 8 - 1) / (G / 8); // tiles of the busiest workgroup
+    const long per = most * IRV_BAND * IRV_TCOLS, batch = 64L * WPB;
+    return ((per + batch - 1) / batch) * batch;
+}
+// Entry = {pixel, arms of the pixel (left | right << 8 | top << 16 | bottom << 24), boxes, row}; boxes = max left << 16 |
+// max right << 24 over ALL region rows: the rectangle a vote starts to read before the row arms have arrived, and -- every
+// region pixel being an input of some iteration's vote -- the box whose change tiles decide whether the entry is evaluated again
+// (bits 0..15: the same maxima over the rows y - top .. y only, unused since round 5).
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Packed-halfword decode of a region row block (8 pixels of the 16-bit state map in four dwords) and of a change-tile row,
@@ -126,53 +172,50 @@ ADC_HD uint32_t irv_tile_hit(uint32_t word, uint32_t nk, uint32_t want4)
     return (x - 0x01010101u) & ~x & 0x80808080u;
 }
 struct IrvBlock {
-    uint32_t okm;   // pixels that count in the vote (bit q = pixel px0 + q)
-    uint32_t first; // bin of the lowest counted pixel
-    uint32_t same;  // the counted pixels that fall into `first` (== okm when single)
-    bool single;    // all counted pixels fall into `first`
-    bool open;      // an eligible predecessor of p in this block is not final yet
+    uint32_t okm;        // pixels that count in SOME iteration's vote (bit q = pixel px0 + q)
+    uint32_t k0, k1, k2, k3; // their keys t << 11 | bin, packed like the state halfwords (t = iteration from which the pixel counts)
+    uint32_t first;      // key of the lowest counted pixel
+    uint32_t same;       // the counted pixels that share that key
 };
-// The pixels of `rem` (a non-empty subset of a block's counted pixels) that share the bin of the lowest one; *bin = that bin.
-ADC_HD uint32_t irv_same_bin_mask(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t vw, uint32_t rem, uint32_t* bin)
+// The pixels of `rem` (a non-empty subset of a block's counted pixels) that share the key of the lowest one; *key = that key.
+ADC_HD uint32_t irv_same_key_mask(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t rem, uint32_t* key)
 {
-    const uint32_t b0 = vx & 0x07FF07FFu, b1 = vy & 0x07FF07FFu, b2 = vz & 0x07FF07FFu, b3 = vw & 0x07FF07FFu;
     const int q0 = __builtin_ffs((int)rem) - 1;
-    const uint32_t wsel = q0 < 2 ? b0 : (q0 < 4 ? b1 : (q0 < 6 ? b2 : b3));
-    const uint32_t f = (wsel >> (16 * (q0 & 1))) & IRV_BIN_MASK, f2 = f * 0x00010001u;
-    // halfwords that differ from that bin: (d + 0x7FF) carries into bit 11 iff d != 0
-    const uint32_t difm = irv_gather8((b0 ^ f2) + 0x07FF07FFu, (b1 ^ f2) + 0x07FF07FFu, (b2 ^ f2) + 0x07FF07FFu, (b3 ^ f2) + 0x07FF07FFu, 11);
-    *bin = f;
+    const uint32_t wsel = q0 < 2 ? k0 : (q0 < 4 ? k1 : (q0 < 6 ? k2 : k3));
+    const uint32_t f = (wsel >> (16 * (q0 & 1))) & IRV_KEY_MASK, f2 = f * 0x00010001u;
+    // halfwords that differ from that key: (d + 0x3FFF) carries into bit 14 iff d != 0 (keys are 14 bits wide)
+    const uint32_t difm = irv_gather8(((k0 ^ f2) & 0x3FFF3FFFu) + 0x3FFF3FFFu, ((k1 ^ f2) & 0x3FFF3FFFu) + 0x3FFF3FFFu,
+                                      ((k2 ^ f2) & 0x3FFF3FFFu) + 0x3FFF3FFFu, ((k3 ^ f2) & 0x3FFF3FFFu) + 0x3FFF3FFFu, 14);
+    *key = f;
     return rem & ~difm;
 }
-// Block of 8 pixels px0 .. px0 + 7 of region row yt, of which [xl, xr] belong to the region of p = (x, y).
-ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t vw, int px0, int xl, int xr, int yt, int y, int x)
+// bits 2j, 2j+1 of an 8-bit pixel mask -> bit 11 of the low / high halfword of word j (the key's t field += 1)
+ADC_HD uint32_t irv_adj_word(uint32_t m, int j) { return (((m >> (2 * j)) & 1u) << IRV_F_SHIFT) | (((m >> (2 * j + 1)) & 1u) << (IRV_F_SHIFT + 16)); }
+// Block of 8 pixels px0 .. px0 + 7 of region row yt, of which [xl, xr] belong to the region of p = (x, y), a pixel of list lp.
+ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t vw, int px0, int xl, int xr, int yt, int y, int x, int lp)
 {
     IrvBlock r;
     const uint32_t inm = (((2u << adc_imin(xr - px0, 7)) - 1u) & ~((1u << adc_imax(xl - px0, 0)) - 1u)) & 0xffu;
-    // pixels that precede p in raster order
+    // pixels that precede p in raster order, and p itself (a pixel does not vote for itself: it is invalid while it is voted for)
     const uint32_t prem = yt < y ? 0xffu : (yt == y ? ((1u << adc_imax(0, adc_imin(x - px0, 8))) - 1u) : 0u);
+    const uint32_t selfm = (yt == y && x >= px0 && x < px0 + 8) ? (1u << (x - px0)) : 0u;
     const uint32_t b0 = vx & 0x07FF07FFu, b1 = vy & 0x07FF07FFu, b2 = vz & 0x07FF07FFu, b3 = vw & 0x07FF07FFu; // bins
-    const uint32_t elm = irv_gather8(vx, vy, vz, vw, 15);  // eligible
-    const uint32_t finm = irv_gather8(vx, vy, vz, vw, 14); // final
+    const uint32_t l1m = irv_gather8(vx, vy, vz, vw, 14); // on the mismatch list
+    const uint32_t l2m = irv_gather8(vx, vy, vz, vw, 15); // on the occlusion list
     // bin == 0x7FF (invalid / never counted): 0x7FF + 1 carries into bit 11 of the halfword
     const uint32_t invm = irv_gather8(b0 + 0x00010001u, b1 + 0x00010001u, b2 + 0x00010001u, b3 + 0x00010001u, 11);
-    // eligible pixels of this pass are visible only if they precede p (already processed by the sequential scan);
-    // otherwise they are still invalid
-    r.okm = inm & ~invm & (~elm | prem);
-    // an eligible predecessor that is not final yet: this vote may still change
-    r.open = (inm & elm & prem & ~finm) != 0u;
+    // pixels that count one iteration later than they were filled (irv_plan.h, top)
+    const uint32_t adjm = lp == 1 ? ((l1m & ~prem) | l2m) : (l2m & ~prem);
+    r.k0 = (vx & 0x3FFF3FFFu) + irv_adj_word(adjm, 0);
+    r.k1 = (vy & 0x3FFF3FFFu) + irv_adj_word(adjm, 1);
+    r.k2 = (vz & 0x3FFF3FFFu) + irv_adj_word(adjm, 2);
+    r.k3 = (vw & 0x3FFF3FFFu) + irv_adj_word(adjm, 3);
+    // t >= IRV_LEVELS (filled in the last iteration and only visible in the next one): never counted.  t + 3 >= 8 carries into bit 14
+    const uint32_t latem = irv_gather8((r.k0 & 0x38003800u) + 0x18001800u, (r.k1 & 0x38003800u) + 0x18001800u,
+                                       (r.k2 & 0x38003800u) + 0x18001800u, (r.k3 & 0x38003800u) + 0x18001800u, 14);
+    r.okm = inm & ~invm & ~selfm & ~latem;
     r.first = 0u;
     r.same = 0u;
-    r.single = false;
-    if (r.okm != 0u) {
-        const int q0 = __builtin_ffs((int)r.okm) - 1;
-        const uint32_t wsel = q0 < 2 ? b0 : (q0 < 4 ? b1 : (q0 < 6 ? b2 : b3));
-        r.first = (wsel >> (16 * (q0 & 1))) & IRV_BIN_MASK;
-        const uint32_t f2 = r.first * 0x00010001u;
-        // halfwords that differ from the first counted bin: (d + 0x7FF) carries into bit 11 iff d != 0
-        const uint32_t difm = irv_gather8((b0 ^ f2) + 0x07FF07FFu, (b1 ^ f2) + 0x07FF07FFu, (b2 ^ f2) + 0x07FF07FFu, (b3 ^ f2) + 0x07FF07FFu, 11);
-        r.same = r.okm & ~difm;
-        r.single = r.same == r.okm;
-    }
+    if (r.okm != 0u) r.same = irv_same_key_mask(r.k0, r.k1, r.k2, r.k3, r.okm, &r.first);
     return r;
 }

@@ -3,31 +3,26 @@
 // filled, which round runs and when a pass has converged is decided on the device.
 //
 // Semantics kept exactly: 5 iterations x {mismatches, occlusions}; inside a pass the reference fills the
-// still-invalid pixels of the list in raster order IN PLACE, so a vote sees the fills of the list pixels that precede
-// it.  Per pass we iterate "value(p) = vote(p | values of the eligible pixels that precede p in raster order)" to its
-// fixed point: the system is triangular, every (chaotic, in-place) iteration converges to the sequential result, and a
-// whole round without a change proves the fixed point.  Votes only ever need lround(d) - dmin of a region pixel, so the
-// pass works on a 16-bit STATE MAP (2 bytes per pixel, L2-resident at 1080p):
-//     bits 0..10  histogram bin (0x7FF = invalid / never counted)
-//     bit  14     final   (the value can no longer change in this pass: set together with the value, ONE 16-bit store)
-//     bit  15     eligible (pixel of the current list that was invalid at pass start)
+// still-invalid pixels of the list in raster order IN PLACE, so a vote sees the fills of the list pixels that precede it, and
+// later passes see the fills of earlier ones.  Round 5: all ten passes are ONE fixed-point iteration on ONE 16-bit state per
+// pixel (irv_plan.h, top: bin | iteration of the fill | list) -- the system is triangular in the order (iteration, list, raster
+// position), so every chaotic in-place iteration converges to the sequential result and a whole round without a change proves
+// it.  Votes only ever need lround(d) - dmin of a region pixel, so the state map is 2 bytes per pixel (L2-resident at 1080p).
 // A vote (one wave per entry) reads the cross region as 16-byte row blocks (8 pixels per lane and load, 16 region rows
-// x 4 blocks per trip: one trip for a typical region of 13 rows x 13 pixels) into an LDS histogram.  Entries whose
-// eligible predecessors were all final get the final bit and are never evaluated again; from round 1 on only entries
-// whose dependency box (k_irv_bbox) saw a change in the previous round are re-evaluated (8x8 change tiles).
+// x 4 blocks per trip: one trip for a typical region of 13 rows x 13 pixels) into the LDS histograms of the iterations from
+// which the pixels count, and takes the first iteration whose CUMULATIVE histogram passes the vote.  From round 1 on only
+// entries whose region saw a change in the previous round are re-evaluated (8x8 change tiles over the region's bounding box).
 //
 // The chain.  Kernel k reads the state its predecessor wrote (slot k & 1) and the predecessor's accumulator
 // acc[(k-1) & 63] (list length / "something changed"), derives its own action -- every block derives the same one -- and
 // block 0 publishes the new state into slot (k+1) & 1 and clears the accumulators kernel k+2 will use.  No host round
 // trip, no grid barrier (measured: 4.2-4.8 us on this chip against 2.4-2.9 us for a dependent launch,
 // tools/ubench/grid_sync.hip), no ticket atomics:
-//     BEGIN  write the previous pass's fills back to the float map, mark the eligible pixels of the next list, build the
-//            work list (pixels whose region is too small to ever pass the vote are left out)
+//     BEGIN  seed the working copy of the map, build the state map and the work list (listed pixels whose region is too
+//            small to ever pass the vote are left out)
 //     ROUND  ONE kernel per round: every wave holds (up to) 64 list entries, one per lane, decides per lane whether the
-//            entry has to be re-evaluated and evaluates its dirty entries one after the other.  (The first version ran a
-//            compaction kernel and a vote kernel per round; a round of the long tail is a chain of dependent memory round
-//            trips, and the second kernel boundary + plan + list round trip were 40 % of it.)
-//     FINAL  write the last pass's fills back
+//            entry has to be re-evaluated and evaluates its dirty entries one after the other.
+//     FINAL  write the fills back
 // The chain length is a BUDGET (adc_handle::irv_budget, adapted from the kernels the last Matches of the handle needed);
 // when it is exhausted before the state machine reaches DONE, adc_wait continues the same chain synchronously and redoes
 // the stages behind it -- a performance cliff, never a different result.
@@ -141,6 +136,19 @@ __device__ __forceinline__ int irv_row_prefix(int v)
 }
 #undef IRV_DPP
 
+// A 16-byte block of the state map, read PAST the CU's L1 (sc1: served by the XCD's L2).  What the other workgroups of this XCD
+// have written in THIS kernel so far is there -- the sweep down a band (irv_plan.h) lives on that; exactness does not.  (An
+// acquire fence per vote -- buffer_inv sc1, which drops the whole L1 -- made the votes 7x slower, measured.)
+#ifndef IRV_LOAD_CPOL
+#define IRV_LOAD_CPOL 16 /* sc1 */
+#endif
+typedef unsigned int irv_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 irv_ld_state(__amdgpu_buffer_rsrc_t rs, uint32_t elem)
+{
+    const irv_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 2u), 0, IRV_LOAD_CPOL);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // ------------------------------------------------------------------------------------------- the kernel of the chain
 // Work-list entry: {pixel, arms of the pixel, max left | max right << 8 of its dependency box, row y}.
 // Workgroups of up to 16 waves (blockDim.x = 64 * waves): the dirty entries of a workgroup's waves are
@@ -152,7 +160,8 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                                                 const uint16_t* __restrict__ sup_h, uint16_t* st16, int4* list, uint8_t* chg,
                                                 const uint32_t* __restrict__ bbox32, const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
                                                 int D, int min_region, int chg_bytes, int tpitch, int irv_ts, float irv_th,
-                                                int32_t* __restrict__ evals_arr)
+                                                int32_t* __restrict__ evals_arr, int seg_cap, int xcd_mode, int32_t* wg_n /* entries per workgroup segment */,
+                                                unsigned long long* listed_bits /* bit p: pixel p goes on the work list (BEGIN -> BEGIN2) */)
 {
     IRV_TR(8);
     IRV_T(0);
@@ -164,23 +173,27 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     // the slowest load of the kernel) has arrived.  Slots beyond the list hold older entries or zeros: always in-bounds.
     // (The state is fetched with a VECTOR load -- lane l reads word l, lane 8 the accumulator -- because scalar loads return
     // out of order: the kernel-argument loads would wait for it.)
-    const int4 spec = list[(size_t)gw * 64 + lane];
+    int4* seg = list + (size_t)blockIdx.x * seg_cap; // this workgroup's segment of the work list (irv_plan.h)
+    const int4 spec = seg[threadIdx.x];
     const int cword = ctrl[lane < 8 ? 16 * (k & 1) + lane : IRV_ACC + ((k + 63) & 63)];
+    const int ngv = wg_n[blockIdx.x]; // (a vector load like the state: scalar loads return out of order)
     const uint32_t want4 = ((uint32_t)((k + 254) % 255) + 1u) * 0x01010101u; // stamp of kernel k - 1
     const uint32_t stamp = (uint32_t)(k % 255) + 1u;
     const uint8_t* chg_rd = chg + (size_t)((k + 1) & 1) * chg_bytes;
     uint8_t* chg_wr = chg + (size_t)(k & 1) * chg_bytes;
     // Slots behind the end of the list hold IRV_LIST_END (see irv_plan.h): a wave that finds nothing else skips this phase.
-    uint32_t spec_state = IRV_FINAL;
+    uint32_t spec_state = 0u;
     bool spec_box = false;
     if (__ballot(spec.x != IRV_LIST_END) != 0ull) {
         const bool have = spec.x != IRV_LIST_END;
         const int p = have ? spec.x : 0, y = have ? spec.w : 0, x = p - y * W;
         spec_state = st16[(uint32_t)(y * SP + x)]; // (32-bit offsets from a uniform base: saddr addressing, no 64-bit VGPR pairs)
-        const int top = (int)(((uint32_t)spec.y >> 16) & 255u), ml = spec.z & 255, mr = (spec.z >> 8) & 255;
+        // the bounding box of the WHOLE region: every region pixel is an input of some iteration's vote
+        const int top = (int)(((uint32_t)spec.y >> 16) & 255u), bot = (int)((uint32_t)spec.y >> 24);
+        const int ml = (int)(((uint32_t)spec.z >> 16) & 255u), mr = (int)((uint32_t)spec.z >> 24);
         // (a lane without an entry gets an empty tile range: no loads)
         spec_box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, have ? adc_imin(W - 1, x + mr) / IRV_TILE : -1,
-                                 adc_imax(0, y - top) / IRV_TILE, y / IRV_TILE, want4);
+                                 adc_imax(0, y - top) / IRV_TILE, adc_imin(H - 1, y + bot) / IRV_TILE, want4);
     }
     const IrvState sprev = {__builtin_amdgcn_readlane(cword, 0), __builtin_amdgcn_readlane(cword, 1), __builtin_amdgcn_readlane(cword, 2),
                             __builtin_amdgcn_readlane(cword, 3), __builtin_amdgcn_readlane(cword, 4), __builtin_amdgcn_readlane(cword, 5),
@@ -190,11 +203,10 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     if (pl.act != IRV_FINAL_WB && blockIdx.x == 0 && threadIdx.x == 0) irv_publish(ctrl, k, pl.s);
     if (pl.act == IRV_DONE) return;
     int32_t* acc = ctrl + IRV_ACC + (k & 63);
-    const int P = W * H;
     if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
         // evaluation statistics: every wave counts in its own slot (a same-address atomic per wave and round cost more
         // than the votes of a tail round: they retire at ~8 ns each); cleared by the first kernel, summed by the last
-        if (pl.act == IRV_BEGIN && pl.s.pass == 0)
+        if (pl.act == IRV_BEGIN)
             for (int t = blockIdx.x * T + threadIdx.x; t < NW; t += gridDim.x * T) evals_arr[t] = 0;
         if (pl.act == IRV_FINAL_WB && blockIdx.x == 0) {
             __shared__ int esum[IRV_MAXW];
@@ -211,115 +223,129 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             }
         }
         // the no-op kernels behind the end of the chain (the budget's surplus) then find no entry and skip the state / tile
-        // round trip: the first batch of the list becomes end markers
-        if (pl.act == IRV_FINAL_WB) list[(size_t)gw * 64 + lane].x = IRV_LIST_END;
-        const bool have_state = !(pl.act == IRV_BEGIN && pl.s.pass == 0); // pass 0: the state map is not initialised yet
-        const int which = (pl.s.pass & 1) ? ADC_LABEL_OCCLUSION : ADC_LABEL_MISMATCH; // mismatches, then occlusions (:170-171)
-        if (pl.act == IRV_BEGIN) // clear both change-tile planes of the pass (bytes, written as dwords)
+        // round trip: the first batch of the segment becomes end markers
+        if (pl.act == IRV_FINAL_WB) seg[threadIdx.x].x = IRV_LIST_END;
+        if (pl.act == IRV_BEGIN) // clear both change-tile planes (bytes, written as dwords)
             for (int t = blockIdx.x * T + threadIdx.x; t < chg_bytes / 2; t += gridDim.x * T) reinterpret_cast<uint32_t*>(chg)[t] = 0u;
-        __shared__ int wcnt[IRV_PPT][IRV_MAXW];
-        __shared__ int base;
-        for (int c0 = blockIdx.x * (T * IRV_PPT); c0 < P; c0 += gridDim.x * (T * IRV_PPT)) {
-            uint32_t listed = 0u; // bit q: pixel c0 + q * T + threadIdx.x goes on the work list
-#pragma unroll 1
-            for (int q = 0; q < IRV_PPT; q++) {
-                const int p = c0 + q * T + threadIdx.x;
-                bool li = false;
-                if (p < P) {
-                    const int y = p / W, x = p - y * W;
-                    const size_t i16 = (size_t)y * SP + x;
-                    float dv = have_state ? disp[p] : disp_io[p]; // pass 0 starts from the LR-checked map itself
-                    if (have_state) { // fills of the previous pass: the vote result is best_bin + min_disparity (:211)
-                        const uint32_t s = st16[i16];
-                        if ((s & IRV_ELIG) && (s & IRV_BIN_MASK) != IRV_BIN_MASK) {
-                            dv = (float)((int)(s & IRV_BIN_MASK) + dmin);
-                            disp[p] = dv;
-                        }
+        // one coalesced pass over the image: state map / working copy (BEGIN), fills (FINAL)
+        const int P = W * H;
+        for (int c0 = blockIdx.x * T; c0 < P; c0 += gridDim.x * T) {
+            const int p = c0 + threadIdx.x;
+            bool li = false;
+            if (p < P) {
+                const int y = p / W, x = p - y * W;
+                const size_t i16 = (size_t)y * SP + x;
+                if (pl.act == IRV_FINAL_WB) { // fills: the vote result is best_bin + min_disparity (multistep_refiner.cpp:211)
+                    float dv = disp[p];
+                    const uint32_t sv = st16[i16];
+                    if ((sv >> IRV_LIST_SHIFT) != 0u && (sv & IRV_BIN_MASK) != IRV_BIN_MASK) dv = (float)((int)(sv & IRV_BIN_MASK) + dmin);
+                    disp_io[p] = dv; // the result goes straight back into the pipeline's map
+                } else {
+                    const float dv = disp_io[p]; // the LR-checked map itself ...
+                    disp[p] = dv;                // ... seeds the working copy (what a continued chain's FINAL starts from)
+                    const uint32_t lab = label[p];
+                    const bool e = (lab == ADC_LABEL_MISMATCH || lab == ADC_LABEL_OCCLUSION) && (dv == ADC_INVALID_FLOAT);
+                    // the vote needs count > irv_ts and count <= region size == horizontal-first support count, so
+                    // pixels with sup_h <= irv_ts stay invalid whatever happens: on their list (they are invalid in every
+                    // iteration), but not on the work list
+                    li = e && ((int)sup_h[p] > min_region);
+                    uint32_t bin = IRV_BIN_MASK;
+                    if (dv != ADC_INVALID_FLOAT) {
+                        const long b = lroundf(dv) - dmin; // multistep_refiner.cpp:193-196
+                        if (b >= 0 && b < D) bin = (uint32_t)b; // (outside the histogram: never counted)
                     }
-                    if (!have_state) disp[p] = dv;              // ... and seeds the working copy
-                    if (pl.act == IRV_FINAL_WB) disp_io[p] = dv; // the result goes straight back into the pipeline's map
-                    if (pl.act == IRV_BEGIN) {
-                        const bool e = (label[p] == which) && (dv == ADC_INVALID_FLOAT);
-                        // the vote needs count > irv_ts and count <= region size == horizontal-first support count, so
-                        // pixels with sup_h <= irv_ts stay invalid whatever happens: eligible (they order the pass) but
-                        // final from the start and not on the work list
-                        li = e && ((int)sup_h[p] > min_region);
-                        uint32_t bin = IRV_BIN_MASK;
-                        if (dv != ADC_INVALID_FLOAT) {
-                            const long b = lroundf(dv) - dmin; // multistep_refiner.cpp:193-196
-                            if (b >= 0 && b < D) bin = (uint32_t)b; // (outside the histogram: never counted)
-                        }
-                        st16[i16] = (uint16_t)(bin | (e ? IRV_ELIG : 0u) | (li ? 0u : IRV_FINAL));
-                    }
+                    st16[i16] = (uint16_t)(bin | (e ? lab << IRV_LIST_SHIFT : 0u));
                 }
-                listed |= (li ? 1u : 0u) << q;
+            }
+            if (pl.act == IRV_BEGIN) { // (the 64 pixels of a wave are consecutive and start at a multiple of 64)
                 const unsigned long long m = __ballot(li);
-                if (lane == 0) wcnt[q][wave] = __popcll(m);
+                if (lane == 0 && c0 + wave * 64 < P) listed_bits[(c0 + wave * 64) >> 6] = m;
             }
-            if (pl.act != IRV_BEGIN) continue; // (uniform)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int tot = 0;
-                for (int q = 0; q < IRV_PPT; q++)
-                    for (int w = 0; w < WPB; w++) tot += wcnt[q][w];
-                base = tot ? atomicAdd(acc, tot) : 0; // one same-address atomic per chunk of pixels (they retire at ~8 ns each)
-            }
-            __syncthreads();
-            int off = base;
-#pragma unroll 1
-            for (int q = 0; q < IRV_PPT; q++) {
-                const int p = c0 + q * T + threadIdx.x;
-                const bool li = (listed >> q) & 1u;
-                const unsigned long long m = __ballot(li);
-                int mine = off;
-                for (int w = 0; w < WPB; w++) {
-                    const int c = wcnt[q][w];
-                    mine += w < wave ? c : 0;
-                    off += c;
-                }
-                if (li) { // everything a round needs to know about the entry in ONE 16-byte load
-                    const long i = mine + __popcll(m & ((1ull << lane) - 1ull));
-                    list[irv_list_slot(i, (int)gridDim.x, WPB)] = make_int4(p, (int)arms32[p], (int)bbox32[p], p / W);
-                }
-            }
-            __syncthreads();
         }
         return;
     }
-    // ROUND.  Phase 1 (one entry per lane; done above for batch 0): is the entry still open, and did a pixel of its
-    // dependency box change in the previous round?  Change tiles are BYTES holding the stamp of the last kernel that changed
-    // a pixel of the 8x8 tile (0 = never; a stamp aliasing a kernel 510 launches earlier can only cause a redundant
-    // evaluation, never a missed one).  Phase 2: the dirty entries of the workgroup are pooled in LDS.  Phase 3: wave w
-    // evaluates pool entries w, w + waves, ...
-    const int round = pl.s.round, n = pl.s.n;
-    extern __shared__ int lds_dyn[]; // [waves][D] histograms, then the pool: [waves][64] int4
-    int* hist = lds_dyn + wave * D;
-    int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * D + 3) & ~3)); // (16-byte aligned whatever D is)
+    if (pl.act == IRV_BEGIN2) {
+        // The workgroup walks ITS tiles (irv_plan.h: tile t belongs to workgroup t % G) row by row and compacts the listed pixels
+        // into its segment in the order (row inside the band, tile, column) -- the order in which the rounds evaluate them.
+        __shared__ int wcnt[IRV_MAXW];
+        __shared__ int base;
+        if (threadIdx.x == 0) base = 0;
+        __syncthreads();
+        const int my_tiles = irv_wg_tiles(W, H, (int)gridDim.x, (int)blockIdx.x, xcd_mode), per_step = T / IRV_TCOLS;
+        const int tk = threadIdx.x / IRV_TCOLS, xi = threadIdx.x % IRV_TCOLS;
+#pragma unroll 1
+        for (int j = 0; j < IRV_BAND; j++) {
+#pragma unroll 1
+            for (int k0 = 0; k0 < my_tiles; k0 += per_step) {
+                bool li = false;
+                int p = 0;
+                if (k0 + tk < my_tiles) {
+                    int band, tx;
+                    irv_wg_tile(W, H, (int)gridDim.x, (int)blockIdx.x, k0 + tk, xcd_mode, &band, &tx);
+                    const int y = band * IRV_BAND + j, x = tx * IRV_TCOLS + xi;
+                    if (y < H && x < W) {
+                        p = y * W + x;
+                        li = (listed_bits[p >> 6] >> (p & 63)) & 1ull;
+                    }
+                }
+                const unsigned long long m = __ballot(li);
+                if (lane == 0) wcnt[wave] = __popcll(m);
+                __syncthreads();
+                int mine = base, tot = 0;
+                for (int w = 0; w < WPB; w++) {
+                    const int c = wcnt[w];
+                    mine += w < wave ? c : 0;
+                    tot += c;
+                }
+                if (li) // everything a round needs to know about the entry in ONE 16-byte load
+                    seg[mine + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(p, (int)arms32[p], (int)bbox32[p], p / W);
+                __syncthreads();
+                if (threadIdx.x == 0) base += tot;
+                __syncthreads();
+            }
+        }
+        const int ng = base;
+        for (int t = ng + threadIdx.x; t < ((ng + T - 1) / T) * T && t < seg_cap; t += T) seg[t].x = IRV_LIST_END; // the rest of the last batch
+        if (threadIdx.x == 0) {
+            wg_n[blockIdx.x] = ng;
+            if (ng) atomicAdd(acc, ng); // (the chain state's n: statistics only)
+        }
+        return;
+    }
+    // ROUND.  Phase 1 (one entry per lane; done above for batch 0): did a pixel of the entry's region box change in the previous
+    // round?  Change tiles are BYTES holding the stamp of the last kernel that changed a pixel of the 8x8 tile (0 = never; a
+    // stamp aliasing a kernel 510 launches earlier can only cause a redundant evaluation, never a missed one).  Phase 2: the
+    // dirty entries of the workgroup are pooled in LDS.  Phase 3: wave w evaluates pool entries w, w + waves, ...
+    const int round = pl.s.round;
+    extern __shared__ int lds_dyn[]; // [waves][IRV_LEVELS][D] histograms, then the pool: [waves][64] int4
+    int* hist = lds_dyn + wave * (IRV_LEVELS * D);
+    int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * IRV_LEVELS * D + 3) & ~3)); // (16-byte aligned whatever D is)
     __shared__ int pcount[IRV_MAXW];
     const int sub = lane >> 2, bslot = lane & 3;
-    const long B = 64L * NW;
+    const __amdgpu_buffer_rsrc_t st_rs = __builtin_amdgcn_make_buffer_rsrc(st16, 0, (SP * H + 64) * 2, 0x00020000);
+    const int ng = __builtin_amdgcn_readfirstlane(ngv); // entries of this workgroup's segment, in evaluation order
     int evals = 0;
-    for (long b0 = 0; b0 < n; b0 += B) {
-        const long i = irv_list_index(b0, (int)blockIdx.x, wave, lane, (int)gridDim.x);
+    if (ng > 0) // the wave's histograms start empty; every vote clears the rows it has touched behind itself
+        for (int b = lane; b < IRV_LEVELS * D; b += 64) hist[b] = 0;
+    for (int b0 = 0; b0 < ng; b0 += T) {
+        const int i = b0 + (int)threadIdx.x;
         int4 ent = spec;
         if (b0 != 0) {
-            ent = list[b0 + (size_t)gw * 64 + lane];
+            ent = seg[i];
             __syncthreads(); // the previous batch's pool has been consumed
         }
         uint32_t mystate = spec_state;
         bool box = spec_box;
-        if (b0 != 0) { // (later batches are full up to n: entries of this pass, or older ones / end markers behind n)
+        if (b0 != 0) { // (later batches are full up to ng: entries of this chain, or older ones / end markers behind ng)
             const bool have = ent.x != IRV_LIST_END;
             const int p = have ? ent.x : 0, y = have ? ent.w : 0, x = p - y * W;
             mystate = st16[(uint32_t)(y * SP + x)];
-            const int top = (int)(((uint32_t)ent.y >> 16) & 255u), ml = ent.z & 255, mr = (ent.z >> 8) & 255;
+            const int top = (int)(((uint32_t)ent.y >> 16) & 255u), bot = (int)((uint32_t)ent.y >> 24);
+            const int ml = (int)(((uint32_t)ent.z >> 16) & 255u), mr = (int)((uint32_t)ent.z >> 24);
             box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, have ? adc_imin(W - 1, x + mr) / IRV_TILE : -1,
-                                adc_imax(0, y - top) / IRV_TILE, y / IRV_TILE, want4);
+                                adc_imax(0, y - top) / IRV_TILE, adc_imin(H - 1, y + bot) / IRV_TILE, want4);
         }
-        // The first round of a pass marks the unused slots of the first batch (older entries, whatever the BEGIN kernel did not
-        // overwrite) as the end of the list: from round 1 on the waves that hold nothing else skip the phase above.
-        if (round == 0 && b0 == 0 && i >= n && ent.x != IRV_LIST_END) list[(size_t)gw * 64 + lane].x = IRV_LIST_END;
-        const bool dirty = i < n && (round == 0 || box) && !(mystate & IRV_FINAL); // final values are never re-evaluated
+        const bool dirty = i < ng && (round == 0 || box);
         IRV_T(2);
         // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
         // consumers find pool item t by a prefix sum over the (<= 16) counts
@@ -340,9 +366,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
             const uint32_t pz = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z);
             const uint32_t cur = pz & 0xFFFFu; // (only this wave writes the entry in this round)
+            const int lp = (int)(cur >> IRV_LIST_SHIFT); // the entry's list: 1 mismatch, 2 occlusion
             const int x = p - y * W;
-            for (int b = lane; b < D; b += 64) hist[b] = 0;
-            bool deps_open = false;
+            uint32_t lvls = 0u; // iterations from which a pixel seen by this lane starts to count
             const int top = (int)(((uint32_t)armsp >> 16) & 255u), nrows = top + (int)((uint32_t)armsp >> 24) + 1; // region rows y-top .. y+bottom
             const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
             // the read box: blocks blkL .. blkR cover the widest row of the region
@@ -359,7 +385,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 uint4 vfirst;
                 {
                     const bool in0 = sub < rend && blkL + bslot <= blkR;
-                    vfirst = *reinterpret_cast<const uint4*>(st16 + (in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own));
+                    vfirst = irv_ld_state(st_rs, in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own);
                 }
                 IRV_T(4);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
@@ -377,80 +403,74 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                         uint4 v = vfirst;
                         if (r0 + bo != 0) { // (uniform) loads stay unconditional: masked-out lanes read the entry's own block
                             const uint32_t addr = rowok && blk <= blkR ? (uint32_t)(yt * SP + blk * 8) : own;
-                            v = *reinterpret_cast<const uint4*>(st16 + addr);
+                            v = irv_ld_state(st_rs, addr);
                         }
                         IRV_T(5);
                         // The 8 pixels of the block, decoded as packed halfwords (irv_plan.h: irv_decode_block): which pixels
-                        // count, and which of them share the first one's bin?
-                        uint32_t okm = 0u;
+                        // count from which iteration on, and which of them share the first one's key (iteration | bin)?
                         if (use) {
-                            const IrvBlock bd = irv_decode_block(v.x, v.y, v.z, v.w, blk * 8, xl, xr, yt, y, x);
-                            deps_open = deps_open || bd.open;
-                            okm = bd.okm;
-                            // One LDS atomic per DISTINCT bin of the block (same-address LDS atomics serialise: never one per pixel).  The
-                            // pixels of the first bin come with the decode; a region row that straddles a disparity edge holds a second
+                            const IrvBlock bd = irv_decode_block(v.x, v.y, v.z, v.w, blk * 8, xl, xr, yt, y, x, lp);
+                            uint32_t okm = bd.okm;
+                            // One LDS atomic per DISTINCT key of the block (same-address LDS atomics serialise: never one per pixel).  The
+                            // pixels of the first key come with the decode; a region row that straddles a disparity edge holds a second
                             // surface (24-27 % of the blocks of a natural image hold several bins, tools/irv_block_stats.py), rarely a
-                            // third: the loop takes the lowest remaining pixel's bin and all pixels that share it.  Round 4: before, every
-                            // pixel of a block with several bins was counted by its own atomic, the wave running as many trips as its worst
-                            // lane had pixels (2.7-4.4 trips per vote; refine stage of the structured pair 4.75 -> 4.28 ms,
-                            // profiles/r4_ab_k8_merge_bins.txt; IRV_PER_PIXEL_ATOMICS restores that form for the A/B).  (Counting the
-                            // dominant bin in registers across the wave was measured too: slower, the extra wave reduction costs more.)
-#ifdef IRV_PER_PIXEL_ATOMICS
-                            if (okm != 0u && bd.single) {
-                                atomicAdd(&hist[bd.first], __popc(okm));
-                                okm = 0u;
-                            }
-#else
+                            // third: the loop takes the lowest remaining pixel's key and all pixels that share it.
                             if (okm != 0u) {
-                                atomicAdd(&hist[bd.first], __popc(bd.same));
+                                atomicAdd(&hist[(int)(bd.first >> IRV_F_SHIFT) * D + (int)(bd.first & IRV_BIN_MASK)], __popc(bd.same));
+                                lvls |= 1u << (bd.first >> IRV_F_SHIFT);
                                 okm &= ~bd.same;
                             }
 #pragma clang loop unroll(disable)
                             while (okm != 0u) {
-                                uint32_t bin2;
-                                const uint32_t same2 = irv_same_bin_mask(v.x, v.y, v.z, v.w, okm, &bin2);
-                                atomicAdd(&hist[bin2], __popc(same2));
+                                uint32_t key2;
+                                const uint32_t same2 = irv_same_key_mask(bd.k0, bd.k1, bd.k2, bd.k3, okm, &key2);
+                                atomicAdd(&hist[(int)(key2 >> IRV_F_SHIFT) * D + (int)(key2 & IRV_BIN_MASK)], __popc(same2));
+                                lvls |= 1u << (key2 >> IRV_F_SHIFT);
                                 okm &= ~same2;
                             }
-#endif
                         }
-#ifdef IRV_PER_PIXEL_ATOMICS
-                        if (okm != 0u) { // pixels of several bins: one atomic each
-#pragma clang loop unroll(disable)
-                            for (uint32_t m = okm; m != 0u; m &= m - 1u) {
-                                const int q = __ffs((int)m) - 1;
-                                const uint32_t wq = q < 2 ? v.x : (q < 4 ? v.y : (q < 6 ? v.z : v.w));
-                                atomicAdd(&hist[(wq >> (16 * (q & 1))) & IRV_BIN_MASK], 1);
-                            }
-                        }
-#endif
                         if (!__any(rowok && (blkL + bo + 4 <= b1x))) break;
                     }
                 }
             }
             IRV_T(6);
-            // first maximum (lowest bin on ties) and total count (multistep_refiner.cpp:199-209): key = count << 11 | (2047 - bin)
-            int key = 0, cnt = 0;
-            for (int b = lane; b < D; b += 64) {
-                const int hv = hist[b];
-                cnt += hv;
-                key = adc_imax(key, hv > 0 ? ((hv << 11) | (0x7FF - b)) : 0);
-            }
-            key = irv_wave_max(key);
-            cnt = irv_wave_sum(cnt);
-            const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
-            const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-            const bool all_final = __ballot(deps_open) == 0ull; // every eligible predecessor in the region was already final
-            IRV_T(7);
-            if (lane == 0) {
-                const uint32_t i16 = (uint32_t)(y * SP + x);
-                const uint32_t nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
-                const uint32_t ns = nb | IRV_ELIG | (all_final ? IRV_FINAL : 0u);
-                if (ns != cur) st16[i16] = (uint16_t)ns; // value and final bit in ONE store
-                if (nb != (cur & IRV_BIN_MASK)) {
-                    chg_wr[(uint32_t)((y / IRV_TILE) * tpitch + x / IRV_TILE)] = (uint8_t)stamp;
-                    *acc = 1;
+            // The votes of the iterations, lowest first, on the CUMULATIVE histograms (row `it` += the last non-empty row below it);
+            // an iteration that adds no pixel repeats the previous decision (which failed).  First maximum (lowest bin on ties)
+            // and total count (multistep_refiner.cpp:199-209): key = count << 11 | (2047 - bin).
+            uint32_t present = 0u;
+#pragma unroll
+            for (int it = 0; it < IRV_LEVELS; it++) present |= (__ballot((lvls >> it) & 1u) != 0ull ? 1u : 0u) << it;
+            uint32_t ns = IRV_BIN_MASK | ((uint32_t)lp << IRV_LIST_SHIFT); // no iteration's vote passes: invalid
+            int below = -1;
+#pragma clang loop unroll(disable)
+            for (int it = 0; it < IRV_LEVELS; it++) {
+                if (!((present >> it) & 1u)) continue; // (uniform)
+                int key = 0, cnt = 0;
+                for (int b = lane; b < D; b += 64) {
+                    int hv = hist[it * D + b];
+                    if (below >= 0) { hv += hist[below * D + b]; hist[it * D + b] = hv; }
+                    cnt += hv;
+                    key = adc_imax(key, hv > 0 ? ((hv << 11) | (0x7FF - b)) : 0);
                 }
+                below = it;
+                key = irv_wave_max(key);
+                cnt = irv_wave_sum(cnt);
+                const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
+                if (adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT) {
+                    ns = (uint32_t)bbin | ((uint32_t)it << IRV_F_SHIFT) | ((uint32_t)lp << IRV_LIST_SHIFT);
+                    break;
+                }
+            }
+            // leave the histograms empty: only the rows of iterations that occurred were written (1-2 of 5 for most votes)
+#pragma clang loop unroll(disable)
+            for (int it = 0; it < IRV_LEVELS; it++)
+                if ((present >> it) & 1u) // (uniform)
+                    for (int b = lane; b < D; b += 64) hist[it * D + b] = 0;
+            IRV_T(7);
+            if (lane == 0 && ns != cur) { // bin and iteration in ONE store; both matter to the votes that see this pixel
+                st16[(uint32_t)(y * SP + x)] = (uint16_t)ns;
+                chg_wr[(uint32_t)((y / IRV_TILE) * tpitch + x / IRV_TILE)] = (uint8_t)stamp;
+                *acc = 1;
             }
         }
     }
@@ -480,27 +500,33 @@ static int irv_wpb(int D)
     static const int wmax = [] { const char* e = getenv("ADC_IRV_WPB"); const int v = e ? atoi(e) : IRV_MAXW; return v >= 1 && v <= IRV_MAXW ? v : IRV_MAXW; }();
     int w = 1;
     while (2 * w <= wmax) w *= 2;
-    while (w > 1 && (size_t)w * D * 4 + (size_t)w * 64 * 16 > 60 * 1024) w >>= 1;
+    while (w > 1 && (size_t)w * IRV_LEVELS * D * 4 + (size_t)w * 64 * 16 > 60 * 1024) w >>= 1;
     return w;
 }
-size_t adc_irv_waves(int grid) { return (size_t)IRV_MAXW * grid; } // (upper bound over all block shapes)
-// entries the work list must hold: whole batches of 64 entries per wave of the chain's grid (irv_list_slot)
-size_t adc_irv_list_entries(size_t pixels, int D, int grid)
+size_t adc_irv_waves(int grid) { return (size_t)IRV_MAXW * grid + (size_t)grid; } // per-wave evaluation counters + per-workgroup segment lengths
+// entries the work list must hold: one segment of whole batches per workgroup of the chain's grid (irv_plan.h: irv_seg_cap)
+static int irv_xcd_mode()
 {
-    const size_t B = (size_t)64 * irv_wpb(D) * grid;
-    return ((pixels + B - 1) / B) * B;
+    static const int v = [] { const char* e = getenv("ADC_IRV_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+size_t adc_irv_list_entries(int W, int H, int D, int grid)
+{
+    return (size_t)grid * (size_t)adc_imax((int)irv_seg_cap(W, H, grid, irv_wpb(D), 0), (int)irv_seg_cap(W, H, grid, irv_wpb(D), 1));
 }
 static hipError_t irv_launch(adc_handle* h, int k0, int count)
 {
     const AdcParams& p = h->p;
     const int tpitch = h->chg_pitch, chg_bytes = tpitch * ((p.H + IRV_TILE - 1) / IRV_TILE);
     const int wpb = irv_wpb(p.D);
-    const size_t lds = (size_t)((wpb * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
+    const size_t lds = (size_t)((wpb * IRV_LEVELS * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
     for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(k_irv_u, dim3((unsigned)h->irv_grid), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
                            h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
                            reinterpret_cast<const uint32_t*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
-                           p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr);
+                           p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr,
+                           (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, irv_xcd_mode()), irv_xcd_mode(), h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
+                           reinterpret_cast<unsigned long long*>(h->elig));
     return hipGetLastError();
 }
 
@@ -547,7 +573,7 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     h->vote_evals = st[6];
     if (*continued) h->irv_overflows++; // (the FINAL kernel of the continued chain has written the result into disp_l)
     // budget of the next Match: the kernels this one actually needed (st[7] = index of the first kernel that found
-    // nothing left to do) + 12 % + 4
+    // nothing left to do) + 25 % + 8
     const int used = st[7] + 1;
     static const int fixed = [] { const char* ev = getenv("ADC_IRV_BUDGET"); return ev ? atoi(ev) : 0; }();
     // (the longest chain of the last 8 Matches of the handle: the pairs of a stream differ -- at the KITTI size 3 of 23 distinct
@@ -556,6 +582,8 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     h->irv_used_hist[h->irv_used_pos++ & 7] = used;
     int longest = 0;
     for (int i = 0; i < 8; i++) longest = adc_imax(longest, h->irv_used_hist[i]);
-    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + longest / 8 + 4);
+    // (round 5: the chain of a natural 1080p image is 50-75 kernels instead of ~350 and varies more from pair to pair, relatively:
+    // a quarter of margin instead of an eighth -- 10 surplus kernels cost 0.05 ms, a continuation a synchronisation and the tail stages)
+    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + longest / 4 + 8);
     return hipSuccess;
 }

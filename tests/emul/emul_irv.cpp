@@ -1,8 +1,9 @@
 // CPU model of the device-driven region-voting chain (adcensus_amd/csrc/k_voting.hip): the SAME state machine
 // (irv_plan.h: every kernel derives its action from the state and the accumulators its predecessor left) and the SAME
-// work-list layout (irv_list_slot) drive plain-loop versions of the kernel's phases on the same 16-bit state map
-// (bin | final | eligible) and the two change-tile planes, with the waves of a round visited in a shuffled order against
-// the in-place map (arbitrary scheduling).  Test infrastructure.
+// work-list layout (per-workgroup segments of tiles, sorted by row inside the band: irv_seg_cap / irv_wg_tiles) drive plain-loop versions of the kernel's phases on the same 16-bit state map
+// (bin | iteration of the fill | list: ONE fixed-point iteration over all ten passes of the reference, irv_plan.h) and the two
+// change-tile planes, with the waves of a round visited in a shuffled order against the in-place map (arbitrary scheduling).
+// The vote itself is written per pixel here (the kernel decodes packed halfwords: emul_irv_swar_check).  Test infrastructure.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,25 +16,29 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
 {
     const int P = W * H, SP = (W + 7) & ~7, T = IRV_TILE;
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
-    const int G = groups > 0 ? groups : 2, WPB = wpb > 0 ? wpb : 4, NW = G * WPB; // the (emulated) grid: decides the list layout (irv_list_slot)
-    const long B = 64L * NW, cap = ((P + B - 1) / B) * B;
-    struct Ent { int p, arms, mlmr, y; };
+    const int G = groups > 0 ? groups : 2, WPB = wpb > 0 ? wpb : 4; // the (emulated) grid: decides the list layout
+    const int XCD = 1; // (the kernel's default; a grid that is not a multiple of 8 falls back to round-robin inside the helpers)
+    const long cap = irv_seg_cap(W, H, G, WPB, XCD), BT = 64L * WPB;
+    struct Ent { int p, arms, box, y; };
     std::vector<uint16_t> st((size_t)SP * H + 64, 0xFFFF);
-    std::vector<int32_t> ctrl(IRV_CTRL_INTS, 0), hist(D);
+    std::vector<int32_t> ctrl(IRV_CTRL_INTS, 0), hist((size_t)IRV_LEVELS * D);
     std::vector<int32_t> chg(2 * (size_t)tiles_x * tiles_y, 0); // two planes (round parity)
-    std::vector<Ent> list(cap, Ent{0, 0, 0, 0});
-    std::vector<uint8_t> bb((size_t)P * 3);
+    std::vector<Ent> list((size_t)cap * G, Ent{IRV_LIST_END, 0, 0, 0});
+    std::vector<int> wg_n(G, 0);
+    std::vector<uint8_t> listed_bit(P, 0);
+    std::vector<float> work(P);
+    std::vector<uint8_t> bb((size_t)P * 2);
     for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
+        for (int x = 0; x < W; x++) { // widest H arms over all region rows (k_irv_bbox)
             const uint8_t* a = arms + ((size_t)y * W + x) * 4;
             int ml = 0, mr = 0;
-            for (int t = -(int)a[2]; t <= 0; t++) {
+            for (int t = -(int)a[2]; t <= (int)a[3]; t++) {
                 const uint8_t* q = arms + ((size_t)(y + t) * W + x) * 4;
                 ml = std::max(ml, (int)q[0]);
                 mr = std::max(mr, (int)q[1]);
             }
-            uint8_t* o = &bb[((size_t)y * W + x) * 3];
-            o[0] = a[2]; o[1] = (uint8_t)ml; o[2] = (uint8_t)mr;
+            bb[((size_t)y * W + x) * 2] = (uint8_t)ml;
+            bb[((size_t)y * W + x) * 2 + 1] = (uint8_t)mr;
         }
     srand(seed);
     long kernels = 0, total_evals = 0;
@@ -44,94 +49,128 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
         int32_t* acc = &ctrl[IRV_ACC + (k & 63)];
         kernels++;
         if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
-            const bool have_state = !(pl.act == IRV_BEGIN && pl.s.pass == 0);
-            const int which = (pl.s.pass & 1) ? ADC_LABEL_OCCLUSION : ADC_LABEL_MISMATCH;
             if (pl.act == IRV_BEGIN) std::fill(chg.begin(), chg.end(), 0);
-            // the blocks of the kernel claim list ranges with an atomic in arbitrary order: model it by visiting the
-            // chunks of pixels (one per workgroup iteration) in a shuffled order
-            const int CH = 1024 * IRV_PPT;
-            std::vector<int> chunks((P + CH - 1) / CH);
-            for (size_t c = 0; c < chunks.size(); c++) chunks[c] = (int)c;
-            for (size_t c = chunks.size(); c > 1; c--) std::swap(chunks[c - 1], chunks[rand() % c]);
-            for (int c : chunks)
-                for (int p = c * CH; p < std::min(P, (c + 1) * CH); p++) {
-                    const int y = p / W, x = p - y * W;
-                    const size_t i16 = (size_t)y * SP + x;
-                    float dv = disp[p];
-                    if (have_state) {
-                        const uint32_t s = st[i16];
-                        if ((s & IRV_ELIG) && (s & IRV_BIN_MASK) != IRV_BIN_MASK) { dv = (float)((int)(s & IRV_BIN_MASK) + dmin); disp[p] = dv; }
-                    }
-                    if (pl.act == IRV_BEGIN) {
-                        const bool e = label[p] == which && dv == ADC_INVALID_FLOAT;
-                        const bool listed = e && (int)sup_h[p] > min_region;
-                        uint32_t bin = IRV_BIN_MASK;
-                        if (dv != ADC_INVALID_FLOAT) { const long b = lroundf(dv) - dmin; if (b >= 0 && b < D) bin = (uint32_t)b; }
-                        st[i16] = (uint16_t)(bin | (e ? IRV_ELIG : 0u) | (listed ? 0u : IRV_FINAL));
-                        if (listed) {
-                            const uint8_t* o = &bb[(size_t)p * 3];
+            for (int p = 0; p < P; p++) { // one pass over the image (any order)
+                const int y = p / W, x = p - y * W;
+                const size_t i16 = (size_t)y * SP + x;
+                if (pl.act == IRV_FINAL_WB) {
+                    float dv = work[p];
+                    const uint32_t s = st[i16];
+                    if ((s >> IRV_LIST_SHIFT) != 0u && (s & IRV_BIN_MASK) != IRV_BIN_MASK) dv = (float)((int)(s & IRV_BIN_MASK) + dmin);
+                    disp[p] = dv;
+                } else {
+                    const float dv = disp[p];
+                    work[p] = dv;
+                    const uint32_t lab = label[p];
+                    const bool e = (lab == ADC_LABEL_MISMATCH || lab == ADC_LABEL_OCCLUSION) && dv == ADC_INVALID_FLOAT;
+                    listed_bit[p] = e && (int)sup_h[p] > min_region;
+                    uint32_t bin = IRV_BIN_MASK;
+                    if (dv != ADC_INVALID_FLOAT) { const long b = lroundf(dv) - dmin; if (b >= 0 && b < D) bin = (uint32_t)b; }
+                    st[i16] = (uint16_t)(bin | (e ? lab << IRV_LIST_SHIFT : 0u));
+                }
+            }
+        } else if (pl.act == IRV_BEGIN2) {
+            // every workgroup walks its own tiles row by row (irv_plan.h); workgroups in a shuffled order
+            std::vector<int> wgs(G);
+            for (int g = 0; g < G; g++) wgs[g] = g;
+            for (int g = G; g > 1; g--) std::swap(wgs[g - 1], wgs[rand() % g]);
+            for (int g : wgs) {
+                int ng = 0;
+                const int my_tiles = irv_wg_tiles(W, H, G, g, XCD);
+                for (int j = 0; j < IRV_BAND; j++)
+                    for (int kk = 0; kk < my_tiles; kk++)
+                        for (int xi = 0; xi < IRV_TCOLS; xi++) {
+                            int band, tx;
+                            irv_wg_tile(W, H, G, g, kk, XCD, &band, &tx);
+                            const int y = band * IRV_BAND + j, x = tx * IRV_TCOLS + xi;
+                            if (y >= H || x >= W) continue;
+                            const int p = y * W + x;
+                            if (!listed_bit[p]) continue;
                             const uint8_t* a = arms + (size_t)p * 4;
                             const int arms32 = (int)((uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)a[2] << 16) | ((uint32_t)a[3] << 24));
-                            list[irv_list_slot((*acc)++, G, WPB)] = Ent{p, arms32, (int)o[1] | ((int)o[2] << 8), y};
+                            list[(size_t)g * cap + ng++] = Ent{p, arms32, (int)(((uint32_t)bb[(size_t)p * 2] << 16) | ((uint32_t)bb[(size_t)p * 2 + 1] << 24)), y};
                         }
-                    }
-                }
+                if (ng > cap) return -3; // (cannot happen: a segment holds every pixel of the workgroup's tiles)
+                for (long t = ng; t < ((ng + BT - 1) / BT) * BT && t < cap; t++) list[(size_t)g * cap + t].p = IRV_LIST_END;
+                wg_n[g] = ng;
+                *acc += ng;
+            }
         } else if (pl.act == IRV_ROUND) {
-            // every wave: phase 1 (one entry per lane: open and dirty?), phase 2 (evaluate the dirty ones); waves in a
-            // shuffled order against the in-place map (arbitrary scheduling)
-            const int round = pl.s.round, n = pl.s.n;
+            // every wave: phase 1 (one entry per lane: dirty?), phase 2 (evaluate the dirty ones); waves in a shuffled order
+            // against the in-place map (arbitrary scheduling)
+            const int round = pl.s.round;
             const int32_t want = ((k + 254) % 255) + 1, stamp = (k % 255) + 1; // stamps and planes go by KERNEL index
             const int32_t* chg_rd = chg.data() + (size_t)((k + 1) & 1) * tiles_x * tiles_y;
             int32_t* chg_wr = chg.data() + (size_t)(k & 1) * tiles_x * tiles_y;
-            std::vector<int> waves(NW);
-            for (int w = 0; w < NW; w++) waves[w] = w;
-            for (int w = NW; w > 1; w--) std::swap(waves[w - 1], waves[rand() % w]);
-            for (long b0 = 0; b0 < n; b0 += B)
-                for (int gw : waves) {
-                    int todo[64], nt = 0;
-                    for (int lane = 0; lane < 64; lane++) {
-                        const long i = irv_list_index(b0, gw / WPB, gw % WPB, lane, G);
-                        if (i >= n) continue;
-                        const Ent& e = list[b0 + (size_t)gw * 64 + lane];
+            // workgroups in a shuffled order; a workgroup takes its segment batch by batch, pools the dirty entries of the batch
+            // in list order and its WPB waves take consecutive pool items: groups of WPB items, each group in a shuffled order
+            std::vector<int> wgs(G);
+            for (int g = 0; g < G; g++) wgs[g] = g;
+            for (int g = G; g > 1; g--) std::swap(wgs[g - 1], wgs[rand() % g]);
+            for (int g : wgs)
+                for (long b0 = 0; b0 < wg_n[g]; b0 += BT) {
+                    std::vector<int> todo;
+                    std::vector<uint16_t> seen;
+                    for (long i = b0; i < std::min((long)wg_n[g], b0 + BT); i++) {
+                        const Ent& e = list[(size_t)g * cap + i];
                         const int p = e.p, y = e.y, x = p - y * W;
-                        if (st[(size_t)y * SP + x] & IRV_FINAL) continue;
                         bool dirty = round == 0;
                         if (!dirty) {
-                            const int top = (e.arms >> 16) & 255, ml = e.mlmr & 255, mr = (e.mlmr >> 8) & 255;
+                            const int top = (e.arms >> 16) & 255, bot = (e.arms >> 24) & 255, ml = (e.box >> 16) & 255, mr = (e.box >> 24) & 255;
                             const int tx0 = std::max(0, x - ml) / T, tx1 = std::min(W - 1, x + mr) / T;
-                            const int ty0 = std::max(0, y - top) / T, ty1 = y / T;
+                            const int ty0 = std::max(0, y - top) / T, ty1 = std::min(H - 1, y + bot) / T;
                             for (int ty = ty0; ty <= ty1; ty++)
                                 for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want; // byte stamps (k_voting.hip)
                         }
-                        if (dirty) todo[nt++] = lane;
+                        if (dirty) { todo.push_back((int)i); seen.push_back(st[(size_t)y * SP + x]); } // (phase 1 reads the entry's own state)
                     }
-                    total_evals += nt;
-                    for (int t = 0; t < nt; t++) {
-                        const Ent& e = list[b0 + (size_t)gw * 64 + todo[t]];
-                        const int p = e.p, y = e.y, x = p - y * W;
-                        std::fill(hist.begin(), hist.end(), 0);
-                        bool deps_open = false;
-                        const uint8_t* arm = arms + (size_t)p * 4;
-                        for (int dy = -(int)arm[2]; dy <= (int)arm[3]; dy++) {
-                            const int yt = y + dy;
-                            const uint8_t* a2 = arms + ((size_t)yt * W + x) * 4;
-                            for (int px = x - (int)a2[0]; px <= x + (int)a2[1]; px++) {
-                                const uint32_t s = st[(size_t)yt * SP + px];
-                                const bool el = (s & IRV_ELIG) != 0, pre = yt < y || (yt == y && px < x);
-                                const uint32_t bin = s & IRV_BIN_MASK;
-                                if (bin != IRV_BIN_MASK && (!el || pre)) hist[bin]++;
-                                if (el && pre && !(s & IRV_FINAL)) deps_open = true;
+                    total_evals += (long)todo.size();
+                    for (size_t c0 = 0; c0 < todo.size(); c0 += WPB) {
+                        std::vector<size_t> grp;
+                        for (size_t c = c0; c < std::min(todo.size(), c0 + WPB); c++) grp.push_back(c);
+                        for (size_t c = grp.size(); c > 1; c--) std::swap(grp[c - 1], grp[rand() % c]);
+                        for (size_t t : grp) {
+                            const Ent& e = list[(size_t)g * cap + todo[t]];
+                            const int p = e.p, y = e.y, x = p - y * W;
+                            const uint32_t cur = seen[t];
+                            const int lp = (int)(cur >> IRV_LIST_SHIFT);
+                            std::fill(hist.begin(), hist.end(), 0);
+                            const uint8_t* arm = arms + (size_t)p * 4;
+                            for (int dy = -(int)arm[2]; dy <= (int)arm[3]; dy++) {
+                                const int yt = y + dy;
+                                const uint8_t* a2 = arms + ((size_t)yt * W + x) * 4;
+                                for (int px = x - (int)a2[0]; px <= x + (int)a2[1]; px++) {
+                                    if (yt == y && px == x) continue; // a pixel does not vote for itself
+                                    const uint32_t s = st[(size_t)yt * SP + px];
+                                    const uint32_t bin = s & IRV_BIN_MASK;
+                                    if (bin == IRV_BIN_MASK) continue;
+                                    const int lq = (int)(s >> IRV_LIST_SHIFT), fq = (int)((s >> IRV_F_SHIFT) & 7u);
+                                    const bool pre = yt < y || (yt == y && px < x);
+                                    int tq; // the iteration from which q counts (irv_plan.h, top)
+                                    if (lq == 0) tq = fq;
+                                    else if (lq == lp) tq = pre ? fq : fq + 1;
+                                    else tq = lp == 1 ? fq + 1 : fq;
+                                    if (tq < IRV_LEVELS) hist[(size_t)tq * D + bin]++;
+                                }
+                            }
+                            uint32_t ns = IRV_BIN_MASK | ((uint32_t)lp << IRV_LIST_SHIFT);
+                            for (int it = 0; it < IRV_LEVELS; it++) {
+                                if (it) for (int b = 0; b < D; b++) hist[(size_t)it * D + b] += hist[(size_t)(it - 1) * D + b];
+                                // the kernel's key: count << 11 | (2047 - bin), maximum = highest count, lowest bin on ties
+                                int key = 0, cnt = 0;
+                                for (int b = 0; b < D; b++) { const int hv = hist[(size_t)it * D + b]; cnt += hv; if (hv > 0) key = std::max(key, (hv << 11) | (0x7FF - b)); }
+                                const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
+                                if (adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT) {
+                                    ns = (uint32_t)bbin | ((uint32_t)it << IRV_F_SHIFT) | ((uint32_t)lp << IRV_LIST_SHIFT);
+                                    break;
+                                }
+                            }
+                            if (ns != cur) {
+                                st[(size_t)y * SP + x] = (uint16_t)ns;
+                                chg_wr[(y / T) * tiles_x + x / T] = stamp;
+                                *acc = 1;
                             }
                         }
-                        // the kernel's key: count << 11 | (2047 - bin), maximum = highest count, lowest bin on ties
-                        int key = 0, cnt = 0;
-                        for (int b = 0; b < D; b++) { cnt += hist[b]; if (hist[b] > 0) key = std::max(key, (hist[b] << 11) | (0x7FF - b)); }
-                        const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
-                        const bool fill = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-                        const size_t i16 = (size_t)y * SP + x;
-                        const uint32_t cur = st[i16], nb = fill ? (uint32_t)bbin : IRV_BIN_MASK;
-                        st[i16] = (uint16_t)(nb | IRV_ELIG | (deps_open ? 0u : IRV_FINAL));
-                        if (nb != (cur & IRV_BIN_MASK)) { chg_wr[(y / T) * tiles_x + x / T] = stamp; *acc = 1; }
                     }
                 }
         }
@@ -145,8 +184,8 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The packed-halfword helpers of irv_plan.h against per-pixel loops on random inputs (values drawn so that equal bins,
-// invalid bins, eligible / final flags and range edges all occur often).  Returns the number of disagreements.
+// The packed-halfword helpers of irv_plan.h against per-pixel loops on random inputs (values drawn so that equal keys,
+// invalid bins, both lists, late fills and range edges all occur often).  Returns the number of disagreements.
 extern "C" long emul_irv_swar_check(unsigned seed, long trials)
 {
     srand(seed);
@@ -154,52 +193,56 @@ extern "C" long emul_irv_swar_check(unsigned seed, long trials)
     for (long t = 0; t < trials; t++) {
         // ---- region row block
         uint16_t s16[8];
-        const int nb = 1 + rand() % 4;                   // few distinct bins -> "single bin" happens
+        const int nb = 1 + rand() % 4;                   // few distinct bins -> "single key" happens
         const int pool[4] = {rand() % 2047, rand() % 2047, IRV_BIN_MASK, rand() % 2047};
         for (int q = 0; q < 8; q++) {
             uint32_t v = (uint32_t)pool[rand() % nb];
-            if (rand() % 3 == 0) v |= IRV_ELIG;
-            if (rand() % 2 == 0) v |= IRV_FINAL;
-            if (rand() % 4 == 0) v |= 0x3800u;           // bits 11..13 are unused: must not matter
+            const int lq = rand() % 3;                    // not listed / mismatch / occlusion
+            v |= (uint32_t)lq << IRV_LIST_SHIFT;
+            if (lq != 0 && (v & IRV_BIN_MASK) != IRV_BIN_MASK) v |= (uint32_t)(rand() % IRV_LEVELS) << IRV_F_SHIFT; // filled in iteration 0..4
             s16[q] = (uint16_t)v;
         }
         uint32_t w[4];
         for (int j = 0; j < 4; j++) w[j] = (uint32_t)s16[2 * j] | ((uint32_t)s16[2 * j + 1] << 16);
-        const int px0 = 8 * (rand() % 50), y = 5 + rand() % 5, yt = y - 2 + rand() % 5, x = px0 - 6 + rand() % 20;
+        const int px0 = 8 * (rand() % 50), y = 5 + rand() % 5, yt = y - 2 + rand() % 5, x = px0 - 6 + rand() % 20, lp = 1 + rand() % 2;
         int xl = px0 - 4 + rand() % 12, xr = xl + rand() % 14;
         if (xr < px0) xr = px0;                           // (the kernel only decodes blocks that intersect [xl, xr])
         if (xl > px0 + 7) xl = px0 + 7;
         if (xr < xl) xr = xl;
-        const IrvBlock got = irv_decode_block(w[0], w[1], w[2], w[3], px0, xl, xr, yt, y, x);
-        uint32_t okm = 0, first = 0;
-        bool single = true, open = false, have = false;
+        const IrvBlock got = irv_decode_block(w[0], w[1], w[2], w[3], px0, xl, xr, yt, y, x, lp);
+        uint32_t okm = 0;
+        uint32_t keys[8];
         for (int q = 0; q < 8; q++) {
             const int px = px0 + q;
             const uint32_t sv = s16[q], bin = sv & IRV_BIN_MASK;
-            const bool in = px >= xl && px <= xr, el = (sv & IRV_ELIG) != 0, pre = yt < y || (yt == y && px < x);
-            if (in && bin != IRV_BIN_MASK && (!el || pre)) {
-                okm |= 1u << q;
-                if (!have) { first = bin; have = true; }
-                single = single && bin == first;
-            }
-            if (in && el && pre && !(sv & IRV_FINAL)) open = true;
+            const int lq = (int)(sv >> IRV_LIST_SHIFT), fq = (int)((sv >> IRV_F_SHIFT) & 7u);
+            const bool in = px >= xl && px <= xr, pre = yt < y || (yt == y && px < x), self = yt == y && px == x;
+            int tq;
+            if (lq == 0) tq = fq;
+            else if (lq == lp) tq = pre ? fq : fq + 1;
+            else tq = lp == 1 ? fq + 1 : fq;
+            keys[q] = ((uint32_t)tq << IRV_F_SHIFT) | bin;
+            if (in && !self && bin != IRV_BIN_MASK && tq < IRV_LEVELS) okm |= 1u << q;
         }
-        if (got.okm != okm || got.open != open) bad++;
-        else if (okm && (got.first != first || got.single != single)) bad++;
-        else if (okm) { // the pixels of the first bin, and -- on what is left -- the pixels that share the bin of the lowest one
-            uint32_t same = 0;
+        if (got.okm != okm) bad++;
+        else if (okm) { // the pixels of the first key, and -- on what is left -- the pixels that share the key of the lowest one
+            const uint32_t gk[4] = {got.k0, got.k1, got.k2, got.k3};
+            bool keys_ok = true;
             for (int q = 0; q < 8; q++)
-                if (((okm >> q) & 1u) && (s16[q] & IRV_BIN_MASK) == first) same |= 1u << q;
-            if (got.same != same) bad++;
-            uint32_t rem = okm & ~same;
+                if (((okm >> q) & 1u) && ((gk[q >> 1] >> (16 * (q & 1))) & IRV_KEY_MASK) != keys[q]) keys_ok = false;
+            if (!keys_ok) { bad++; continue; }
+            uint32_t rem = okm;
+            bool first = true;
             while (rem) {
-                uint32_t bin = 0xFFFFu, want_mask = 0;
-                const uint32_t got_mask = irv_same_bin_mask(w[0], w[1], w[2], w[3], rem, &bin);
-                const uint32_t b = s16[__builtin_ctz(rem)] & IRV_BIN_MASK;
+                uint32_t key = 0xFFFFu, want_mask = 0;
+                const uint32_t got_mask = first ? got.same : irv_same_key_mask(got.k0, got.k1, got.k2, got.k3, rem, &key);
+                if (first) key = got.first;
+                const uint32_t kq = keys[__builtin_ctz(rem)];
                 for (int q = 0; q < 8; q++)
-                    if (((rem >> q) & 1u) && (s16[q] & IRV_BIN_MASK) == b) want_mask |= 1u << q;
-                if (bin != b || got_mask != want_mask || !got_mask) { bad++; break; }
+                    if (((rem >> q) & 1u) && keys[q] == kq) want_mask |= 1u << q;
+                if (key != kq || got_mask != want_mask || !got_mask) { bad++; break; }
                 rem &= ~got_mask;
+                first = false;
             }
         }
         // ---- change-tile row
@@ -217,5 +260,35 @@ extern "C" long emul_irv_swar_check(unsigned seed, long trials)
         for (int tx = txb; tx <= last; tx++) want = want || tb[tx - cb] == stamp;
         if ((hit != 0) != want) bad++;
     }
+    return bad;
+}
+
+// The tiles of all workgroups partition the image, and a workgroup's tiles fit its segment (irv_plan.h: irv_wg_tiles / irv_wg_tile /
+// irv_seg_cap).  Returns the number of violations.
+extern "C" long emul_irv_tile_partition(int W, int H, int G, int WPB, int XCD)
+{
+    std::vector<int> owner((size_t)W * H, -1);
+    long bad = 0;
+    const long cap = irv_seg_cap(W, H, G, WPB, XCD);
+    for (int g = 0; g < G; g++) {
+        const int nt = irv_wg_tiles(W, H, G, g, XCD);
+        long pixels = 0;
+        for (int k = 0; k < nt; k++) {
+            int band, tx;
+            irv_wg_tile(W, H, G, g, k, XCD, &band, &tx);
+            if (band < 0 || band >= irv_bands(H) || tx < 0 || tx >= irv_tiles_x(W)) { bad++; continue; }
+            if (XCD && G % 8 == 0 && band % 8 != g % 8) bad++; // a band belongs to ONE XCD
+            for (int j = 0; j < IRV_BAND; j++)
+                for (int xi = 0; xi < IRV_TCOLS; xi++) {
+                    const int y = band * IRV_BAND + j, x = tx * IRV_TCOLS + xi;
+                    if (y >= H || x >= W) continue;
+                    if (owner[(size_t)y * W + x] != -1) bad++;
+                    owner[(size_t)y * W + x] = g;
+                    pixels++;
+                }
+        }
+        if (pixels > cap) bad++;
+    }
+    for (int v : owner) bad += v < 0;
     return bad;
 }

@@ -401,7 +401,8 @@ def test_refiner_parallel_forms(emul, dumps, name):
     # the device-driven chain (k_voting.hip): state machine of irv_plan.h on the 16-bit state map, shuffled vote order
     emul.emul_irv_chain.restype = C.c_long
     # (the grid decides the work-list layout; 2 x 4 and 5 x 1 waves = batches of 512 / 320 entries: lists span several batches)
-    for seed, groups, wpb in ((3, 2, 4), (77, 5, 1)):
+    # 16 x 1: a multiple of 8 workgroups -> whole bands belong to one "XCD" (irv_wg_tile)
+    for seed, groups, wpb in ((3, 2, 4), (77, 5, 1), (9, 16, 1)):
         d = o["disp_after_lr"].copy()
         stats = (C.c_long * 3)()
         L = max(0, min(opt.cross_L1, 255))
@@ -528,6 +529,16 @@ def test_interpolation_skipping_is_exact(emul, seed, density, ns):
         assert same(got, want)
         if density <= 0.003:
             assert n < 0.6 * plain.value, (n, plain.value)   # the sparse band is crossed in jumps
+
+
+def test_voting_tiles_partition_the_image(emul):
+    """irv_plan.h: the tiles of the voting chain's workgroups (bands of 16 rows, a band belongs to one XCD) cover every pixel
+    exactly once and fit the workgroup's list segment -- for the grids the launcher uses and odd shapes."""
+    emul.emul_irv_tile_partition.restype = C.c_long
+    for w, h in ((1920, 1080), (1242, 375), (450, 375), (1, 1), (1, 40), (33, 17), (7, 129), (640, 16)):
+        for g, wpb in ((64, 16), (128, 16), (512, 16), (512, 1), (5, 1), (2, 4), (24, 8)):
+            for xcd in (0, 1):
+                assert emul.emul_irv_tile_partition(w, h, g, wpb, xcd) == 0, (w, h, g, wpb, xcd)
 
 
 def test_voting_packed_halfword_helpers(emul):

@@ -1,7 +1,7 @@
 """GPU tier at BASELINE.json's FULL size (1920x1080, D=128): the whole Match against the reference CPU program
 (~20 s of host time per pair), repeatability, and the equality of the aggregation paths (plain 8 passes vs fused
 cost + pass pairs) through the stage-level debug surface.  Exercises what the small cases cannot: many segments per
-line, all 17 median bands, hundreds of voting rounds, multi-round grids."""
+line, all 17 median bands, a long voting chain, multi-round grids."""
 import numpy as np
 import pytest
 
@@ -118,4 +118,6 @@ def test_full_size_stage_isolation_structured(hip, oracle):
     rep = gpu_harness.stage_report(left, right, opt, o)
     bad = gpu_harness.failing(rep)
     assert not bad, "structured 1080p (oracle=%s): %s" % (oracle.kind, bad)
-    assert rep["disp_after_irv"]["voting_rounds_evals"][0] > 100  # the chain really ran its hundreds of rounds
+    # the chain really ran a long fixed-point iteration (round 5: all ten passes iterate at once -- ~80 rounds where the
+    # pass-after-pass chain of rounds 1-4 took ~255), and every entry was evaluated at least once
+    assert rep["disp_after_irv"]["voting_rounds_evals"][0] > 30 and rep["disp_after_irv"]["voting_rounds_evals"][1] > 100000
