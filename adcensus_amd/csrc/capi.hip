@@ -87,7 +87,13 @@ int adc_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-const char* adc_version(void) { return "adcensus-mi355x 0.1 (gfx950)"; }
+// (a library whose asm-prefetch / register-ring kernels were NOT re-verified on the generated code -- build() with
+// ADC_BUILD_SKIP_CODEGEN_CHECK=1 -- says so: the hand-counted s_waitcnt values are only proven for a checked build)
+#ifdef ADC_CODEGEN_UNCHECKED
+const char* adc_version(void) { return "adcensus-mi355x 0.2 (gfx950) [generated-code checks SKIPPED]"; }
+#else
+const char* adc_version(void) { return "adcensus-mi355x 0.2 (gfx950)"; }
+#endif
 const char* adc_last_error(void) { return g_last_error.c_str(); }
 
 static hipError_t alloc_all(adc_handle* h)

@@ -321,7 +321,7 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
             acc2_ = agg_sum<SMALL, V>(vzero, ring2 + i2_ * 64, k1_);                              \
             if (k_ > k1_) acc2_ = agg_sum<SMALL, V>(acc2_, ring2, k_ - k1_);                      \
         }                                                                                         \
-        *reinterpret_cast<V*>(dpn) = acc2_;                                                       \
+        ADC_VOL_STORE(reinterpret_cast<V*>(dpn), acc2_);                                          \
         dpn += fstep;                                                                             \
         slot2_s = slot2_s + 1 == R ? 0 : slot2_s + 1;                                             \
     } while (0)
@@ -336,7 +336,7 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
             mcur++;                                                                               \
             if (s_ >= s0 && s_ < s1) AGG_EMIT2();                                                 \
         } else {                                                                                  \
-            *reinterpret_cast<V*>(dpn) = (ACC);                                                   \
+            ADC_VOL_STORE(reinterpret_cast<V*>(dpn), (ACC));                                      \
             dpn += fstep;                                                                         \
         }                                                                                         \
     } while (0)
@@ -501,8 +501,8 @@ __device__ __forceinline__ void agg_march_body(const float* __restrict__ src, fl
 // data load of one entry (VPL floats per lane) into a prefetch slot
 #define AGG_LDV(DST, PTR)                                                                                         \
     do {                                                                                                          \
-        if constexpr (VPL == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory");  \
-        else asm volatile("global_load_dword %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory");                     \
+        if constexpr (VPL == 2) asm volatile("global_load_dwordx2 %0, %1, off" ADC_VOL_NT_STR : "=v"(DST) : "v"(PTR) : "memory");  \
+        else asm volatile("global_load_dword %0, %1, off" ADC_VOL_NT_STR : "=v"(DST) : "v"(PTR) : "memory");                     \
     } while (0)
     // The asm-prefetch loop needs every refill index valid without clamping: j + 2*AGG_PF <= hi.
     if (j + 2 * AGG_PF <= hi) {

@@ -28,6 +28,20 @@
 // with a device form (inline asm) and an emulation form (a modelled VGPR file, with the same M0-relative addressing).
 #pragma once
 
+#ifndef ADC_VOL_NT_STR // (adc_internal.h defines the same; this header is also compiled for the CPU, without it)
+// Streaming hint for the volume accesses (every element is read once and written once per pass; 1 GB >> every cache):
+// the loads / stores of the marching kernels (K4, K5, K6) are marked non-temporal: same-box A/B at 1080p, K4 launch 0.394 -> 0.376 ms
+// (0.462 -> 0.445 in the slower clock state of the same box), scanline stage -1 %, right-view WTA -4 % (profiles/r5_ab_nontemporal.txt);
+// -DADC_VOL_NT=0 switches it off (tools/build_variant.sh).
+#if !defined(ADC_VOL_NT) || ADC_VOL_NT
+#define ADC_VOL_NT_STR " nt"
+#define ADC_VOL_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define ADC_VOL_NT_STR ""
+#define ADC_VOL_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
+#endif
+
 #define RR_BLK 35
 #define RR_PF 8
 

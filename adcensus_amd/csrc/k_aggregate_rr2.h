@@ -39,7 +39,7 @@ struct AggCostIn {
 typedef float rr2_f2 __attribute__((ext_vector_type(2)));
 RR_FN rr2_f2 rr2_make(float a, float b) { rr2_f2 r; r.x = a; r.y = b; return r; }
 #define RR2_LDS_TABLES extern __shared__ __attribute__((aligned(16))) float rr2_lds[]
-#define RR2_VLOAD(DST, PTR) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(DST) : "v"(PTR) : "memory")
+#define RR2_VLOAD(DST, PTR) asm volatile("global_load_dwordx2 %0, %1, off" ADC_VOL_NT_STR : "=v"(DST) : "v"(PTR) : "memory")
 #define RR2_WAIT_TAKE(DST, SRC, N) asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b64 %0, %1" : "=&v"(DST) : "v"(SRC), "n"(N) : "memory")
 #define RR2_DRAIN8(D, S)                                                                                             \
     asm volatile("s_waitcnt vmcnt(0)\n\t"                                                                            \
@@ -352,7 +352,7 @@ RR_FN void agg_rr2_piece(const float* __restrict__ src, float* __restrict__ dst,
             const float cf_ = (float)(r_ >> 16);                                                                     \
             acc_ = rr2_make(rr_divide(acc_.x, cf_, y_), rr_divide(acc_.y, cf_, y_)); /* cross_aggregator.cpp:389 */  \
         }                                                                                                            \
-        *reinterpret_cast<rr2_f2*>(dpn) = acc_;                                                                      \
+        ADC_VOL_STORE(reinterpret_cast<rr2_f2*>(dpn), acc_);                                                         \
         dpn += RR2_MSTEP_ST;                                                                                         \
     } while (0)
 

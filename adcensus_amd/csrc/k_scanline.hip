@@ -94,11 +94,14 @@ __device__ __forceinline__ void vload(const float* p, float* r)
 template <int VPL>
 __device__ __forceinline__ void vstore(float* p, const float* r)
 {
-    if constexpr (VPL == 1) p[0] = r[0];
-    else if constexpr (VPL == 2) *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]);
+    // (volume stores: streamed, ADC_VOL_STORE in adc_internal.h)
+    typedef float so_f2 __attribute__((ext_vector_type(2)));
+    typedef float so_f4 __attribute__((ext_vector_type(4)));
+    if constexpr (VPL == 1) ADC_VOL_STORE(p, r[0]);
+    else if constexpr (VPL == 2) { so_f2 v_ = {r[0], r[1]}; ADC_VOL_STORE(reinterpret_cast<so_f2*>(p), v_); }
     else {
 #pragma unroll
-        for (int q = 0; q < VPL; q += 4) *reinterpret_cast<float4*>(p + q) = make_float4(r[q], r[q + 1], r[q + 2], r[q + 3]);
+        for (int q = 0; q < VPL; q += 4) { so_f4 v_ = {r[q], r[q + 1], r[q + 2], r[q + 3]}; ADC_VOL_STORE(reinterpret_cast<so_f4*>(p + q), v_); }
     }
 }
 
@@ -508,18 +511,18 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         const int ro_ = so_rmap_offset_m<VPL, VERT>(g, mpf, cl_last);                                          \
         if constexpr (PIN) {                                                                                   \
             if constexpr (VPL == 1) {                                                                          \
-                asm volatile("global_load_dword v[%1], %0, off" ::"v"(spn), "n"(SO_RC(U)) : "memory");         \
+                asm volatile("global_load_dword v[%1], %0, off" ADC_VOL_NT_STR ::"v"(spn), "n"(SO_RC(U)) : "memory");         \
                 asm volatile("global_load_ubyte v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory"); \
             } else {                                                                                           \
-                asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
+                asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ADC_VOL_NT_STR ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
                 asm volatile("global_load_ushort v[%2], %0, %1" ::"v"(ro_), "s"(rmap), "n"(SO_RR(U)) : "memory"); \
             }                                                                                                  \
         } else {                                                                                               \
             if constexpr (VPL == 1) {                                                                          \
-                asm volatile("global_load_dword %0, %1, off" : "=v"(pfc[PIN ? 0 : (U)]) : "v"(spn) : "memory"); \
+                asm volatile("global_load_dword %0, %1, off" ADC_VOL_NT_STR : "=v"(pfc[PIN ? 0 : (U)]) : "v"(spn) : "memory"); \
                 asm volatile("global_load_ubyte %0, %1, %2" : "=v"(pfr[PIN ? 0 : (U)]) : "v"(ro_), "s"(rmap) : "memory"); \
             } else {                                                                                           \
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pfc[PIN ? 0 : (U)]) : "v"(spn) : "memory"); \
+                asm volatile("global_load_dwordx2 %0, %1, off" ADC_VOL_NT_STR : "=v"(pfc[PIN ? 0 : (U)]) : "v"(spn) : "memory"); \
                 asm volatile("global_load_ushort %0, %1, %2" : "=v"(pfr[PIN ? 0 : (U)]) : "v"(ro_), "s"(rmap) : "memory"); \
             }                                                                                                  \
         }                                                                                                      \
@@ -538,10 +541,10 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
 #define SO_ISSUE_DF(U)                                                                                         \
     do {                                                                                                       \
         if constexpr (VPL == 1) {                                                                              \
-            asm volatile("global_load_dword v[%1], %0, off" ::"v"(spn), "n"(SO_RC(U)) : "memory");               \
+            asm volatile("global_load_dword v[%1], %0, off" ADC_VOL_NT_STR ::"v"(spn), "n"(SO_RC(U)) : "memory");               \
             asm volatile("global_load_ubyte v[%2], %0, %1" ::"v"(rof), "s"(rmap), "n"(SO_RR(U)) : "memory");     \
         } else {                                                                                               \
-            asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
+            asm volatile("global_load_dwordx2 v[%1:%2], %0, off" ADC_VOL_NT_STR ::"v"(spn), "n"(SO_RC(U)), "n"(SO_RC(U) + 1) : "memory"); \
             asm volatile("global_load_ushort v[%2], %0, %1" ::"v"(rof), "s"(rmap), "n"(SO_RR(U)) : "memory");    \
         }                                                                                                      \
         spn += fstep;                                                                                          \

@@ -194,8 +194,8 @@ __global__ __launch_bounds__(64 * WTAM_WAVES) void k_wta_right_march(const float
     _Pragma("unroll") for (int j = 0; j < VPW; j++) {                                                                 \
         const int c = un.x0 + dmin + (s) * 64 + wave * VPW + j;                                                       \
         const float* vp = row + (size_t)(c < 0 ? 0 : (c >= W ? W - 1 : c)) * Dp;                                      \
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(buf[j][0]) : "v"(lane4), "s"(vp) : "memory");              \
-        if constexpr (VPL == 2) asm volatile("global_load_dword %0, %1, %2 offset:256" : "=v"(buf[j][1]) : "v"(lane4), "s"(vp) : "memory"); \
+        asm volatile("global_load_dword %0, %1, %2" ADC_VOL_NT_STR : "=v"(buf[j][0]) : "v"(lane4), "s"(vp) : "memory");              \
+        if constexpr (VPL == 2) asm volatile("global_load_dword %0, %1, %2 offset:256" ADC_VOL_NT_STR : "=v"(buf[j][1]) : "v"(lane4), "s"(vp) : "memory"); \
     }
 #define WTAM_TAKE(buf)                                                                                                \
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WTAM_DEPTH - 1) * VPW * VPL) : "memory");                               \
