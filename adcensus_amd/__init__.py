@@ -369,6 +369,12 @@ class ADCensusStereo:
         if rc != 0:
             raise RuntimeError("adc_debug_run(%d) failed: %s" % (stage, last_error()))
 
+    def debug_set_budget(self, kernels):
+        """Test hook: the launch budget of the NEXT Match's voting chain (adc_debug_run ADC_RUN_REGION_VOTING with arg < 0)."""
+        rc = lib().adc_debug_run(self._h, RUN_REGION_VOTING, -int(kernels))
+        if rc != 0:
+            raise RuntimeError("adc_debug_run failed: " + last_error())
+
     def debug_counter(self, which):
         return int(lib().adc_debug_counter(self._h, which))
 

@@ -943,6 +943,7 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     case ADC_RUN_WTA: e = adc_launch_wta(h); break;
     case ADC_RUN_LRCHECK: e = adc_launch_lrcheck(h); break;
     case ADC_RUN_REGION_VOTING: // arg > 0: launch budget (kernels) of this run, e.g. 4 to force the continuation path
+        if (arg < 0) { h->irv_budget = -arg; return 0; } // test hook: only set the budget of the NEXT Match's chain (continuation inside adc_wait)
         if (arg > 0) h->irv_budget = arg;
         e = adc_run_region_voting(h);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -961,6 +962,14 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     e = hipStreamSynchronize(h->heavy);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { set_error("adc_debug_run sync", e); return 2; }
+    if (stage == ADC_RUN_SCANLINE && h->so_nseg_last > 1) {
+        // (round-4 advisor finding) the row passes ran as speculative segments; behind a Match adc_wait redoes the stage with whole
+        // rows when a seam failed -- here the aggregated volume is gone (the passes ping-pong over it), so a failed seam is an
+        // ERROR of the debug call instead of a silently inexact volume
+        int fails = 0;
+        if (hipMemcpy(&fails, h->armmax + 2, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { set_error("adc_debug_run: seam flag", hipGetLastError()); return 2; }
+        if (fails != 0) { g_last_error = "adc_debug_run(ADC_RUN_SCANLINE): a speculative row segment failed its seam check; rerun with ADC_SO_SEG=1"; return 3; }
+    }
     if (stage == ADC_RUN_MEDIAN && h->pin_flags && h->pin_flags[0] != 0) { // what adc_wait does behind a Match
         e = adc_median_fallback(h);
         h->pin_flags[0] = 0;

@@ -747,10 +747,11 @@ def pmc_traffic(workload, whd):
     """HBM bytes per aggregation launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
     separate --pmc runs, gfx950 correction per MI355X_MICROARCH.md).  None when not collected for this workload / size
     or when it was collected on other aggregation kernel sources (k4_source_hash)."""
-    if whd != (1920, 1080, 128):
+    tags = {(1920, 1080, 128): "", (1242, 375, 128): "_1242x375"}  # (the 1080p files carry no size suffix)
+    if whd not in tags:
         return None
-    for rnd in ("r4", "r3"):  # the newest measurement taken on exactly these kernel sources
-        p = os.path.join(ROOT, "profiles", "%s_k4_pmc_traffic_%s.json" % (rnd, workload))
+    for rnd in ("r5", "r4", "r3"):  # the newest measurement taken on exactly these kernel sources
+        p = os.path.join(ROOT, "profiles", "%s_k4_pmc_traffic_%s%s.json" % (rnd, workload, tags[whd]))
         try:
             with open(p) as f:
                 o = json.load(f)

@@ -240,10 +240,15 @@ int adc_debug_run(adc_handle* h, int stage, int arg);
 /* Test-only event counters of the handle: which = 0 -> number of times adc_wait had to redo the median filter with the
  * single-workgroup kernel (hand-off time-out of the banded kernel); 1 -> continuations of the voting chain (launch budget
  * too small); 2 -> aggregation redos (assumed ring depth too small); 3 -> launch budget (kernels) of the next Match's
- * voting chain.  ADC_RUN_REGION_VOTING of adc_debug_run takes the budget of that run as `arg` (0 = keep). */
+ * voting chain; 4 -> Matches redone because a scanline row segment failed its seam check, 5 -> segments per row of the last
+ * scanline run, 6 -> seams that failed in it; 7 -> speculative median seams that differed, 8 -> the last median used speculative
+ * bands; 9 -> consecutive Matches that needed different aggregation plans (short-arm / long-arm image), 10 -> Matches whose
+ * aggregation was enqueued as two plans (the device chose), 11 -> redos that restarted at the aggregation, 12 -> Matches for which
+ * both plans will still be enqueued.  ADC_RUN_REGION_VOTING of adc_debug_run takes the budget of that run as `arg` (0 = keep;
+ * arg < 0: run nothing, set the budget of the NEXT Match's chain to -arg). */
 int64_t adc_debug_counter(adc_handle* h, int which);
-/* Statistics of the last region-voting run: total fixed-point rounds over the 10 passes and
- * total vote evaluations. */
+/* Statistics of the last region-voting run: rounds of the fixed-point iteration (all ten passes of the reference iterate at
+ * once since round 5) and total vote evaluations. */
 int adc_debug_voting_stats(adc_handle* h, int64_t* rounds, int64_t* evaluations);
 
 #ifdef __cplusplus

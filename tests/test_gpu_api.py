@@ -202,13 +202,25 @@ def test_async_pipeline_assumptions_and_budgets(hip, oracle, monkeypatch):
     assert st.debug_counter(11) == part0 + 1         # ... from the aggregation on (cost records / arms of the pair were kept)
     # the voting budget remembers the longest chain of the last 8 Matches: the structured pair after two noise pairs does NOT
     # overrun it (it did while the budget followed the previous Match alone)
-    assert st.debug_counter(1) == over0 and st.debug_counter(3) == kept_budget
+    assert st.debug_counter(1) == over0 and abs(st.debug_counter(3) - kept_budget) <= 6
+    need_s = st.voting_stats()[0] + 4                # kernels of the structured pair's chain: BEGIN, BEGIN2, its rounds, FINAL, DONE
     for _ in range(8):                               # eight short chains later the budget has shrunk to the noise pair's ...
         assert same(st.match(*n_pair), want_n)
-    assert st.debug_counter(3) < kept_budget
-    assert same(st.match(*s_pair), want_s)           # ... the structured pair overruns it: continued by adc_wait, same result
-    assert st.debug_counter(1) >= over0 + 1 and st.debug_counter(3) >= kept_budget
+    small_budget = st.debug_counter(3)
+    assert small_budget < kept_budget
+    assert same(st.match(*s_pair), want_s)           # ... a chain that overruns it is continued by adc_wait: same result
+    if abs(need_s - small_budget) > 3:               # (not when it is a matter of a round more or less)
+        assert (st.debug_counter(1) >= over0 + 1) == (need_s > small_budget), (need_s, small_budget)
+    assert st.debug_counter(3) >= kept_budget - 6    # (the number of rounds of a chaotic iteration varies by one or two from run to run)
     assert same(st.match(*s_pair), want_s)
+    st.Release()
+    # the continuation path for certain: a chain budget of 4 kernels through the stage-level hook, then a whole Match on the handle
+    st = A.ADCensusStereo(device=0)
+    assert st.Initialize(w, h, cases.to_product_option(opt))
+    assert same(st.match(*s_pair), want_s)
+    st.debug_set_budget(4)
+    over1 = st.debug_counter(1)
+    assert same(st.match(*s_pair), want_s) and st.debug_counter(1) == over1 + 1
     st.Release()
 
 
@@ -394,7 +406,8 @@ def test_aggregation_kernel_families_ab(hip, env):
 
 @pytest.mark.parametrize("env,expect_redo", [({"ADC_SO_SEG": "0"}, False), ({"ADC_SO_SEG": "2"}, False), ({"ADC_SO_SEG": "3"}, False),
                                              ({"ADC_SO_SEG": "5", "ADC_SO_FAST": "1"}, False), ({"ADC_SO_SEG": "4", "ADC_SO_FAST": "0"}, False),
-                                             ({"ADC_SO_SEG": "3", "ADC_SO_WARM": "16"}, True)])
+                                             ({"ADC_SO_SEG": "3", "ADC_SO_WARM": "16"}, True),
+                                             ({"ADC_SO_SEG": "1"}, False)])  # (whole rows: the kernels a failed seam falls back to, stage by stage)
 def test_scanline_segment_variants(hip, env, expect_redo):
     """K5 row passes cut into verified segments (k_scanline_seg / k_scanline_pin_seg): forced segment counts on both kernel
     families stay bit-exact stage by stage (oracle cost_aggr in, cost_so out; no seam fails with the production warm-up), and

@@ -343,7 +343,7 @@ extern "C" long irv_joint_chunks(float* out, const float* d0, const uint8_t* lab
 // inside a band the dirty entries are evaluated ROW BY ROW (step j = row r0 + j of every band; all pixels of that row at once,
 // against the map as it was after step j - 1).  R = H: one top-down sweep of the whole image per round.
 extern "C" long irv_joint_bands(float* out, const float* d0, const uint8_t* label, const uint8_t* arms, int W, int H, int dmin, int D,
-                                int irv_ts, float irv_th, int R, long* evals_per_round, long* changes_per_round, long max_rounds)
+                                int irv_ts, float irv_th, int R, int level_aware, long* evals_per_round, long* changes_per_round, long max_rounds)
 {
     const int P = W * H;
     std::vector<uint8_t> f(P, 5);
@@ -352,6 +352,9 @@ extern "C" long irv_joint_bands(float* out, const float* d0, const uint8_t* labe
         if (label[p] == 0 && d0[p] != ADC_INVALID_FLOAT) { f[p] = 0; b[p] = (int)(lroundf(d0[p]) - dmin); }
     const int TW = (W + 7) / 8, TH = (H + 7) / 8;
     std::vector<uint8_t> tchg_prev((size_t)TW * TH, 1), tchg_now((size_t)TW * TH, 0), dirty(P);
+    // level_aware: a second tile map for changes that involve iteration 0 (min of old and new fill iteration == 0); a pixel that is
+    // filled at iteration 0 depends only on inputs that count at iteration 0 -- a mismatch pixel only on the rows above it
+    std::vector<uint8_t> t0_prev((size_t)TW * TH, 1), t0_now((size_t)TW * TH, 0);
     std::vector<int> add((size_t)5 * D);
     struct Upd { int p; uint8_t f; int b; };
     std::vector<Upd> upd;
@@ -359,6 +362,7 @@ extern "C" long irv_joint_bands(float* out, const float* d0, const uint8_t* labe
     for (;; rounds++) {
         long evals = 0, changes = 0;
         std::fill(tchg_now.begin(), tchg_now.end(), 0);
+        std::fill(t0_now.begin(), t0_now.end(), 0);
         for (int p = 0; p < P; p++) {
             dirty[p] = 0;
             if (label[p] == 0) continue;
@@ -371,9 +375,11 @@ extern "C" long irv_joint_bands(float* out, const float* d0, const uint8_t* labe
                     const uint8_t* arm2 = arms + ((size_t)(y + t) * W + x) * 4;
                     ml = std::max(ml, (int)arm2[0]); mr = std::max(mr, (int)arm2[1]);
                 }
-                for (int ty = (y - arm[2]) / 8; ty <= (y + arm[3]) / 8 && !dt; ty++)
+                const bool lvl0 = level_aware && f[p] == 0;
+                const int ybot = (lvl0 && label[p] == ADC_LABEL_MISMATCH) ? y : y + arm[3];
+                for (int ty = (y - arm[2]) / 8; ty <= ybot / 8 && !dt; ty++)
                     for (int tx = (x - ml) / 8; tx <= (x + mr) / 8; tx++)
-                        if (tchg_prev[(size_t)ty * TW + tx]) { dt = true; break; }
+                        if (lvl0 ? t0_prev[(size_t)ty * TW + tx] : tchg_prev[(size_t)ty * TW + tx]) { dt = true; break; }
             }
             dirty[p] = dt;
         }
@@ -423,6 +429,7 @@ extern "C" long irv_joint_bands(float* out, const float* d0, const uint8_t* labe
                 }
             }
             for (const Upd& u : upd) {
+                if (f[u.p] == 0 || u.f == 0) t0_now[(size_t)((u.p / W) / 8) * TW + (u.p % W) / 8] = 1;
                 f[u.p] = u.f; b[u.p] = u.b;
                 changes++;
                 tchg_now[(size_t)((u.p / W) / 8) * TW + (u.p % W) / 8] = 1;
@@ -430,6 +437,7 @@ extern "C" long irv_joint_bands(float* out, const float* d0, const uint8_t* labe
         }
         if (rounds < max_rounds) { evals_per_round[rounds] = evals; changes_per_round[rounds] = changes; }
         tchg_prev.swap(tchg_now);
+        t0_prev.swap(t0_now);
         if (changes == 0) { rounds++; break; }
     }
     memcpy(out, d0, (size_t)P * 4);

@@ -75,12 +75,12 @@ def main():
               "sequential steps per round %s" % ("row" if rm else "column", Cn, rounds, ok, e.sum() / 1e6, [int(v) for v in e], [int(v) for v in list(stp)[:rounds]]))
 
     lib.irv_joint_bands.restype = C.c_long
-    for R in (8, 16, 32, 64, 135, H):
-        rounds = lib.irv_joint_bands(P(out), P(d0), P(lab), P(arms), W, H, opt.min_disparity, D, opt.irv_ts, C.c_float(opt.irv_th), R, evr, chr_, MR)
+    for R, la in ((8, 0), (16, 0), (32, 0), (64, 0), (135, 0), (H, 0), (8, 1), (16, 1)):
+        rounds = lib.irv_joint_bands(P(out), P(d0), P(lab), P(arms), W, H, opt.min_disparity, D, opt.irv_ts, C.c_float(opt.irv_th), R, la, evr, chr_, MR)
         ok = np.array_equal(out.view(np.uint32), o["disp_after_irv"].view(np.uint32))
         e = np.array(list(evr))[:rounds]
-        print("  bands of %d rows swept row by row, all bands side by side: %d rounds, equals the reference: %s; evaluations %.3f M %s"
-              % (R, rounds, ok, e.sum() / 1e6, [int(v) for v in e]))
+        print("  bands of %d rows swept row by row, all bands side by side%s: %d rounds, equals the reference: %s; evaluations %.3f M %s"
+              % (R, ", iteration-aware dirty test" if la else "", rounds, ok, e.sum() / 1e6, [int(v) for v in e]))
 
 
 if __name__ == "__main__":
