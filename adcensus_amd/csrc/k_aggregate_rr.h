@@ -33,7 +33,7 @@
 // the loads / stores of the marching kernels (K4, K5, K6) are marked non-temporal: same-box A/B at 1080p, K4 launch 0.394 -> 0.376 ms
 // (0.462 -> 0.445 in the slower clock state of the same box), scanline stage -1 %, right-view WTA -4 % (profiles/r5_ab_nontemporal.txt);
 // -DADC_VOL_NT=0 switches it off (tools/build_variant.sh).
-#if !defined(ADC_VOL_NT) || ADC_VOL_NT
+#if (!defined(ADC_VOL_NT) || ADC_VOL_NT) && !defined(RR_EMUL) // (the CPU build of this header has no such builtin)
 #define ADC_VOL_NT_STR " nt"
 #define ADC_VOL_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
 #else

@@ -484,20 +484,23 @@ static int irv_min_region(const adc_handle* h)
     const int Lmax = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
     return Lmax <= 127 ? h->p.opt.irv_ts : -1; // u16 support counts cannot wrap for L <= 127
 }
-// Launch shape of the chain: up to 16 waves per workgroup (fewer when the histograms + pool would not fit into 64 KB of
-// LDS); workgroups: one per 2048 pixels, rounded up to a power of two, between 64 and 512 (two per CU of an MI355X) --
-// measured at 1242x375: 256 workgroups 218 pairs/s, 512: 209, 128: 201; ADC_IRV_GRID / ADC_IRV_WPB override.
+// Launch shape of the chain: 8 waves per workgroup (fewer when the histograms + pool would not fit into 64 KB of LDS);
+// workgroups: one per 1024 pixels, rounded up to a power of two, between 128 and 1024 (four per CU of an MI355X: the whole grid
+// co-resident).  Round 5, structured 1080p pairs, refine stage (profiles/r5_k8_workgroup_shapes.txt): 16 waves x 512 workgroups
+// 3.58 / 4.03 ms, 8 x 1024 3.27 / 3.65 (fewer rounds AND fewer evaluations: a workgroup's waves take CONSECUTIVE entries of its
+// segment, so smaller workgroups follow the sweep order more closely), 8 x 768 3.50 / 3.67, 8 x 2048 3.86 / 4.18, 4 x 1024
+// 3.90 / 3.68; KITTI size: 16 x 256 = 8 x 512.  ADC_IRV_GRID / ADC_IRV_WPB override.
 int adc_irv_grid(size_t pixels)
 {
     static const int g_env = [] { const char* e = getenv("ADC_IRV_GRID"); return e ? atoi(e) : 0; }();
     if (g_env > 0) return g_env;
-    int g = 64;
-    while (g < 512 && (size_t)g * 2048 < pixels) g *= 2;
+    int g = 128;
+    while (g < 1024 && (size_t)g * 1024 < pixels) g *= 2;
     return g;
 }
 static int irv_wpb(int D)
 {
-    static const int wmax = [] { const char* e = getenv("ADC_IRV_WPB"); const int v = e ? atoi(e) : IRV_MAXW; return v >= 1 && v <= IRV_MAXW ? v : IRV_MAXW; }();
+    static const int wmax = [] { const char* e = getenv("ADC_IRV_WPB"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= IRV_MAXW ? v : 8; }();
     int w = 1;
     while (2 * w <= wmax) w *= 2;
     while (w > 1 && (size_t)w * IRV_LEVELS * D * 4 + (size_t)w * 64 * 16 > 60 * 1024) w >>= 1;
@@ -573,7 +576,7 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     h->vote_evals = st[6];
     if (*continued) h->irv_overflows++; // (the FINAL kernel of the continued chain has written the result into disp_l)
     // budget of the next Match: the kernels this one actually needed (st[7] = index of the first kernel that found
-    // nothing left to do) + 25 % + 8
+    // nothing left to do) + 25 % (at least 2) + 2
     const int used = st[7] + 1;
     static const int fixed = [] { const char* ev = getenv("ADC_IRV_BUDGET"); return ev ? atoi(ev) : 0; }();
     // (the longest chain of the last 8 Matches of the handle: the pairs of a stream differ -- at the KITTI size 3 of 23 distinct
@@ -584,6 +587,7 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     for (int i = 0; i < 8; i++) longest = adc_imax(longest, h->irv_used_hist[i]);
     // (round 5: the chain of a natural 1080p image is 50-75 kernels instead of ~350 and varies more from pair to pair, relatively:
     // a quarter of margin instead of an eighth -- 10 surplus kernels cost 0.05 ms, a continuation a synchronisation and the tail stages)
-    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + longest / 4 + 8);
+    // a short chain (an image with next to no eligible pixel: 6 kernels) gets 4 surplus kernels, a long one a quarter
+    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + adc_imax(longest / 4, 2) + 2);
     return hipSuccess;
 }
