@@ -162,7 +162,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin
     HIP_OK(hipMalloc(&h->disp_vote, P * 4));
     HIP_OK(hipMalloc(&h->vote_counters, 512 * sizeof(int32_t)));
-    // voting chain budget of the FIRST Match of a handle (later ones adapt: kernels used + 25 % + 2): a natural 1080p image needs
+    // voting chain budget of the FIRST Match of a handle (later ones adapt: kernels used + 40 % + 2): a natural 1080p image needs
     // ~50-75 kernels (round 5: all passes iterate at once; ~350 before); kernels past the end of the chain are no-ops of ~4 us, an
     // exhausted budget costs a synchronous continuation
     h->irv_budget = 256;

@@ -576,7 +576,7 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     h->vote_evals = st[6];
     if (*continued) h->irv_overflows++; // (the FINAL kernel of the continued chain has written the result into disp_l)
     // budget of the next Match: the kernels this one actually needed (st[7] = index of the first kernel that found
-    // nothing left to do) + 25 % (at least 2) + 2
+    // nothing left to do) + 40 % (at least 2) + 2
     const int used = st[7] + 1;
     static const int fixed = [] { const char* ev = getenv("ADC_IRV_BUDGET"); return ev ? atoi(ev) : 0; }();
     // (the longest chain of the last 8 Matches of the handle: the pairs of a stream differ -- at the KITTI size 3 of 23 distinct
@@ -588,6 +588,8 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     // (round 5: the chain of a natural 1080p image is 50-75 kernels instead of ~350 and varies more from pair to pair, relatively:
     // a quarter of margin instead of an eighth -- 10 surplus kernels cost 0.05 ms, a continuation a synchronisation and the tail stages)
     // a short chain (an image with next to no eligible pixel: 6 kernels) gets 4 surplus kernels, a long one a quarter
-    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + adc_imax(longest / 4, 2) + 2);
+    // (measured on 24 distinct structured pairs: with a quarter of margin 1-2 of ~28 Matches still overran -- the chains of a stream
+    // vary 48-75 kernels --, and a continuation costs ~1.5 ms where 6 more surplus kernels cost 0.03 ms: 40 %)
+    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + adc_imax(2 * longest / 5, 2) + 2);
     return hipSuccess;
 }

@@ -536,7 +536,7 @@ def test_voting_tiles_partition_the_image(emul):
     exactly once and fit the workgroup's list segment -- for the grids the launcher uses and odd shapes."""
     emul.emul_irv_tile_partition.restype = C.c_long
     for w, h in ((1920, 1080), (1242, 375), (450, 375), (1, 1), (1, 40), (33, 17), (7, 129), (640, 16)):
-        for g, wpb in ((64, 16), (128, 16), (512, 16), (512, 1), (5, 1), (2, 4), (24, 8)):
+        for g, wpb in ((128, 8), (256, 8), (1024, 8), (64, 16), (512, 16), (512, 1), (5, 1), (2, 4), (24, 8)):
             for xcd in (0, 1):
                 assert emul.emul_irv_tile_partition(w, h, g, wpb, xcd) == 0, (w, h, g, wpb, xcd)
 
