@@ -81,9 +81,9 @@ struct adc_handle {
     float *disp_l, *disp_r, *disp_tmp;
     uint8_t* label;
     uint8_t* elig;       // scratch: invalid mask of the LR check (byte per pixel), then the voting chain's bitmap of the pixels on its work list
-    uint8_t* irv_bbox;   // uchar4 per pixel: {top, max left, max right} dependency box of the vote
-    int32_t* vote_list;  // work list of the voting pass: int4 entries (k_voting.hip)
-    int32_t* vote_evals_arr; // evaluation counter per wave of the chain's grid (statistics)
+    uint8_t* irv_bbox;   // uchar4 per pixel: widest H arms {left, right} over the rows y-top..y and over ALL region rows (k_irv_bbox): read box / dirty box of a vote
+    int32_t* vote_list;  // work list of the voting chain: int4 entries, one segment per workgroup in evaluation order (irv_plan.h)
+    int32_t* vote_evals_arr; // evaluation counter per wave of the chain's grid (statistics), then the entries per workgroup segment
     int32_t* interp_list;     // target list of the interpolation (its own buffers: the voting chain may be CONTINUED after
     int32_t* interp_counters; // the interpolation has run once, and must find its list and control block untouched)
     int32_t* ray_tab;     // [max_search][16] packed ray offsets (dy<<16 | dx&0xffff), NULL when a step is too close to a .5 tie
@@ -124,7 +124,7 @@ struct adc_handle {
     int32_t* pin_flags;   // pinned host word: error flag of the banded median's hand-off (read back after every Match)
     int bgrx_valid;       // bgrx_l holds the packed left image of the current pair (written by the arms stage)
     uint32_t* bgrx_l;     // left image packed B | G<<8 | R<<16 per pixel (interpolation gathers)
-    uint16_t* st16;      // region voting: 16-bit state map [H][st16_pitch] {bin:11 | final | eligible} (k_voting.hip)
+    uint16_t* st16;      // region voting: 16-bit state map [H][st16_pitch] {bin:11 | iteration of the fill:3 | list:2} (irv_plan.h)
     int st16_pitch;      // row pitch of st16 in elements (multiple of 8: rows start 16-byte aligned)
     float* disp_vote;    // the map the voting chain works on (copy of the LR-checked map, copied back when the chain ends)
     int irv_grid;        // workgroups of the voting chain (adc_irv_grid, fixed per handle: the work-list layout depends on it)

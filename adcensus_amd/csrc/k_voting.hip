@@ -1,6 +1,6 @@
 // k_voting.hip -- K8 iterative region voting (MultiStepRefiner::IterativeRegionVoting, multistep_refiner.cpp:153-227),
-// DEVICE-DRIVEN: the host enqueues a fixed chain of identical kernels and never looks at the data; which list is being
-// filled, which round runs and when a pass has converged is decided on the device.
+// DEVICE-DRIVEN: the host enqueues a fixed chain of identical kernels and never looks at the data; which round runs and when the
+// iteration has converged is decided on the device.
 //
 // Semantics kept exactly: 5 iterations x {mismatches, occlusions}; inside a pass the reference fills the
 // still-invalid pixels of the list in raster order IN PLACE, so a vote sees the fills of the list pixels that precede it, and
@@ -570,7 +570,7 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
         h->irv_chain += 64;
         if ((e = hipMemcpyAsync(st, h->vote_counters + 16 * (h->irv_chain & 1), 8 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return e;
-        if (++guard > (1 << 16)) return hipErrorUnknown; // cannot happen: a pass converges in <= n rounds
+        if (++guard > (1 << 16)) return hipErrorUnknown; // cannot happen: the triangular system converges in <= 10 n rounds
     }
     h->vote_rounds = st[5];
     h->vote_evals = st[6];
@@ -587,7 +587,7 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     for (int i = 0; i < 8; i++) longest = adc_imax(longest, h->irv_used_hist[i]);
     // (round 5: the chain of a natural 1080p image is 50-75 kernels instead of ~350 and varies more from pair to pair, relatively:
     // a quarter of margin instead of an eighth -- 10 surplus kernels cost 0.05 ms, a continuation a synchronisation and the tail stages)
-    // a short chain (an image with next to no eligible pixel: 6 kernels) gets 4 surplus kernels, a long one a quarter
+    // a short chain (an image with next to no listed pixel: 6 kernels) gets 4 surplus kernels, a long one 40 %
     // (measured on 24 distinct structured pairs: with a quarter of margin 1-2 of ~28 Matches still overran -- the chains of a stream
     // vary 48-75 kernels --, and a continuation costs ~1.5 ms where 6 more surplus kernels cost 0.03 ms: 40 %)
     h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + adc_imax(2 * longest / 5, 2) + 2);
