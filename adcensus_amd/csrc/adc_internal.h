@@ -109,6 +109,7 @@ struct adc_handle {
     int armmax_small[2];  // arm maxima of the last image that fitted the small rings (0 = none seen)
     int agg_gate, agg_gate_thr; // set while a plan of a two-plan run is being enqueued: gate code (3 / 4) and packed depths
     int redo_partial;     // redos that restarted at the aggregation instead of the whole Match
+    int match_pending;    // a Match was enqueued and adc_wait has not yet looked at its arm maxima / speculation flags
     int fuse_cost;        // set by the pipeline: the first aggregation pass computes the matching cost itself
     int agg_first_fused;  // the last aggregation run did so (pass timings: the regular passes are 1..)
     int fuse_wta;         // set by the pipeline: the last scanline pass also writes the left-view disparity map

@@ -371,6 +371,7 @@ static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
     MARK(0, h->heavy);
     static const bool fuse_cost = [] { const char* e = getenv("ADC_FUSE_COST"); return e ? atoi(e) != 0 : true; }();
     const bool fuse_cost_now = fuse_cost && !(h->paper & ADC_PAPER_RIGHT_ARMS); // (paper mode: plain kernels on a stored cost volume)
+    h->match_pending = 1; // (adc_wait looks at this Match's arm maxima / speculation flags exactly once)
     if (from_aggregation) {
         MARK(1, h->heavy);
         MARK(2, h->heavy);
@@ -588,8 +589,9 @@ int adc_wait(adc_handle* h)
         h->armmax_host[0] = h->pin_flags[4];
         h->armmax_host[1] = h->pin_flags[5];
         h->arm_known = 1;
-        if (h->so_seg_off > 0) h->so_seg_off--; // (whole rows for a while after a failed seam)
-        {   // which plan did this image need?  Consecutive Matches that need different plans = a mixed stream: the next 64
+        if (h->match_pending && h->so_seg_off > 0) h->so_seg_off--; // (whole rows for a while after a failed seam)
+        if (h->match_pending) { // (once per Match: a second adc_wait without a Match in between must not count again)
+            // which plan did this image need?  Consecutive Matches that need different plans = a mixed stream: the next 64
             // Matches enqueue both plans and let the device choose (k_aggregate.hip) instead of assuming and redoing
             const int small_L = adc_agg_small_L(h);
             const int plan = (h->pin_flags[4] <= small_L && h->pin_flags[5] <= small_L) ? 1 : 2;
@@ -598,6 +600,7 @@ int adc_wait(adc_handle* h)
             else if (h->agg_dual > 0) h->agg_dual--;
             h->agg_last_plan = plan;
         }
+        h->match_pending = 0;
     }
     // (2) the voting chain ran out of its launch budget before it converged: continue it, redo the stages behind it
     int continued = 0;
