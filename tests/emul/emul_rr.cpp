@@ -168,3 +168,12 @@ extern "C" int emul_rr2_window_identity(int steps, int start)
     }
     return bad;
 }
+
+// The launch gate shared by every marching aggregation body (agg_gate_skip, k_aggregate_rr.h): does the launch with the
+// given code / packed depths skip its work for an image with these arm maxima?  (CPU tier: exactly one of the two plans of a
+// two-plan run works, whatever the image; the per-direction codes of the debug surface; the verify code.)
+extern "C" int emul_agg_gate_skip(int armmax_h, int armmax_v, int small_variant, int small_L, int vert)
+{
+    const int armmax[4] = {armmax_h, armmax_v, 0, 0};
+    return agg_gate_skip(armmax, small_variant, small_L, vert != 0) ? 1 : 0;
+}

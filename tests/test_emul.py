@@ -531,6 +531,29 @@ def test_interpolation_skipping_is_exact(emul, seed, density, ns):
             assert n < 0.6 * plain.value, (n, plain.value)   # the sparse band is crossed in jumps
 
 
+def test_aggregation_launch_gate(emul):
+    """agg_gate_skip (k_aggregate_rr.h): of the two plans a mixed stream enqueues back to back (codes 3 / 4, depths packed as
+    depth_h | depth_v << 16, 0x7fff = that direction runs the full ring anyway) exactly ONE works for every image; the debug
+    surface's per-direction codes 0 / 1 are complementary too; the verify code 2 skips exactly when the arm does not fit."""
+    g = emul.emul_agg_gate_skip
+    for dh in (1, 3, 8, 0x7fff):
+        for dv in (1, 4, 8, 0x7fff):
+            thr = dh | (dv << 16)
+            for ah in (0, 1, 3, 4, 8, 9, 34):
+                for av in (0, 1, 4, 5, 8, 9, 34):
+                    for vert in (0, 1):
+                        s_skips, f_skips = g(ah, av, 3, thr, vert), g(ah, av, 4, thr, vert)
+                        assert s_skips + f_skips == 1, (dh, dv, ah, av)
+                        assert s_skips == (0 if (ah <= dh and av <= dv) else 1)
+    for small_L in (1, 8):
+        for a in (0, 1, 8, 9, 34):
+            for vert in (0, 1):
+                ah, av = (5, a) if vert else (a, 5)
+                assert g(ah, av, 0, small_L, vert) + g(ah, av, 1, small_L, vert) == 1
+                assert g(ah, av, 2, small_L, vert) == (1 if a > small_L else 0)
+                assert g(ah, av, -1, small_L, vert) == 0
+
+
 def test_voting_tiles_partition_the_image(emul):
     """irv_plan.h: the tiles of the voting chain's workgroups (bands of 16 rows, a band belongs to one XCD) cover every pixel
     exactly once and fit the workgroup's list segment -- for the grids the launcher uses and odd shapes."""
