@@ -113,6 +113,9 @@ struct adc_handle {
     int fuse_cost;        // set by the pipeline: the first aggregation pass computes the matching cost itself
     int agg_first_fused;  // the last aggregation run did so (pass timings: the regular passes are 1..)
     int fuse_wta;         // set by the pipeline: the last scanline pass also writes the left-view disparity map
+    int fuse_agg_so;      // set by the pipeline: the last aggregation pass may move into the first scanline pass (short-arm plan)
+    int so_agg_fused;     // adc_launch_aggregate did so: vol_a holds the volume BEFORE that pass (consumed by the scanline stage)
+    int agg_so_fusions;   // Matches that ran that way
     int wta_left_done;    // the scanline stage did so: adc_launch_wta only runs the right view
     float* med_hand;      // banded median: per-band hand-off rows [bands][med_hpitch], indexed by wavefront level
     int med_hpitch;
@@ -182,6 +185,7 @@ hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream);
 size_t adc_so_cls_bytes(int W, int H);
 hipError_t adc_launch_scanline(adc_handle* h, int passes);      // vol_a -> vol_a via vol_b (passes=4)
 int adc_so_segments(const adc_handle* h, int* warm_out);        // verified segments per row of the next scanline run
+bool adc_so_can_fuse_agg(const adc_handle* h);                  // the next scanline run can take over the last aggregation pass
 size_t adc_so_seam_bytes(int W, int H, int Dp);
 hipError_t adc_launch_wta(adc_handle* h);                       // vol_a -> disp_l, disp_r
 hipError_t adc_launch_wta_left(adc_handle* h);                  // vol_a -> disp_l only (debug form of the left view)

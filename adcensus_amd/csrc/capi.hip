@@ -406,9 +406,11 @@ static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
     HIP_OK(adc_launch_records(h));
     } // (!from_aggregation)
     h->fuse_cost = fuse_cost_now ? 1 : 0;
+    h->fuse_agg_so = 1; // (the launcher decides: short-arm plan, arms <= 4, segmented row passes)
     {
         const hipError_t e_ = adc_launch_aggregate(h, 4); // aggregator_.Aggregate(4), :164
         h->fuse_cost = 0;
+        h->fuse_agg_so = 0;
         h->armmax_valid = 0;
         HIP_OK(e_);
     }
@@ -993,6 +995,7 @@ int64_t adc_debug_counter(adc_handle* h, int which)
     case 10: return h->agg_dual_runs; // Matches whose aggregation was enqueued as two plans (the device chose)
     case 11: return h->redo_partial;  // redos that restarted at the aggregation (not the whole Match)
     case 12: return h->agg_dual;      // > 0: the next Match enqueues both plans
+    case 13: return h->agg_so_fusions; // Matches whose last aggregation pass ran inside the first scanline pass
     case 3: return h->irv_budget;
     case 7: return h->med_spec_fails;
     case 8: return h->med_spec_last;

@@ -892,6 +892,13 @@ static hipError_t agg_sequence(adc_handle* h, int iterations, bool dry, bool fir
         if (prof && launch < 2) hipEventRecord(h->ev_agg[launch], h->heavy); // (only the marks adc_wait reads: start of the first / first regular launch)
         // second pass of the iteration (dividing): vertical after a horizontal first pass and vice versa
         const int wsec = hf ? which_v : which_h;
+        // The LAST pass (horizontal, dividing) of a short-arm image moves into the first scanline pass (k_scanline_seg_agg:
+        // one launch and 2 V of traffic less): arms up to 4, assumed or known; the other horizontal passes verify the depth.
+        if (!hf && k + 1 == iterations && iterations == 4 && h->fuse_agg_so && !h->agg_gate && marching && which_h == 1 &&
+            (h->armmax_valid == 1 || h->armmax_valid == 2) && agg_assumed_depth(h, false) <= 4 && adc_so_can_fuse_agg(h)) {
+            if (!dry) { h->so_agg_fused = 1; h->agg_so_fusions++; }
+            break;
+        }
         const bool pair = pair_env && marching && k + 1 < iterations &&
                           (wsec == 1 || (wsec == 2 && (pair_full >= 2 || (pair_full == 1 && regring_fits))));
         if (!dry) {
@@ -958,9 +965,12 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
         h->armmax_host[1] = h->armmax_small[1] > 0 ? h->armmax_small[1] : small_L;
         h->armmax_valid = 2;
         AggSeq s_dry, f_dry;
+        h->agg_gate = 3; // (also during the dry runs: a plan of a two-plan run never moves its last pass into the scanline stage)
         e = agg_sequence(h, iterations, true, false, false, &s_dry);
         h->armmax_valid = 3;
+        h->agg_gate = 4;
         if (e == hipSuccess) e = agg_sequence(h, iterations, true, false, false, &f_dry);
+        h->agg_gate = 0;
         const bool usable = e == hipSuccess && s_dry.first_fused && f_dry.first_fused;
         if (usable) {
             h->armmax_valid = 2;

@@ -266,13 +266,24 @@ __device__ __forceinline__ void so_rmap_load_words(const uint8_t* __restrict__ r
 #define SO_CLOBBERS "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147"
 // SEG (row passes, VPL <= 2): the path is cut into nseg verified segments (adc_device_fn.h: adc_so_seg_start), wave = (segment,
 // path); `seam` = this pass's seam slots [path][nseg - 1][Dp].
-template <int VPL, bool VERT, bool DPP, bool WTA, bool PIN, bool SEG = false>
+// AGG (round 5, the L->R row pass of short-arm images): the pass ALSO computes the last aggregation pass (horizontal, dividing:
+// cross_aggregator.cpp:327-394 with the arms of `aggrec`, k_arms.hip's rec_h = {arm_lo, arm_hi, divisor}) on its input -- `src`
+// is the volume BEFORE that pass; the aggregated volume is never written or read back (one launch and 2 V of traffic less).
+// The data stream runs SO_AGG_LA = 4 elements ahead of the recurrence; the last 9 raw pixel vectors live in a register shift
+// ring (position k = raw element e + 4 - k); element e's value is the sequential f32 sum from 0.0f over t = -arm_lo .. +arm_hi
+// (ring positions 4 + arm_lo down to 4 - arm_hi; the masked-out positions add +0.0f to a non-negative sum: exact) divided by
+// the count, like the separate pass.  Arms up to 4 only (the host launches this form when the assumed depth allows it, and the
+// other horizontal passes of the Match verify the assumption on the device).
+#define SO_AGG_LA 4
+template <int VPL, bool VERT, bool DPP, bool WTA, bool PIN, bool SEG = false, bool AGG = false>
 __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __restrict__ dst,
                                         const uint32_t* __restrict__ c1w, int ngr,
                                         const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso,
                                         int dir, float P1a, float P1b, float P1c, float P2a, float P2b, float P2c,
-                                        float* __restrict__ disp, int allow_fast, int nseg = 1, int warm = 0, float* __restrict__ seam = nullptr)
+                                        float* __restrict__ disp, int allow_fast, int nseg = 1, int warm = 0, float* __restrict__ seam = nullptr,
+                                        const uint32_t* __restrict__ aggrec = nullptr)
 {
+    static_assert(!AGG || (SEG && !PIN && !VERT && !WTA && VPL == 2), "fused aggregation: the L->R row pass, two disparities per lane, compiler-allocated slots");
     static_assert(!WTA || DPP, "the fused winner-takes-all relies on the uniform (SGPR) path minimum of the DPP reduction");
     static_assert(!SEG || (!WTA && !VERT && VPL <= 2), "verified segments: row passes of the asm-prefetch kernels");
     constexpr int Dp = 64 * VPL;
@@ -312,11 +323,39 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
     const uint32_t* c1p = c1w + (size_t)g.path * ngr; // this path's d1 words (uniform)
     const int cl_last = g.d0 + VPL - 1 + dmin;         // xr of the lane's last disparity = x - cl_last
 
+    // ---- fused aggregation (AGG): the register ring of raw pixel vectors and the arm records of this row
+    float agr[AGG ? 2 * SO_AGG_LA + 1 : 1][VPL];
+    const uint32_t* recp = AGG ? aggrec + (size_t)g.path * W : nullptr; // (dir > 0: path element e is column e)
+#define SO_AGG_PUSH(C)                                                                                         \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int t_ = 2 * SO_AGG_LA; t_ > 0; t_--)                                           \
+            _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) agr[t_][k_] = agr[t_ - 1][k_];                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) agr[0][k_] = (C)[k_];                               \
+    } while (0)
+#define SO_AGG_EVAL(EIDX, C)                                                                                   \
+    do {                                                                                                       \
+        const uint32_t rec_ = recp[(EIDX)];                                                                    \
+        const int top_ = SO_AGG_LA + (int)(rec_ & 255u), bot_ = SO_AGG_LA - (int)((rec_ >> 8) & 255u);         \
+        const float cnt_ = (float)(rec_ >> 16);                                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) {                                                   \
+            float acc_ = 0.0f;                                                                                 \
+            _Pragma("unroll") for (int t_ = 2 * SO_AGG_LA; t_ >= 0; t_--) acc_ += (t_ <= top_ && t_ >= bot_) ? agr[t_][k_] : 0.0f; \
+            (C)[k_] = acc_ / cnt_; /* cross_aggregator.cpp:389 (x / 1 == x) */                                  \
+        }                                                                                                      \
+    } while (0)
     float Lp[VPL]; // previous path element's costs; padding lanes (d >= D) hold the sentinel
     float minLp;
     {
         const size_t pix = so_pixel<VERT>(g, e0);
         float c[VPL];
+        if constexpr (AGG) {
+#pragma unroll
+            for (int t_ = 0; t_ <= 2 * SO_AGG_LA; t_++) { // ring position t_ = raw element e0 + 4 - t_ (clamped: the arms never reach outside the row)
+                const int er_ = adc_imax(0, adc_imin(g.plen - 1, e0 + SO_AGG_LA - t_));
+                vload<VPL>(src + so_pixel<VERT>(g, er_) * Dp + g.d0, agr[t_]);
+            }
+            SO_AGG_EVAL(e0, c);
+        } else
         vload<VPL>(src + pix * Dp + g.d0, c);
         if (!SEG || seg == 0) vstore<VPL>(dst + pix * Dp + g.d0, c); // first pixel: dst = src (scanline_optimizer.cpp:99,208)
         float lmin = ADC_LARGE_FLOAT; // sentinels take part in the first minimum (scanline_optimizer.cpp:107-110)
@@ -491,7 +530,8 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         const long long pstep = (long long)(VERT ? W : 1) * dir; // pixels per path step
         const long long fstep = pstep * Dp;
         const size_t px1 = so_pixel<VERT>(g, e0 + 1);
-        const float* spn = src + px1 * Dp + g.d0; // next element to prefetch
+        // (AGG: the data stream runs SO_AGG_LA elements ahead of the recurrence, clamped at the end of the ROW)
+        const float* spn = src + (AGG ? so_pixel<VERT>(g, adc_imin(e0 + 1 + SO_AGG_LA, g.plen - 1)) : px1) * Dp + g.d0; // next element to prefetch
         const uint32_t* cwn = c1p + (e0 >> 2);     // next d1 word to prefetch (e0 is a multiple of 4)
         float* dpn = dst + px1 * Dp + g.d0;        // next element to store
         long long dstep = fstep;                   // ... and how far the store pointer moves per step
@@ -526,7 +566,7 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
                 asm volatile("global_load_ushort %0, %1, %2" : "=v"(pfr[PIN ? 0 : (U)]) : "v"(ro_), "s"(rmap) : "memory"); \
             }                                                                                                  \
         }                                                                                                      \
-        spn += ii < last ? fstep : 0;                                                                          \
+        spn += (ii < last && (!AGG || ii + SO_AGG_LA < g.plen - 1)) ? fstep : 0;                               \
         mpf += ii < last ? dir : 0;                                                                            \
         ii += ii < last ? 1 : 0;                                                                               \
     } while (0)
@@ -556,6 +596,23 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         cwn += 1;                                                                                              \
         gi++;                                                                                                  \
     } while (0)
+#ifdef SO_PROXY_AGG
+#define SO_PROXY_STEP(E)                                                                                       \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int t_ = 8; t_ > 0; t_--)                                                       \
+            _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) prx[t_][k_] = prx[t_ - 1][k_];                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) prx[0][k_] = (E).c[k_];                             \
+        const int lo_ = (E).c1 & 3, hi_ = 4 + (((E).c1 >> 2) & 3); /* a wave-uniform span of 2 .. 8 ring entries */ \
+        const float cnt_ = (float)(1 + (((E).c1 >> 4) & 15));                                                  \
+        _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) {                                                   \
+            float acc_ = 0.0f;                                                                                 \
+            _Pragma("unroll") for (int t_ = 0; t_ < 9; t_++) acc_ += (t_ >= lo_ && t_ <= hi_) ? prx[t_][k_] : 0.0f; \
+            (E).c[k_] = (E).c[k_] + 0.0f * (acc_ / cnt_);                                                      \
+        }                                                                                                      \
+    } while (0)
+#else
+#define SO_PROXY_STEP(E) do { } while (0)
+#endif
 // take element U (and, on the first step of a group, the group's d1 word) after waiting for <= WAITN younger ops
 #define SO_TAKE(U, WAITN, E)                                                                                   \
     do {                                                                                                       \
@@ -602,6 +659,11 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         else { (E).c[0] = tc_.x; (E).c[VPL - 1] = tc_.y; }                                                     \
         (E).rb[0] = tr_;                                                                                       \
         (E).c1 = (int)((cw >> (8 * ((U)&3))) & 0xffu);                                                         \
+        SO_PROXY_STEP(E);                                                                                      \
+        if constexpr (AGG) { /* (E).c holds the RAW element e + SO_AGG_LA: push it, aggregate element e = e0 + i + U */ \
+            SO_AGG_PUSH((E).c);                                                                                \
+            SO_AGG_EVAL(e0 + i + (U), (E).c);                                                                  \
+        }                                                                                                      \
     } while (0)
 // one full step of the pipelined loop: take, re-issue the slot for the element PF ahead, DP step
 #define SO_PIPE(U, WAITN)                                                                                      \
@@ -634,6 +696,17 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
 #define SO_LAST4(G) SO_LAST(4 * (G)) SO_LAST(4 * (G) + 1) SO_LAST(4 * (G) + 2) SO_LAST(4 * (G) + 3)
         static_assert(PF == 16, "wait counts and the unrolled groups are written for 16 elements / 4 groups in flight");
         uint32_t cw = 0; // d1 word of the current group
+#ifdef SO_PROXY_AGG
+        // TIMING PROXY (tools/build_variant.sh, never in the product; profiles/r5_ab_fusion_proxy.txt): what would a pass cost if
+        // it ALSO aggregated its input?  Per step a register ring of 9 pixel vectors shifts, the ordered sum over a wave-uniform
+        // span of it, a correctly rounded division -- fed into the recurrence through c + 0 * q (results unchanged; without
+        // fast-math the compiler cannot drop it).  Measured before the fused row pass below (AGG) was built.
+        float prx[9][VPL];
+#pragma unroll
+        for (int t_ = 0; t_ < 9; t_++)
+#pragma unroll
+            for (int k_ = 0; k_ < VPL; k_++) prx[t_][k_] = 0.0f;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // start the manual bookkeeping from an empty queue
 #pragma unroll
         for (int G = 0; G < NG; G++) { // prologue, same order as the steady state without the stores
@@ -755,6 +828,8 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
 #undef SO_STEP_F
 #undef SO_STORE
 #undef SO_WTA
+#undef SO_AGG_PUSH
+#undef SO_AGG_EVAL
 }
 
 // VPL <= 2 (disparity ranges up to 128), asm prefetch.  Two kernels: k_scanline keeps the slots in compiler-allocated
@@ -790,6 +865,16 @@ __global__ __launch_bounds__(256) void k_scanline_seg(
     static_assert(VPL <= 2, "asm-prefetch kernels only");
     so_body<VPL, false, DPP, false, false, true>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, nullptr, 0,
                                                  nseg, warm, seam);
+}
+// ... and the L->R pass that also computes the last aggregation pass on its input (AGG, see so_body)
+template <int VPL, bool DPP>
+__global__ __launch_bounds__(256) void k_scanline_seg_agg(
+    const float* __restrict__ src, float* __restrict__ dst, const uint32_t* __restrict__ c1w, int ngr,
+    const uint8_t* __restrict__ rmap, int W, int H, int D, int dmin, int tso, int dir, float P1a, float P1b, float P1c,
+    float P2a, float P2b, float P2c, int nseg, int warm, float* __restrict__ seam, const uint32_t* __restrict__ aggrec)
+{
+    so_body<VPL, false, DPP, false, false, true, true>(src, dst, c1w, ngr, rmap, W, H, D, dmin, tso, dir, P1a, P1b, P1c, P2a, P2b, P2c, nullptr, 0,
+                                                       nseg, warm, seam, aggrec);
 }
 template <int VPL, bool DPP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SO_V0))) void k_scanline_pin_seg(
@@ -855,8 +940,28 @@ int adc_so_segments(const adc_handle* h, int* warm_out)
 }
 size_t adc_so_seam_bytes(int W, int H, int Dp) { (void)W; return (size_t)2 * H * (ADC_SO_MAX_SEG - 1) * Dp * sizeof(float); }
 
+// Passes that are lone-wave chains (fewer paths than the 1024 SIMDs of the chip) run k_scanline_pin with the short form
+// of whole interior chunks (KITTI-size row passes: 375 paths, scanline stage 0.873 -> 0.675 ms, same-box A/B); where
+// every SIMD has a wave or two the pass is bound by its memory streams and runs k_scanline.  ADC_SO_FAST=0 / 1 forces
+// k_scanline / k_scanline_pin everywhere.
+static bool so_uses_pin(int npaths, int nseg)
+{
+    static const int so_fast_env = [] { const char* e = getenv("ADC_SO_FAST"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    return so_fast_env >= 0 ? so_fast_env != 0 : npaths * nseg < 1024;
+}
+// Can the L->R row pass of the next scanline run take over the last aggregation pass (k_scanline_seg_agg)?  Needs the segment
+// form of the compiler-allocated family with two disparities per lane.  (adc_launch_aggregate asks before it drops that pass.)
+bool adc_so_can_fuse_agg(const adc_handle* h)
+{
+    static const bool env = [] { const char* e = getenv("ADC_FUSE_AGG_SO"); return e ? atoi(e) != 0 : true; }();
+    if (!env || h->p.VPL != 2 || !so_use_dpp() || h->paper) return false;
+    const int nseg = adc_so_segments(h, nullptr);
+    return nseg > 1 && !so_uses_pin(h->p.H, nseg);
+}
+
 template <int VPL>
-static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool vert, int dir, float* disp = nullptr, int nseg = 1, int warm = 0)
+static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool vert, int dir, float* disp = nullptr, int nseg = 1, int warm = 0,
+                            bool agg = false)
 {
     const AdcParams& p = h->p;
     const int npaths = vert ? p.W : p.H;
@@ -885,15 +990,19 @@ static hipError_t launch_so(adc_handle* h, const float* src, float* dst, bool ve
             hipLaunchKernelGGL((k_scanline_wide<VPL, VERT_, DPP_, WTA_>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, SO_ARGS); \
     } while (0)
     const bool dpp = so_use_dpp();
-    // Passes that are lone-wave chains (fewer paths than the 1024 SIMDs of the chip) run k_scanline_pin with the short form
-    // of whole interior chunks (KITTI-size row passes: 375 paths, scanline stage 0.873 -> 0.675 ms, same-box A/B); where
-    // every SIMD has a wave or two the pass is bound by its memory streams and runs k_scanline.  ADC_SO_FAST=0 / 1 forces
-    // k_scanline / k_scanline_pin everywhere.
-    static const int so_fast_env = [] { const char* e = getenv("ADC_SO_FAST"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-    const bool so_pin = so_fast_env >= 0 ? so_fast_env != 0 : npaths * nseg < 1024;
+    const bool so_pin = so_uses_pin(npaths, nseg);
     if constexpr (VPL <= 2) {
         if (nseg > 1 && !vert && dpp) { // verified segments: wave = (segment, row); seam slots of this pass
             float* seam = h->so_seam + (size_t)pass * p.H * (nseg - 1) * p.Dp;
+            if constexpr (VPL == 2) {
+                if (agg && !so_pin && dir > 0) { // the pass also computes the last aggregation pass on its input (so_body, AGG)
+                    hipLaunchKernelGGL((k_scanline_seg_agg<VPL, true>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, L.ngr[pass], rmap, p.W,
+                                       p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1],
+                                       h->so_P2[2], nseg, warm, seam, h->rec_h);
+                    return hipGetLastError();
+                }
+            }
+            if (agg) return hipErrorInvalidValue; // (adc_so_can_fuse_agg promised this form)
             if (so_pin)
                 hipLaunchKernelGGL((k_scanline_pin_seg<VPL, true>), dim3(blocks), dim3(64 * wpb), 0, h->heavy, src, dst, c1w, L.ngr[pass], rmap,
                                    p.W, p.H, p.D, p.dmin, p.opt.so_tso, dir, h->so_P1[0], h->so_P1[1], h->so_P1[2], h->so_P2[0], h->so_P2[1],
@@ -944,7 +1053,10 @@ static hipError_t run_so(adc_handle* h, int passes)
     const int nseg = (passes >= 2 && so_use_dpp()) ? adc_so_segments(h, &warm) : 1;
     h->so_nseg_last = nseg;
     if (e == hipSuccess && nseg > 1) e = hipMemsetAsync(h->armmax + 2, 0, sizeof(int), h->heavy);
-    if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1, nullptr, nseg, warm);
+    const bool agg = h->so_agg_fused != 0; // vol_a holds the volume BEFORE the last aggregation pass (adc_launch_aggregate dropped it)
+    h->so_agg_fused = 0;
+    if (agg && (nseg <= 1 || passes < 1)) return hipErrorInvalidValue;
+    if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1, nullptr, nseg, warm, agg);
     if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1, nullptr, nseg, warm);
     if (e == hipSuccess && nseg > 1) {
         const int waves = 2 * h->p.H * (nseg - 1);

@@ -270,8 +270,10 @@ def k4_roofline(prof, W, H, D, lib, workload, kernel=None, in_flight=1):
                     "algorithmic_* = SURVEY 8d numerator (2V+4P[+2P] per algorithmic pass; a pass-pair launch covers two)"}
 
 
-def stage_roofline(stage, ms_per_step, W, H, D):
-    """HBM fractions of the other volume stages from the stage timings (events on the handle's stream) and of the whole Match."""
+def stage_roofline(stage, ms_per_step, W, H, D, fused_tail=False):
+    """HBM fractions of the other volume stages from the stage timings (events on the handle's stream) and of the whole Match.
+    fused_tail: the last aggregation pass ran inside the first scanline pass (short-arm images, k_scanline_seg_agg): the
+    aggregation stage then covers 7 of the 8 algorithmic passes; the scanline stage's traffic is unchanged."""
     P = float(W) * H
     V = 4.0 * P * D
     out = {}
@@ -283,8 +285,12 @@ def stage_roofline(stage, ms_per_step, W, H, D):
     if stage.get("wta", 0) > 0:
         out["wta_right_K6"] = dict(frac(V, stage["wta"]), what="right-view winner-takes-all: one read of V (the left view rides on the last scanline pass)")
     if stage.get("aggregate", 0) > 0:
-        out["aggregate_K4_stage_algorithmic"] = dict(frac(16.0 * V + 40.0 * P, stage["aggregate"]),
-                                                     what="SURVEY 8d stage figure: 8 passes x (2V + 4P) + 8P = 17.07 GB at 1080p / stage time (target >= 0.60)")
+        if fused_tail:
+            out["aggregate_K4_stage_algorithmic"] = dict(frac(14.0 * V + 34.0 * P, stage["aggregate"]),
+                                                         what="7 of the 8 passes x (2V + 4P) + 6P (the 8th runs inside the first scanline pass) / stage time")
+        else:
+            out["aggregate_K4_stage_algorithmic"] = dict(frac(16.0 * V + 40.0 * P, stage["aggregate"]),
+                                                         what="SURVEY 8d stage figure: 8 passes x (2V + 4P) + 8P = 17.07 GB at 1080p / stage time (target >= 0.60)")
     if ms_per_step and ms_per_step > 0:
         out["whole_match"] = dict(frac(26.0 * V, ms_per_step), what="SURVEY 8d whole-pipeline model 26 V (27.6 GB at 1080p/128) / ms_per_step")
     return out
@@ -342,12 +348,12 @@ def measure_workload(A, device, W, H, D, workload, steps, warmup, inflight, pair
         total = farm.done_counter(len(m.mine), dist, tensor_device)
     keep = max(1, (steps + inflight - 1) // inflight)
     m.fallbacks = {"median_handoff": 0, "voting_continuations": 0, "aggregation_redos": 0, "scanline_seam_redos": 0,
-                   "median_spec_seam_failures": 0, "aggregation_two_plan_matches": 0, "matches": warmup + steps}
+                   "median_spec_seam_failures": 0, "aggregation_two_plan_matches": 0, "aggregation_tail_in_scanline": 0, "matches": warmup + steps}
     if host_pairs is None:
         # how often adc_wait had to complete an assumption of the asynchronous pipeline (warm-up + timed region, all pipelines)
         for st in m.handles:
             for key, which in (("median_handoff", 0), ("voting_continuations", 1), ("aggregation_redos", 2), ("scanline_seam_redos", 4),
-                               ("median_spec_seam_failures", 7), ("aggregation_two_plan_matches", 10)):
+                               ("median_spec_seam_failures", 7), ("aggregation_two_plan_matches", 10), ("aggregation_tail_in_scanline", 13)):
                 m.fallbacks[key] += int(st.debug_counter(which))
             m.fallbacks["scanline_segments_per_row"] = int(m.handles[0].debug_counter(5))
             m.fallbacks["voting_chain_budget"] = int(m.handles[0].debug_counter(3))
@@ -509,7 +515,8 @@ def main():
             "stage_ms": stage,
             "roofline": k4_roofline(prof, W, H, D, lib, a.workload, m.handles[0].aggregate_kernel(), F),
             # (per-GPU time per Match: weak scaling = ms_per_step, strong = ms_per_step x ranks)
-            "stage_roofline": dict(stage_roofline(stage, ms_per_step * (world if strong else 1), W, H, D),
+            "stage_roofline": dict(stage_roofline(stage, ms_per_step * (world if strong else 1), W, H, D,
+                                                  fused_tail=m.fallbacks.get("aggregation_tail_in_scanline", 0) * 2 > m.fallbacks.get("matches", 1) * len(m.handles)),
                                    **({} if F == 1 else {"note": "%d pipelines in flight: stage times include co-running kernels of other pairs; whole_match is a throughput figure" % F})),
             "async_fallbacks": m.fallbacks,
         }
@@ -555,7 +562,9 @@ def main():
                       "workload": "%s %dx%d D=%d (%d distinct pairs, seeds %d+i)" % (other, W, H, D, len(ids2), 777 if other == "structured" else 12345),
                       "stage_ms": s2,
                       "roofline": k4_roofline(pf2, W, H, D, lib, other, m2.handles[0].aggregate_kernel(), 1),
-                      "stage_roofline": stage_roofline(s2, 1000.0 * e2 / n2, W, H, D), "async_fallbacks": m2.fallbacks}
+                      "stage_roofline": stage_roofline(s2, 1000.0 * e2 / n2, W, H, D,
+                                                       fused_tail=m2.fallbacks.get("aggregation_tail_in_scanline", 0) * 2 > m2.fallbacks.get("matches", 1)),
+                      "async_fallbacks": m2.fallbacks}
         if ref2:  # every output of the leg against the reference CPU program's map of the same pair
             got2 = {pid: farm.digest(m2.output(pid).tobytes()) for pid in ids2}
             out[other]["reference_check"] = {"pairs": len(got2), "reference_checked": sum(1 for k in got2 if str(k) in ref2),

@@ -39,7 +39,8 @@ def _check(path, want):
 
 def test_scanline_prefetch_slots(device_asm):
     res, seen = _check(device_asm("k_scanline"), ["k_scanlineILi1E", "k_scanlineILi2E", "k_scanline_pinILi1E", "k_scanline_pinILi2E",
-                                                  "k_scanline_segILi1E", "k_scanline_segILi2E", "k_scanline_pin_segILi1E", "k_scanline_pin_segILi2E"])
+                                                  "k_scanline_segILi1E", "k_scanline_segILi2E", "k_scanline_pin_segILi1E", "k_scanline_pin_segILi2E",
+                                                  "k_scanline_seg_aggILi2E"])  # (+ the L->R pass that also aggregates its input)
     # every asm-prefetch instantiation of both kernel families was analysed (+ the row passes cut into verified segments)
     assert all(v == (1 if "_seg" in k else 5) for k, v in seen.items()), seen
     assert all(r["asm_loads"] >= 100 for r in res.values())  # prologue + first block + both steady-state forms, 16 slots + d1 words
