@@ -35,6 +35,18 @@
 #endif
 
 
+// Fault injection -- TEST BUILDS ONLY.  libadcensus_hip_faultinj.so (csrc/Makefile, target faultinj) is capi.hip compiled with
+// -DADC_FAULT_INJECTION=1 and linked with the product's kernel objects; the product library never defines it.  There every HIP
+// call of capi.hip's object-lifetime and Match path goes through ADC_HIP(call): the n-th one (ADC_TEST_FAIL_AT=<n> in the
+// environment, or adc_test_fail_at(n)) is NOT executed and reports hipErrorOutOfMemory -- the reference's contract for that is
+// `return false` (ADCensusStereo.cpp:31-40,71-76; SURVEY.md 8b "HIP failure -> false").  tests/test_gpu_faults.py.
+#ifdef ADC_FAULT_INJECTION
+extern "C" int adc_test_fault_now(void);
+#define ADC_HIP(call) (adc_test_fault_now() ? hipErrorOutOfMemory : (call))
+#else
+#define ADC_HIP(call) (call)
+#endif
+
 struct AdcParams {
     int W, H;
     int dmin, dmax, D; // D = dmax - dmin
@@ -52,6 +64,12 @@ struct adc_handle {
                         // the latency-bound refinement of one pair overlaps the streaming phase of the next
     hipEvent_t ev_in, ev_heavy_done;
     bool own_stream;
+    // Host callers: the left image is uploaded first and the kernels that need only the left image start while the right image is
+    // still on the bus -- it travels on a second stream (capi.hip: match_async_impl / run_heavy)
+    hipStream_t up_stream;
+    hipEvent_t ev_up_gate, ev_right;
+    const uint8_t* up_right_src; // != NULL: run_heavy uploads the right image from here once the left-image kernels are enqueued
+    int up_right_stage;          // ... through the pinned staging buffer (pageable source of an asynchronous call)
 
     // images + per-pixel maps
     uint8_t *img_l, *img_r;         // the pair being matched: the handle's own buffers, or the caller's (adc_match_device)
@@ -178,7 +196,10 @@ hipError_t adc_launch_gray_census(adc_handle* h);
 hipError_t adc_launch_cost(adc_handle* h, float* vol_out);
 hipError_t adc_launch_cost_records(adc_handle* h);
 int adc_agg_small_L(const adc_handle* h);
-hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps
+hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps (= _left + _rest)
+hipError_t adc_launch_arms_left(adc_handle* h); // what needs only the left image: packed pixels, arms, maxima, support counts
+hipError_t adc_launch_arms_rest(adc_handle* h); // what reads both images: colour-step maps (+ paper mode: right-image arms)
+hipError_t adc_launch_aggregate_tail(adc_handle* h); // the dividing H pass adc_launch_aggregate left to the scanline stage, as a launch of its own
 hipError_t adc_launch_records(adc_handle* h); // arms + counts -> packed aggregation records
 hipError_t adc_launch_aggregate(adc_handle* h, int iterations); // vol_a -> vol_a via vol_b
 hipError_t adc_launch_so_classes(adc_handle* h, hipStream_t stream);

@@ -12,8 +12,17 @@
 #include <vector>
 #include <new>
 #include <mutex>
+#include <atomic>
 
 static thread_local std::string g_last_error;
+
+#ifdef ADC_FAULT_INJECTION // (test builds only, adc_internal.h)
+static std::atomic<long> g_fi_calls{0};
+static std::atomic<long> g_fi_fail_at{[] { const char* e = getenv("ADC_TEST_FAIL_AT"); return e ? atol(e) : 0L; }()};
+extern "C" int adc_test_fault_now(void) { const long n = ++g_fi_calls; return n == g_fi_fail_at.load(); }
+extern "C" void adc_test_fail_at(long n) { g_fi_calls = 0; g_fi_fail_at = n; } // the n-th call from now on fails (0: none)
+extern "C" long adc_test_hip_calls(void) { return g_fi_calls.load(); }
+#endif
 
 // Host ranges the CALLER has page-locked for the library (adc_host_register): images / maps inside such a range are
 // transferred by DMA straight from / to the caller's memory, without the pinned staging copies.  Opt-in on purpose: a
@@ -37,7 +46,7 @@ static void set_error(const char* what, hipError_t e)
 }
 #define HIP_OK(call)                          \
     do {                                      \
-        hipError_t e__ = (call);              \
+        hipError_t e__ = ADC_HIP(call);       \
         if (e__ != hipSuccess) {              \
             set_error(#call, e__);            \
             return e__;                       \
@@ -275,13 +284,16 @@ adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int
     h->p.VPL = range <= 64 ? 1 : (range <= 128 ? 2 : (range <= 256 ? 4 : (range <= 512 ? 8 : (range <= 1024 ? 16 : 32))));
     h->p.Dp = 64 * h->p.VPL;
     h->p.opt = *opt;
-    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = ADC_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) == hipSuccess;
     h->own_stream = ok;
     if (ok) ok = (h->heavy = shared_heavy_stream(dev, h->stream)) != nullptr;
-    if (ok) ok = hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess;
-    if (ok) ok = hipEventCreateWithFlags(&h->ev_heavy_done, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; ok && i <= ADC_STAGE_COUNT; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
-    for (int i = 0; ok && i < 9; i++) ok = hipEventCreate(&h->ev_agg[i]) == hipSuccess;
+    if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming)) == hipSuccess;
+    if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_heavy_done, hipEventDisableTiming)) == hipSuccess;
+    if (ok) ok = ADC_HIP(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking)) == hipSuccess;
+    if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_up_gate, hipEventDisableTiming)) == hipSuccess;
+    if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_right, hipEventDisableTiming)) == hipSuccess;
+    for (int i = 0; ok && i <= ADC_STAGE_COUNT; i++) ok = ADC_HIP(hipEventCreate(&h->ev[i])) == hipSuccess;
+    for (int i = 0; ok && i < 9; i++) ok = ADC_HIP(hipEventCreate(&h->ev_agg[i])) == hipSuccess;
     if (ok) ok = alloc_all(h) == hipSuccess;
     if (ok) ok = upload_tables(h) == hipSuccess;
     if (!ok) {
@@ -300,6 +312,7 @@ void adc_destroy(adc_handle* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->heavy) hipStreamSynchronize(h->heavy);
+    if (h->up_stream) hipStreamSynchronize(h->up_stream);
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->so_seam, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->med_sink, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
@@ -312,6 +325,9 @@ void adc_destroy(adc_handle* h)
     for (int i = 0; i < 9; i++) if (h->ev_agg[i]) hipEventDestroy(h->ev_agg[i]);
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_heavy_done) hipEventDestroy(h->ev_heavy_done);
+    if (h->ev_up_gate) hipEventDestroy(h->ev_up_gate);
+    if (h->ev_right) hipEventDestroy(h->ev_right);
+    if (h->up_stream) hipStreamDestroy(h->up_stream);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -378,14 +394,11 @@ static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
         HIP_OK(hipMemsetAsync(h->armmax + 2, 0, 2 * sizeof(int), h->heavy)); // failed seams, "assumed ring too shallow" flag
         h->armmax_valid = 3; // the full ring: valid for every image
     } else {
-    HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
-    // ADC_FUSE_COST (default on): the cost volume is never written -- the first aggregation pass computes each cost
-    // in registers from packed pixel records (k_agg_march<.., COSTIN>); otherwise K2 writes it and pass 1 reads it back
-    if (fuse_cost_now) HIP_OK(adc_launch_cost_records(h));
-    else HIP_OK(adc_launch_cost(h, h->vol_a));
-    MARK(1, h->heavy);
-    HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
-    MARK(2, h->heavy);
+    // Stage order: what needs only the LEFT image first -- arms, support counts, aggregation records (CostAggregation's set-up,
+    // ADCensusStereo.cpp:92; cross_aggregator.cpp:76-86 builds the arms from the left image alone) --, then the right image of a
+    // host caller goes onto the bus on the second stream while those kernels run, then what reads both images (gray / census /
+    // cost records, ComputeCost :84; the colour-step maps of the scanline penalties).  No stage depends on that order.
+    HIP_OK(adc_launch_arms_left(h));
     {   // The maximum arm lengths decide the ring depth of the aggregation kernels and whether same-direction pass pairs
         // can share a launch (k_aggregate.hip).  The host does NOT wait for them: it assumes the maxima of the previous
         // Match of this handle (exact ring depth for that image), the small-ring kernels verify the assumption on the
@@ -404,6 +417,23 @@ static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
         }
     }
     HIP_OK(adc_launch_records(h));
+    MARK(1, h->heavy); // (end of the "arms" stage: collect_timings knows the order)
+    if (h->up_right_src) { // the right image: staged (pageable source of an asynchronous call) and sent on the second stream NOW
+        const size_t PB = (size_t)h->p.W * h->p.H * 3;
+        const uint8_t* from = h->up_right_src;
+        h->up_right_src = nullptr;
+        if (h->up_right_stage) { memcpy(h->pin_in + PB, from, PB); from = h->pin_in + PB; }
+        HIP_OK(hipMemcpyAsync(h->img_r, from, PB, hipMemcpyHostToDevice, h->up_stream));
+        HIP_OK(hipEventRecord(h->ev_right, h->up_stream));
+        HIP_OK(hipStreamWaitEvent(h->heavy, h->ev_right, 0));
+    }
+    HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
+    // ADC_FUSE_COST (default on): the cost volume is never written -- the first aggregation pass computes each cost
+    // in registers from packed pixel records (k_agg_march<.., COSTIN>); otherwise K2 writes it and pass 1 reads it back
+    if (fuse_cost_now) HIP_OK(adc_launch_cost_records(h));
+    else HIP_OK(adc_launch_cost(h, h->vol_a));
+    HIP_OK(adc_launch_arms_rest(h));
+    MARK(2, h->heavy);
     } // (!from_aggregation)
     h->fuse_cost = fuse_cost_now ? 1 : 0;
     h->fuse_agg_so = 1; // (the launcher decides: short-arm plan, arms <= 4, segmented row passes)
@@ -458,6 +488,7 @@ static void collect_timings(adc_handle* h)
         if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = -1.f;
         h->stage_ms[i] = ms;
     }
+    { const float t = h->stage_ms[0]; h->stage_ms[0] = h->stage_ms[1]; h->stage_ms[1] = t; } // run_heavy: the "arms" stage runs in front of "cost"
     float tot = 0.f;
     // average duration of a REGULAR aggregation pass (read V + write V); a fused first pass (write-only) is left out
     const int first = h->agg_first_fused ? 1 : 0;
@@ -478,11 +509,40 @@ static void collect_timings(adc_handle* h)
 static hipError_t enqueue_output(adc_handle* h)
 {
     const size_t P = (size_t)h->p.W * h->p.H;
-    if (h->async_dst && h->async_dst_direct == 1) return hipMemcpyAsync(h->async_dst, h->disp_l, P * 4, hipMemcpyDeviceToHost, h->stream); // page-locked by the caller
+    if (h->async_dst && h->async_dst_direct == 1) return ADC_HIP(hipMemcpyAsync(h->async_dst, h->disp_l, P * 4, hipMemcpyDeviceToHost, h->stream)); // page-locked by the caller
     if (h->async_dst && h->async_dst_direct == 2) return hipSuccess; // (pageable, ADC_HOST_DIRECT: copied by adc_wait after the stream has drained)
-    if (h->async_dst) return hipMemcpyAsync(h->pin_out, h->disp_l, P * 4, hipMemcpyDeviceToHost, h->stream);
-    if (h->device_dst) return hipMemcpyAsync(h->device_dst, h->disp_l, P * 4, hipMemcpyDeviceToDevice, h->stream);
+    if (h->async_dst) return ADC_HIP(hipMemcpyAsync(h->pin_out, h->disp_l, P * 4, hipMemcpyDeviceToHost, h->stream));
+    if (h->device_dst) return ADC_HIP(hipMemcpyAsync(h->device_dst, h->disp_l, P * 4, hipMemcpyDeviceToDevice, h->stream));
     return hipSuccess;
+}
+
+// A HIP call of a Match failed half-way (the reference's contract: Match returns false and the object stays usable,
+// ADCensusStereo.cpp:71-76).  Whatever was already enqueued is drained, every per-Match flag of the handle goes back to its idle
+// value -- a later Match must not find a half-described predecessor: a pending voting chain, a dropped aggregation pass the
+// scanline stage never consumed (round-5 advisor finding), speculation flags of launches that never ran -- and the caller's
+// buffers are forgotten.  What the handle has LEARNED from earlier pairs (arm maxima, chain budget) stays: it is verified on the
+// device for every pair anyway.
+static void abort_match(adc_handle* h)
+{
+    if (h->heavy) hipStreamSynchronize(h->heavy);
+    if (h->up_stream) hipStreamSynchronize(h->up_stream);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipGetLastError();
+    h->up_right_src = nullptr;
+    h->match_pending = 0;
+    h->irv_pending = 0;
+    h->so_agg_fused = 0;
+    h->fuse_cost = 0; h->fuse_agg_so = 0; h->fuse_wta = 0;
+    h->armmax_valid = 0;
+    h->agg_gate = 0;
+    h->wta_left_done = 0;
+    h->timings_pending = false;
+    h->force_median_fallback = 0;
+    h->async_dst = nullptr;
+    h->device_dst = nullptr;
+    if (h->pin_flags) { h->pin_flags[0] = 0; h->pin_flags[4] = h->pin_flags[5] = h->pin_flags[6] = h->pin_flags[7] = 0; }
+    if (h->img_l != h->img_l_own || h->img_r != h->img_r_own) { h->img_l = h->img_l_own; h->img_r = h->img_r_own; }
+    h->bgrx_valid = 0;
 }
 
 int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, void* d_disp)
@@ -493,10 +553,10 @@ int adc_match_device(adc_handle* h, const void* d_left, const void* d_right, voi
     // duration of Match, ADCensusStereo.cpp:78-79): no copy
     h->img_l = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_left));
     h->img_r = const_cast<uint8_t*>(static_cast<const uint8_t*>(d_right));
-    if (run_pipeline(h) != hipSuccess) return 2;
+    if (run_pipeline(h) != hipSuccess) { abort_match(h); return 2; }
     h->device_dst = d_disp;
     h->async_dst = nullptr;
-    if (enqueue_output(h) != hipSuccess) return 2;
+    if (enqueue_output(h) != hipSuccess) { set_error("adc_match_device: output copy", hipGetLastError()); abort_match(h); return 2; }
     return 0;
 }
 
@@ -518,20 +578,29 @@ static int match_async_impl(adc_handle* h, const uint8_t* left, const uint8_t* r
     // soon as the call returns, so they always stage the inputs (a DMA still in flight would read the refilled pixels).  The
     // OUTPUT map of a registered range is written in place by every entry point (it is the caller's until adc_wait anyway).
     const bool reg_in = sync_call && host_registered(left, P * 3) && host_registered(right, P * 3);
-    if (reg_in || direct) { // DMA from the caller's memory (page-locked by the caller: asynchronous; pageable: the runtime stages)
-        if (hipMemcpyAsync(h->img_l, left, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
-        if (hipMemcpyAsync(h->img_r, right, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
-    } else { // staging: the second image is copied while the first one is on the bus
-        memcpy(h->pin_in, left, P * 3);
-        if (hipMemcpyAsync(h->img_l, h->pin_in, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
-        memcpy(h->pin_in + P * 3, right, P * 3);
-        if (hipMemcpyAsync(h->img_r, h->pin_in + P * 3, P * 3, hipMemcpyHostToDevice, h->stream) != hipSuccess) return 2;
+    // The LEFT image goes first; run_heavy sends the right one on the handle's second stream once the kernels that need only the
+    // left image are enqueued (arms, support counts, aggregation records: they run while the right image is on the bus).  The
+    // second stream first waits for everything the handle has enqueued so far (the previous Match's readers of img_r).
+    if (ADC_HIP(hipEventRecord(h->ev_up_gate, h->stream)) != hipSuccess || ADC_HIP(hipStreamWaitEvent(h->up_stream, h->ev_up_gate, 0)) != hipSuccess) {
+        set_error("adc_match: upload gate", hipGetLastError());
+        abort_match(h);
+        return 2;
     }
-    if (run_pipeline(h) != hipSuccess) return 2;
+    const uint8_t* lsrc = left;
+    if (!(reg_in || direct)) { memcpy(h->pin_in, left, P * 3); lsrc = h->pin_in; } // staging (pageable source of an asynchronous call)
+    // (reg_in / direct: DMA from the caller's memory -- page-locked by the caller: asynchronous; pageable: the runtime stages)
+    if (ADC_HIP(hipMemcpyAsync(h->img_l, lsrc, P * 3, hipMemcpyHostToDevice, h->stream)) != hipSuccess) {
+        set_error("adc_match: upload of the left image", hipGetLastError());
+        abort_match(h);
+        return 2;
+    }
+    h->up_right_src = right;
+    h->up_right_stage = (reg_in || direct) ? 0 : 1;
+    if (run_pipeline(h) != hipSuccess) { abort_match(h); return 2; }
     h->async_dst = disp;
     h->async_dst_direct = host_registered(disp, P * 4) ? 1 : (direct ? 2 : 0);
     h->device_dst = nullptr;
-    if (enqueue_output(h) != hipSuccess) return 2;
+    if (enqueue_output(h) != hipSuccess) { set_error("adc_match: output copy", hipGetLastError()); abort_match(h); return 2; }
     return 0;
 }
 
@@ -565,7 +634,7 @@ int adc_wait(adc_handle* h)
 {
     if (!h) return 1;
     hipSetDevice(h->device);
-    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("adc_wait", hipGetLastError()); return 2; }
+    if (ADC_HIP(hipStreamSynchronize(h->stream)) != hipSuccess) { set_error("adc_wait", hipGetLastError()); abort_match(h); return 2; }
     // (1) the aggregation assumed the arm maxima of the previous Match; a longer arm raised the flag and the pass was
     //     skipped: redo with the full ring (valid for every image).
     // (1b) a row of the scanline passes was cut into segments and a segment's warm-up did not reach the state of the full
@@ -577,17 +646,20 @@ int adc_wait(adc_handle* h)
     //     seam count is looked at again behind the redo.
     if (h->pin_flags) {
         for (int attempt = 0; attempt < 2 && (h->pin_flags[7] != 0 || h->pin_flags[6] != 0); attempt++) {
+            // (round-5 advisor finding) a too-shallow ring skipped aggregation passes: the row passes and their seam check then ran
+            // on a stale volume -- a seam that failed THERE says nothing about this image and must not cost 64 Matches of whole
+            // rows (which would also switch the fused tail pass off); the redo re-checks the seams on the real volume
             if (h->pin_flags[7] != 0) { h->arm_redos++; h->arm_known = 0; }
-            if (h->pin_flags[6] != 0) { h->so_seam_redos++; h->so_seg_off = 64; }
+            else if (h->pin_flags[6] != 0) { h->so_seam_redos++; h->so_seg_off = 64; }
             if (h->so_seg_off < 1) h->so_seg_off = 1; // whole rows in every redo
             const bool partial = h->agg_first_fused != 0 && !(h->paper & ADC_PAPER_RIGHT_ARMS);
             if (partial) h->redo_partial++;
             hipError_t e = run_pipeline(h, partial);
             if (e == hipSuccess) e = enqueue_output(h);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { set_error("adc_wait: redo (full aggregation ring / whole scanline rows)", e); return 2; }
+            if (e == hipSuccess) e = ADC_HIP(hipStreamSynchronize(h->stream));
+            if (e != hipSuccess) { set_error("adc_wait: redo (full aggregation ring / whole scanline rows)", e); abort_match(h); return 2; }
         }
-        if (h->pin_flags[7] != 0 || h->pin_flags[6] != 0) { g_last_error = "adc_wait: redo did not clear the speculation flags"; return 2; }
+        if (h->pin_flags[7] != 0 || h->pin_flags[6] != 0) { g_last_error = "adc_wait: redo did not clear the speculation flags"; abort_match(h); return 2; }
         h->armmax_host[0] = h->pin_flags[4];
         h->armmax_host[1] = h->pin_flags[5];
         h->arm_known = 1;
@@ -619,24 +691,24 @@ int adc_wait(adc_handle* h)
     if (e == hipSuccess && continued) {
         e = run_refine_tail(h);
         if (e == hipSuccess) e = enqueue_output(h);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = ADC_HIP(hipStreamSynchronize(h->stream));
     }
-    if (e != hipSuccess) { set_error("adc_wait: region voting continuation", e); return 2; }
+    if (e != hipSuccess) { set_error("adc_wait: region voting continuation", e); abort_match(h); return 2; }
     // (3) a median band gave up waiting for its upstream band: the map is incomplete -- redo the filter with the
     //     single-workgroup kernel (no inter-workgroup dependency) and deliver that result
     if (h->pin_flags && (h->pin_flags[0] != 0 || h->force_median_fallback)) {
         e = adc_median_fallback(h); // (looks at pin_flags[0]: 2 = a speculative seam differed -> chained form first)
         h->pin_flags[0] = 0;
         if (e == hipSuccess) e = enqueue_output(h);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = ADC_HIP(hipStreamSynchronize(h->stream));
         h->median_fallbacks++;
-        if (e != hipSuccess) { set_error("adc_wait: median fallback", e); return 2; }
+        if (e != hipSuccess) { set_error("adc_wait: median fallback", e); abort_match(h); return 2; }
     }
     h->force_median_fallback = 0;
     if (h->med_spec_off > 0 && h->med_spec_last == 0) h->med_spec_off--;
     if (h->async_dst) {
         if (h->async_dst_direct == 2) {
-            if (hipMemcpy(h->async_dst, h->disp_l, (size_t)h->p.W * h->p.H * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_error("adc_wait: copy-out", hipGetLastError()); return 2; }
+            if (ADC_HIP(hipMemcpy(h->async_dst, h->disp_l, (size_t)h->p.W * h->p.H * 4, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("adc_wait: copy-out", hipGetLastError()); abort_match(h); return 2; }
         } else if (h->async_dst_direct == 0) {
             memcpy(h->async_dst, h->pin_out, (size_t)h->p.W * h->p.H * 4);
         }

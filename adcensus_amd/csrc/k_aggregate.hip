@@ -949,6 +949,7 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     }
     h->agg_first_fused = 0;
     h->agg_dual_last = 0;
+    h->so_agg_fused = 0; // (round-5 advisor finding: a Match that failed between this stage and the scanline stage must not leave it set)
     hipError_t e = hipSuccess;
     AggSeq seq;
     // Two plans (a stream that alternates between short-arm and long-arm images, h->agg_dual > 0; pipeline only: the arm maxima
@@ -993,5 +994,18 @@ hipError_t adc_launch_aggregate(adc_handle* h, int iterations)
     }
     // the result must be in vol_a (cost_aggr_): swap the two volume pointers if it ended up in the other one
     if (e == hipSuccess && seq.result != h->vol_a) { h->vol_b = h->vol_a; h->vol_a = seq.result; }
+    return e;
+}
+
+// The dividing H pass of the last iteration that adc_launch_aggregate left to the scanline stage (so_agg_fused), as a launch of
+// its own: what run_so falls back to when its segment plan at scanline time cannot take the pass over after all (round-5 advisor
+// finding: that used to fail the Match).  Full ring: valid whatever the arms are.
+hipError_t adc_launch_aggregate_tail(adc_handle* h)
+{
+    const int keep = h->armmax_valid;
+    h->armmax_valid = 0;
+    const hipError_t e = launch_pass<false, true>(h, h->vol_a, h->vol_b, false, 2);
+    h->armmax_valid = keep;
+    if (e == hipSuccess) { float* t = h->vol_a; h->vol_a = h->vol_b; h->vol_b = t; }
     return e;
 }

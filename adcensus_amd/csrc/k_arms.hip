@@ -149,7 +149,10 @@ hipError_t adc_launch_records(adc_handle* h)
     return hipGetLastError();
 }
 
-hipError_t adc_launch_arms(adc_handle* h)
+// The part of the arms stage that needs only the LEFT image (the aggregation arms come from the left image alone,
+// cross_aggregator.cpp:76-86): packed pixels, arms + image-wide maxima, support counts.  The pipeline runs it FIRST, while the right
+// image of a host caller is still on the bus (capi.hip: run_heavy).
+hipError_t adc_launch_arms_left(adc_handle* h)
 {
     const AdcParams& p = h->p;
     dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
@@ -160,6 +163,14 @@ hipError_t adc_launch_arms(adc_handle* h)
                        p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2, h->armmax);
     hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
                        p.W, p.H);
+    return hipGetLastError();
+}
+// ... and the part that reads BOTH images: the colour-step maps of the scanline penalties (scanline_optimizer.cpp:114-126), and
+// the right-image arms of the opt-in paper mode.
+hipError_t adc_launch_arms_rest(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     if ((h->paper & ADC_PAPER_RIGHT_ARMS) && h->arms_r) { // opt-in paper mode (k_paper.hip): the same arms on the RIGHT image
         hipLaunchKernelGGL(k_pack_bgr, dim3((p.W * p.H + 255) / 256), dim3(256), 0, h->heavy, h->img_r, h->bgrx_r, p.W * p.H);
         hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->bgrx_r, reinterpret_cast<uchar4*>(h->arms_r), p.W, p.H,
@@ -169,4 +180,9 @@ hipError_t adc_launch_arms(adc_handle* h)
     hipLaunchKernelGGL(k_color_diffs, grid2, block, 0, h->heavy, h->img_l, h->img_r, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh,
                        h->cdiff_rv, p.W, p.H);
     return hipGetLastError();
+}
+hipError_t adc_launch_arms(adc_handle* h) // (the whole stage: debug surface)
+{
+    const hipError_t e = adc_launch_arms_left(h);
+    return e != hipSuccess ? e : adc_launch_arms_rest(h);
 }

@@ -596,23 +596,6 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         cwn += 1;                                                                                              \
         gi++;                                                                                                  \
     } while (0)
-#ifdef SO_PROXY_AGG
-#define SO_PROXY_STEP(E)                                                                                       \
-    do {                                                                                                       \
-        _Pragma("unroll") for (int t_ = 8; t_ > 0; t_--)                                                       \
-            _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) prx[t_][k_] = prx[t_ - 1][k_];                  \
-        _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) prx[0][k_] = (E).c[k_];                             \
-        const int lo_ = (E).c1 & 3, hi_ = 4 + (((E).c1 >> 2) & 3); /* a wave-uniform span of 2 .. 8 ring entries */ \
-        const float cnt_ = (float)(1 + (((E).c1 >> 4) & 15));                                                  \
-        _Pragma("unroll") for (int k_ = 0; k_ < VPL; k_++) {                                                   \
-            float acc_ = 0.0f;                                                                                 \
-            _Pragma("unroll") for (int t_ = 0; t_ < 9; t_++) acc_ += (t_ >= lo_ && t_ <= hi_) ? prx[t_][k_] : 0.0f; \
-            (E).c[k_] = (E).c[k_] + 0.0f * (acc_ / cnt_);                                                      \
-        }                                                                                                      \
-    } while (0)
-#else
-#define SO_PROXY_STEP(E) do { } while (0)
-#endif
 // take element U (and, on the first step of a group, the group's d1 word) after waiting for <= WAITN younger ops
 #define SO_TAKE(U, WAITN, E)                                                                                   \
     do {                                                                                                       \
@@ -659,7 +642,6 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
         else { (E).c[0] = tc_.x; (E).c[VPL - 1] = tc_.y; }                                                     \
         (E).rb[0] = tr_;                                                                                       \
         (E).c1 = (int)((cw >> (8 * ((U)&3))) & 0xffu);                                                         \
-        SO_PROXY_STEP(E);                                                                                      \
         if constexpr (AGG) { /* (E).c holds the RAW element e + SO_AGG_LA: push it, aggregate element e = e0 + i + U */ \
             SO_AGG_PUSH((E).c);                                                                                \
             SO_AGG_EVAL(e0 + i + (U), (E).c);                                                                  \
@@ -696,17 +678,6 @@ __device__ __forceinline__ void so_body(const float* __restrict__ src, float* __
 #define SO_LAST4(G) SO_LAST(4 * (G)) SO_LAST(4 * (G) + 1) SO_LAST(4 * (G) + 2) SO_LAST(4 * (G) + 3)
         static_assert(PF == 16, "wait counts and the unrolled groups are written for 16 elements / 4 groups in flight");
         uint32_t cw = 0; // d1 word of the current group
-#ifdef SO_PROXY_AGG
-        // TIMING PROXY (tools/build_variant.sh, never in the product; profiles/r5_ab_fusion_proxy.txt): what would a pass cost if
-        // it ALSO aggregated its input?  Per step a register ring of 9 pixel vectors shifts, the ordered sum over a wave-uniform
-        // span of it, a correctly rounded division -- fed into the recurrence through c + 0 * q (results unchanged; without
-        // fast-math the compiler cannot drop it).  Measured before the fused row pass below (AGG) was built.
-        float prx[9][VPL];
-#pragma unroll
-        for (int t_ = 0; t_ < 9; t_++)
-#pragma unroll
-            for (int k_ = 0; k_ < VPL; k_++) prx[t_][k_] = 0.0f;
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // start the manual bookkeeping from an empty queue
 #pragma unroll
         for (int G = 0; G < NG; G++) { // prologue, same order as the steady state without the stores
@@ -1053,9 +1024,14 @@ static hipError_t run_so(adc_handle* h, int passes)
     const int nseg = (passes >= 2 && so_use_dpp()) ? adc_so_segments(h, &warm) : 1;
     h->so_nseg_last = nseg;
     if (e == hipSuccess && nseg > 1) e = hipMemsetAsync(h->armmax + 2, 0, sizeof(int), h->heavy);
-    const bool agg = h->so_agg_fused != 0; // vol_a holds the volume BEFORE the last aggregation pass (adc_launch_aggregate dropped it)
+    bool agg = h->so_agg_fused != 0; // vol_a holds the volume BEFORE the last aggregation pass (adc_launch_aggregate dropped it)
     h->so_agg_fused = 0;
-    if (agg && (nseg <= 1 || passes < 1)) return hipErrorInvalidValue;
+    // (round-5 advisor finding) adc_launch_aggregate asked adc_so_can_fuse_agg at ITS time; should the plan here differ after all
+    // (whole rows, the pinned family, a single pass), the dropped pass runs as a launch of its own instead of failing the Match
+    if (agg && e == hipSuccess && (nseg <= 1 || passes < 1 || VPL != 2 || so_uses_pin(h->p.H, nseg))) {
+        e = adc_launch_aggregate_tail(h);
+        agg = false;
+    }
     if (e == hipSuccess) e = launch_so<VPL>(h, h->vol_a, h->vol_b, false, +1, nullptr, nseg, warm, agg);
     if (e == hipSuccess && passes >= 2) e = launch_so<VPL>(h, h->vol_b, h->vol_a, false, -1, nullptr, nseg, warm);
     if (e == hipSuccess && nseg > 1) {

@@ -37,8 +37,14 @@ Prints ONE JSON line (rank 0).  Extra objects:
   throughput_mode (N = 1) the same batch with 3 pipelines in flight per GPU.
   scaling_reference (N > 1) rank 0 ALONE on its GPU with the same pairs per GPU and the same number of pipelines, measured
                  after the farm (the other ranks idle at a barrier): the 1-GPU number this box gives for the N-GPU line.
+  match_host     (N = 1) THE DROP-IN FIGURE: pairs/s and ms/pair of ADCensusStereo::Match == adc_match(host, host, host), pageable
+                 and caller-registered buffers, both workloads (`value` above is adc_match_device: images / map resident in HBM).
   cpu_baseline   the reference CPU path (oracle/_ref, kind "reference"; the plain-C port if absent) timed on this host,
                  1 thread, on the WHOLE pair 0 of the batch (--cpu-rows R: the top R rows, scaled).
+  cpu_baseline_all_cores  N independent reference processes side by side (pairs are independent; SURVEY.md 8d "all host cores"),
+                 N stated; N = min(16, host cores, what the free memory holds at 2.6 GB each).
+Exit code: 0; 3 when RCCL was requested and the job had to run its barrier / reductions over gloo instead (the line is still
+printed, with config.comm_backend saying so) -- a broken RCCL must not look like a pass.
 """
 import argparse
 import json
@@ -96,6 +102,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample strip (0 = the whole frame, ~20 s)")
     ap.add_argument("--cpu-baseline-structured", action="store_true",
                     help="also time the reference on the structured pair (SURVEY 8d S2; ~35 s on one host core) -> structured.cpu_baseline")
+    ap.add_argument("--cpu-all-cores", type=int, default=16,
+                    help="processes of the all-host-cores CPU figure (0 = skip; clamped to the host's cores and free memory)")
     ap.add_argument("--no-cone-leg", action="store_true", help="skip the Cone 450x375 D=64 leg (BASELINE.json configs[0] / [1])")
     ap.add_argument("--write-digests", default="", help="write {pair id: sha256} of the batch outputs to this file (N = 1)")
     return ap.parse_args()
@@ -569,6 +577,7 @@ def main():
             got2 = {pid: farm.digest(m2.output(pid).tobytes()) for pid in ids2}
             out[other]["reference_check"] = {"pairs": len(got2), "reference_checked": sum(1 for k in got2 if str(k) in ref2),
                                              "reference_mismatches": sorted(k for k, v in got2.items() if str(k) in ref2 and ref2[str(k)] != v)}
+        out[other]["voting"] = voting_stats(m2)
         # ---- mixed stream: the two workloads alternating through 3 pipelines (what a real image stream looks like to the
         #      history-dependent parts of the pipeline: assumed ring depth, voting launch budget); device-resident
         if not a.no_mixed_leg:
@@ -585,11 +594,28 @@ def main():
         out["throughput_mode"] = {"value": round(t3 / e3, 4), "unit": "pairs/s", "in_flight_per_gpu": 3, "steps": n3,
                                   "note": "same workload, three pipelines (streams) in flight; per-kernel durations are then inflated by co-running kernels, which is why the headline region uses one"}
         m3.release()
+        # ---- the same two legs on the OTHER workload (round-5 review: the natural-image numbers belong into this line)
+        out[other]["host_inclusive"] = host_inclusive_leg(A, local_rank, W, H, D, other, max(5, min(10, a.steps)))
+        n4 = max(6, min(18, a.steps))
+        m4, e4, t4, _, _ = measure_workload(A, local_rank, W, H, D, other, n4, 3, 3, ids2[:6])
+        out[other]["throughput_mode"] = {"value": round(t4 / e4, 4), "unit": "pairs/s", "in_flight_per_gpu": 3, "steps": n4,
+                                         "async_fallbacks": m4.fallbacks}
+        m4.release()
+        # ---- THE DROP-IN FIGURE in one place: what a user of the reference gets from ADCensusStereo::Match(host, host, host)
+        def brief(o):
+            return {"value": o["value"], "unit": "pairs/s", "ms_per_pair": o["ms_per_pair"], "steps": o["steps"]}
+        out["match_host"] = {"entry_point": "ADCensusStereo::Match == adc_match(left, right, disp): host images in, host map out, synchronous "
+                                            "(upload of 12.4 MB, every kernel, download of 8.3 MB inside the timed call)",
+                             a.workload: {"pageable": brief(out["host_inclusive"]), "registered": brief(out["host_inclusive_registered"])},
+                             other: {"pageable": brief(out[other]["host_inclusive"])},
+                             "note": "`value` of this line is adc_match_device (BASELINE.json: inputs resident in HBM when the timed region starts)"}
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(make_pair(a.workload, W, H, D, 0), D, a.cpu_rows, H)
             if a.cpu_baseline_structured and "structured" in out:
                 out["structured"]["cpu_baseline"] = cpu_baseline(make_pair("structured", W, H, D, 0), D, a.cpu_rows, H)
+            if a.cpu_all_cores > 1 and not a.no_extra_legs:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(a.workload, W, H, D, a.cpu_all_cores)
         if world == 1 and not a.no_cone_leg and not a.no_extra_legs:
             out["cone"] = cone_leg(A, local_rank, with_cpu=not a.no_cpu_baseline)
         sys.stdout.flush()
@@ -603,6 +629,18 @@ def main():
         os.dup2(2, 1)  # (anything printed during teardown must not follow the JSON line)
     if dist is not None:
         dist.destroy_process_group()
+    if backend is not None and "RCCL failed" in backend:
+        sys.exit(3)  # (every rank: the communicator that was asked for did not carry the job)
+
+
+def voting_stats(m):
+    """Rounds (kernels of the chain that evaluated votes) and vote evaluations of the LAST Match of pipeline 0 -- the figures a
+    slower box or another dispatch order of the voting chain would move first (round-5 advisor finding)."""
+    try:
+        r, e = m.handles[0].voting_stats()
+        return {"rounds_last_match": r, "evaluations_last_match": e, "chain_budget_next": int(m.handles[0].debug_counter(3))}
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def mixed_stream_leg(A, device, W, H, D, m_other, other, other_ids, workload, n):
@@ -780,6 +818,57 @@ def cpu_model():
     except Exception:
         pass
     return "unknown"
+
+
+def cpu_baseline_all_cores(workload, W, H, D, want):
+    """SURVEY.md 8d, optional "all host cores" figure: N independent reference processes side by side, each matching its own
+    pair (seed 12345 + i / 777 + i) once; value = N / wall time of the slowest.  N = min(want, cores, free memory / 2.6 GB)."""
+    cores = os.cpu_count() or 1
+    try:
+        with open("/proc/meminfo") as f:
+            avail_kb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0]
+    except Exception:  # noqa: BLE001
+        avail_kb = 8 << 20
+    per_proc = 2.6e9 * (W * H * D) / (1920.0 * 1080 * 128) + 0.4e9
+    n = int(max(1, min(want, cores, (0.6 * avail_kb * 1024.0) // per_proc)))
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "import bench\nfrom oracle import pyoracle\n"
+            "orc = pyoracle.load('auto'); pair = bench.make_pair(%r, %d, %d, %d, int(sys.argv[1]))\n"
+            "print('READY', flush=True); sys.stdin.readline()\n"
+            "t0 = time.perf_counter(); orc.match(pair[0], pair[1], pyoracle.Option(max_disparity=%d)); print('SECS %%.3f' %% (time.perf_counter() - t0), flush=True)\n"
+            % (ROOT, workload, W, H, D, D))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(n)]
+    try:
+        for pr in procs:  # every process has built its pair and loaded the oracle before the clock starts
+            while True:
+                line = pr.stdout.readline()
+                if not line or line.startswith("READY"):
+                    break
+        t0 = time.perf_counter()
+        for pr in procs:
+            pr.stdin.write("go\n")
+            pr.stdin.flush()
+        secs = []
+        for pr in procs:
+            for line in pr.stdout:
+                if line.startswith("SECS"):
+                    secs.append(float(line.split()[1]))
+                    break
+        wall = time.perf_counter() - t0
+    finally:
+        for pr in procs:
+            try:
+                pr.stdin.close()
+                pr.wait(timeout=30)
+            except Exception:  # noqa: BLE001
+                pr.kill()
+    if len(secs) != n:
+        return {"value": None, "error": "%d of %d reference processes finished" % (len(secs), n)}
+    return {"value": round(n / wall, 5), "unit": "pairs/s", "cores": n, "processes": n, "host_cores": cores, "cpu_model": cpu_model(),
+            "wall_s": round(wall, 2), "s_per_pair_per_process": [round(min(secs), 2), round(max(secs), 2)],
+            "sample": "%d independent single-threaded reference processes side by side, one whole %s pair each (seeds differ), started together; "
+                      "value = processes / wall time of the slowest" % (n, workload)}
 
 
 def cpu_baseline(pair, D, rows, H):

@@ -190,3 +190,21 @@ def test_bench_pull_queue_two_ranks_gloo_stub():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["farm_check"]["ok"]
     assert d["config"]["comm"]["ranks_in_all_reduce"] == 2
+
+
+def test_bench_exits_nonzero_when_rccl_was_asked_for_and_gloo_carried_the_job():
+    """Round-5 review: on the first real multi-GPU run a broken RCCL must not look like a pass.  Here (no GPU) the RCCL communicator
+    cannot be created: the job still runs over gloo and prints its line -- labelled -- but the exit code is 3 (torchrun reports
+    the failing ranks; the re-exec'ing parent hands torchrun's code on)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ADC_BENCH_MATCHER_MODULE="tests.bench_stub", PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "ADC_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "64", "--height", "48",
+                        "--disp", "16", "--spinup-ms", "0", "--no-host-leg"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["config"]["comm_backend"] == "gloo (RCCL failed)" and d["farm_check"]["ok"]

@@ -555,7 +555,7 @@ def test_aggregation_launch_gate(emul):
 
 
 def test_voting_tiles_partition_the_image(emul):
-    """irv_plan.h: the tiles of the voting chain's workgroups (bands of 16 rows, a band belongs to one XCD) cover every pixel
+    """irv_plan.h: the tiles of the voting chain's workgroups (bands of IRV_BAND = 8 rows, a band belongs to one XCD) cover every pixel
     exactly once and fit the workgroup's list segment -- for the grids the launcher uses and odd shapes."""
     emul.emul_irv_tile_partition.restype = C.c_long
     for w, h in ((1920, 1080), (1242, 375), (450, 375), (1, 1), (1, 40), (33, 17), (7, 129), (640, 16)):
