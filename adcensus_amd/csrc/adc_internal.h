@@ -149,6 +149,7 @@ struct adc_handle {
     uint16_t* st16;      // region voting: 16-bit state map [H][st16_pitch] {bin:11 | iteration of the fill:3 | list:2} (irv_plan.h)
     int st16_pitch;      // row pitch of st16 in elements (multiple of 8: rows start 16-byte aligned)
     float* disp_vote;    // the map the voting chain works on (copy of the LR-checked map, copied back when the chain ends)
+    int irv_xcd_mode;    // 1: the chain's work list uses the band -> XCD sweep layout (the device's workgroup -> XCD mapping was probed)
     int irv_grid;        // workgroups of the voting chain (adc_irv_grid, fixed per handle: the work-list layout depends on it)
     int irv_budget;      // kernels the next Match enqueues for the voting chain (adapted from the last Matches)
     int irv_used_hist[8]; // kernels the last 8 Matches needed
@@ -214,6 +215,7 @@ hipError_t adc_paper_aggregate(adc_handle* h, int iterations);  // k_paper.hip: 
 hipError_t adc_paper_accumulate(adc_handle* h, float* acc, const float* src, int first, int last);
 hipError_t adc_launch_lrcheck(adc_handle* h);
 size_t adc_itp_cell_bytes(int W, int H);       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
+int adc_irv_probe_xcd_mode(int device);         // 1 iff workgroup g of a launch runs on XCD g % 8 on this device (probed once)
 int adc_irv_grid(size_t pixels);                // workgroups of the voting chain for an image of this size
 size_t adc_irv_waves(int grid);                // ints of the chain's statistics block (per-wave counters + per-workgroup segment lengths)
 size_t adc_irv_list_entries(int W, int H, int D, int grid);     // capacity of the voting work list (one segment per workgroup)

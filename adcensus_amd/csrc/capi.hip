@@ -159,6 +159,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->elig, P + 64)); // (LR check: invalid mask, 1 byte per pixel; then the voting chain's bitmap of listed pixels, whole 64-bit words)
     HIP_OK(hipMalloc(&h->irv_bbox, P * 4));
     h->irv_grid = adc_irv_grid(P);
+    h->irv_xcd_mode = adc_irv_probe_xcd_mode(h->device);
     HIP_OK(hipMalloc(&h->vote_list, adc_irv_list_entries(p.W, p.H, p.D, h->irv_grid) * 16)); // int4 per entry, one segment per workgroup (irv_plan.h)
     HIP_OK(hipMemset(h->vote_list, 0xFF, adc_irv_list_entries(p.W, p.H, p.D, h->irv_grid) * 16)); // every slot = IRV_LIST_END
     HIP_OK(hipMalloc(&h->vote_evals_arr, adc_irv_waves(h->irv_grid) * sizeof(int32_t)));
@@ -1068,6 +1069,7 @@ int64_t adc_debug_counter(adc_handle* h, int which)
     case 11: return h->redo_partial;  // redos that restarted at the aggregation (not the whole Match)
     case 12: return h->agg_dual;      // > 0: the next Match enqueues both plans
     case 13: return h->agg_so_fusions; // Matches whose last aggregation pass ran inside the first scanline pass
+    case 14: return h->irv_xcd_mode;   // the voting chain sweeps band -> XCD (the mapping was probed on this device)
     case 3: return h->irv_budget;
     case 7: return h->med_spec_fails;
     case 8: return h->med_spec_last;

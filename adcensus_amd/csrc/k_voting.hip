@@ -31,6 +31,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 
 #include "irv_plan.h"
 
@@ -508,12 +509,46 @@ static int irv_wpb(int D)
 }
 size_t adc_irv_waves(int grid) { return (size_t)IRV_MAXW * grid + (size_t)grid; } // per-wave evaluation counters + per-workgroup segment lengths
 // entries the work list must hold: one segment of whole batches per workgroup of the chain's grid (irv_plan.h: irv_seg_cap)
-static int irv_xcd_mode()
+// The band -> XCD sweep (irv_plan.h: irv_wg_tile) assumes that workgroup g of a launch runs on XCD g % 8.  Exactness never depends
+// on it, but under another partition mode / XCD count / dispatch order the in-kernel sweep would silently degrade to Jacobi rounds
+// (round-5 advisor finding).  So the assumption is PROBED once per device: 1024 workgroups report the XCD they run on
+// (HW_REG_XCC_ID); the sweep layout is used iff all workgroups with the same g % 8 share one XCD.  ADC_IRV_XCD=0 / 1 overrides.
+__global__ __launch_bounds__(64) void k_irv_xcc_probe(int* __restrict__ out)
 {
-    static const int v = [] { const char* e = getenv("ADC_IRV_XCD"); return e ? atoi(e) : 1; }();
-    return v;
+    uint32_t id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(id & 15u);
 }
-size_t adc_irv_list_entries(int W, int H, int D, int grid)
+int adc_irv_probe_xcd_mode(int device)
+{
+    static const int env = [] { const char* e = getenv("ADC_IRV_XCD"); return e ? atoi(e) : -1; }();
+    if (env >= 0) return env;
+    static std::mutex mu;
+    static int cached[64];
+    static bool have[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    const int dv = (device >= 0 && device < 64) ? device : 0;
+    if (have[dv]) return cached[dv];
+    int mode = 0;
+    int* d = nullptr;
+    int hst[1024];
+    if (hipMalloc(&d, sizeof(hst)) == hipSuccess) {
+        if (hipMemset(d, 0xFF, sizeof(hst)) == hipSuccess) {
+            hipLaunchKernelGGL(k_irv_xcc_probe, dim3(1024), dim3(64), 0, 0, d);
+            if (hipGetLastError() == hipSuccess && hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost) == hipSuccess) {
+                mode = 1;
+                for (int g = 0; g < 1024; g++)
+                    if (hst[g] < 0 || hst[g] != hst[g & 7]) mode = 0;
+            }
+        }
+        hipFree(d);
+    }
+    (void)hipGetLastError();
+    cached[dv] = mode;
+    have[dv] = true;
+    return mode;
+}
+size_t adc_irv_list_entries(int W, int H, int D, int grid) // (room for either layout)
 {
     return (size_t)grid * (size_t)adc_imax((int)irv_seg_cap(W, H, grid, irv_wpb(D), 0), (int)irv_seg_cap(W, H, grid, irv_wpb(D), 1));
 }
@@ -528,7 +563,7 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count)
                            h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
                            reinterpret_cast<const uint32_t*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
                            p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr,
-                           (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, irv_xcd_mode()), irv_xcd_mode(), h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
+                           (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, h->irv_xcd_mode), h->irv_xcd_mode, h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
                            reinterpret_cast<unsigned long long*>(h->elig));
     return hipGetLastError();
 }

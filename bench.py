@@ -638,7 +638,8 @@ def voting_stats(m):
     slower box or another dispatch order of the voting chain would move first (round-5 advisor finding)."""
     try:
         r, e = m.handles[0].voting_stats()
-        return {"rounds_last_match": r, "evaluations_last_match": e, "chain_budget_next": int(m.handles[0].debug_counter(3))}
+        return {"rounds_last_match": r, "evaluations_last_match": e, "chain_budget_next": int(m.handles[0].debug_counter(3)),
+                "band_to_xcd_sweep": int(m.handles[0].debug_counter(14))}
     except Exception:  # noqa: BLE001
         return None
 

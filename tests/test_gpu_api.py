@@ -495,3 +495,15 @@ def test_registered_host_buffers(hip, oracle):
             A.host_unregister(arr)
     assert A.lib().adc_host_unregister(l.ctypes.data) == 1  # unknown pointer
     st.Release()
+
+
+def test_voting_sweep_layout_matches_the_device(hip):
+    """The voting chain's band -> XCD sweep (irv_plan.h) assumes workgroup g runs on XCD g % 8; adc_create probes that on the
+    device (HW_REG_XCC_ID of 1024 workgroups) and falls back to the plain layout otherwise (round-5 advisor finding).  On an
+    MI355X in its default partition mode the probe must succeed -- if this fails, the chain still gives exact results (the
+    random-geometry tests run either way) but needs more rounds: look at bench.py's `voting` objects."""
+    st = hip.ADCensusStereo(device=0)
+    assert st.Initialize(64, 48, hip.ADCensusOption(max_disparity=16))
+    mode = st.debug_counter(14)
+    st.Release()
+    assert mode == 1
