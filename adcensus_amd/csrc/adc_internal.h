@@ -64,12 +64,6 @@ struct adc_handle {
                         // the latency-bound refinement of one pair overlaps the streaming phase of the next
     hipEvent_t ev_in, ev_heavy_done;
     bool own_stream;
-    // Host callers: the left image is uploaded first and the kernels that need only the left image start while the right image is
-    // still on the bus -- it travels on a second stream (capi.hip: match_async_impl / run_heavy)
-    hipStream_t up_stream;
-    hipEvent_t ev_up_gate, ev_right;
-    const uint8_t* up_right_src; // != NULL: run_heavy uploads the right image from here once the left-image kernels are enqueued
-    int up_right_stage;          // ... through the pinned staging buffer (pageable source of an asynchronous call)
 
     // images + per-pixel maps
     uint8_t *img_l, *img_r;         // the pair being matched: the handle's own buffers, or the caller's (adc_match_device)
@@ -159,6 +153,7 @@ struct adc_handle {
     int irv_overflows;   // how often adc_wait had to continue the chain (budget too small)
     float *tail_disp_l, *tail_disp_tmp; // buffer roles at the start of the stages behind the voting (for a redo)
     int32_t* vote_counters; // voting chain control block (state slots + accumulator ring), median progress words at [160..]
+    uint32_t* irv_px;    // per-pixel change bitmap of the voting rounds, IRV_PX_PLANES planes (slack budgets, irv_plan.h)
     uint8_t* chg_a;      // change-tile map of the voting rounds: one byte stamp per 8x8 tile, row pitch chg_pitch
     int chg_pitch;
     uint8_t* edge;       // discontinuity adjustment edge mask
@@ -218,6 +213,7 @@ size_t adc_itp_cell_bytes(int W, int H);       // byte maps of the interpolation
 int adc_irv_probe_xcd_mode(int device);         // 1 iff workgroup g of a launch runs on XCD g % 8 on this device (probed once)
 int adc_irv_grid(size_t pixels);                // workgroups of the voting chain for an image of this size
 size_t adc_irv_waves(int grid);                // ints of the chain's statistics block (per-wave counters + per-workgroup segment lengths)
+size_t adc_irv_px_words(int W, int H);          // dwords of the per-pixel change bitmap (all planes)
 size_t adc_irv_list_entries(int W, int H, int D, int grid);     // capacity of the voting work list (one segment per workgroup)
 hipError_t adc_run_region_voting(adc_handle* h); // enqueue only (device-driven chain with a launch budget)
 hipError_t adc_voting_finish(adc_handle* h, int* continued); // after a sync: continue the chain if the budget was too small

@@ -181,6 +181,8 @@ static hipError_t alloc_all(adc_handle* h)
     h->chg_pitch = (((p.W + 7) / 8 + 3) & ~3) + 16;
     const size_t tiles = (size_t)h->chg_pitch * ((p.H + 7) / 8) + 64;
     HIP_OK(hipMalloc(&h->chg_a, 2 * tiles)); // two planes (round parity)
+    HIP_OK(hipMalloc(&h->irv_px, adc_irv_px_words(p.W, p.H) * sizeof(uint32_t)));
+    HIP_OK(hipMemset(h->irv_px, 0, adc_irv_px_words(p.W, p.H) * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&h->edge, P));
     HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
@@ -290,9 +292,6 @@ adc_handle* adc_create(int32_t width, int32_t height, const adc_option* opt, int
     if (ok) ok = (h->heavy = shared_heavy_stream(dev, h->stream)) != nullptr;
     if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming)) == hipSuccess;
     if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_heavy_done, hipEventDisableTiming)) == hipSuccess;
-    if (ok) ok = ADC_HIP(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking)) == hipSuccess;
-    if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_up_gate, hipEventDisableTiming)) == hipSuccess;
-    if (ok) ok = ADC_HIP(hipEventCreateWithFlags(&h->ev_right, hipEventDisableTiming)) == hipSuccess;
     for (int i = 0; ok && i <= ADC_STAGE_COUNT; i++) ok = ADC_HIP(hipEventCreate(&h->ev[i])) == hipSuccess;
     for (int i = 0; ok && i < 9; i++) ok = ADC_HIP(hipEventCreate(&h->ev_agg[i])) == hipSuccess;
     if (ok) ok = alloc_all(h) == hipSuccess;
@@ -313,11 +312,10 @@ void adc_destroy(adc_handle* h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->heavy) hipStreamSynchronize(h->heavy);
-    if (h->up_stream) hipStreamSynchronize(h->up_stream);
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->so_seam, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->med_sink, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
-                    h->chg_a, h->edge, h->arms_r, h->bgrx_r, h->armmax_r, h->vol_c};
+                    h->chg_a, h->irv_px, h->edge, h->arms_r, h->bgrx_r, h->armmax_r, h->vol_c};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
     if (h->pin_out) hipHostFree(h->pin_out);
@@ -326,9 +324,6 @@ void adc_destroy(adc_handle* h)
     for (int i = 0; i < 9; i++) if (h->ev_agg[i]) hipEventDestroy(h->ev_agg[i]);
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_heavy_done) hipEventDestroy(h->ev_heavy_done);
-    if (h->ev_up_gate) hipEventDestroy(h->ev_up_gate);
-    if (h->ev_right) hipEventDestroy(h->ev_right);
-    if (h->up_stream) hipStreamDestroy(h->up_stream);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -395,11 +390,14 @@ static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
         HIP_OK(hipMemsetAsync(h->armmax + 2, 0, 2 * sizeof(int), h->heavy)); // failed seams, "assumed ring too shallow" flag
         h->armmax_valid = 3; // the full ring: valid for every image
     } else {
-    // Stage order: what needs only the LEFT image first -- arms, support counts, aggregation records (CostAggregation's set-up,
-    // ADCensusStereo.cpp:92; cross_aggregator.cpp:76-86 builds the arms from the left image alone) --, then the right image of a
-    // host caller goes onto the bus on the second stream while those kernels run, then what reads both images (gray / census /
-    // cost records, ComputeCost :84; the colour-step maps of the scanline penalties).  No stage depends on that order.
-    HIP_OK(adc_launch_arms_left(h));
+    HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
+    // ADC_FUSE_COST (default on): the cost volume is never written -- the first aggregation pass computes each cost
+    // in registers from packed pixel records (k_agg_march<.., COSTIN>); otherwise K2 writes it and pass 1 reads it back
+    if (fuse_cost_now) HIP_OK(adc_launch_cost_records(h));
+    else HIP_OK(adc_launch_cost(h, h->vol_a));
+    MARK(1, h->heavy);
+    HIP_OK(adc_launch_arms(h));                  // CostAggregation, :92
+    MARK(2, h->heavy);
     {   // The maximum arm lengths decide the ring depth of the aggregation kernels and whether same-direction pass pairs
         // can share a launch (k_aggregate.hip).  The host does NOT wait for them: it assumes the maxima of the previous
         // Match of this handle (exact ring depth for that image), the small-ring kernels verify the assumption on the
@@ -418,23 +416,6 @@ static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
         }
     }
     HIP_OK(adc_launch_records(h));
-    MARK(1, h->heavy); // (end of the "arms" stage: collect_timings knows the order)
-    if (h->up_right_src) { // the right image: staged (pageable source of an asynchronous call) and sent on the second stream NOW
-        const size_t PB = (size_t)h->p.W * h->p.H * 3;
-        const uint8_t* from = h->up_right_src;
-        h->up_right_src = nullptr;
-        if (h->up_right_stage) { memcpy(h->pin_in + PB, from, PB); from = h->pin_in + PB; }
-        HIP_OK(hipMemcpyAsync(h->img_r, from, PB, hipMemcpyHostToDevice, h->up_stream));
-        HIP_OK(hipEventRecord(h->ev_right, h->up_stream));
-        HIP_OK(hipStreamWaitEvent(h->heavy, h->ev_right, 0));
-    }
-    HIP_OK(adc_launch_gray_census(h));           // ComputeCost, ADCensusStereo.cpp:84
-    // ADC_FUSE_COST (default on): the cost volume is never written -- the first aggregation pass computes each cost
-    // in registers from packed pixel records (k_agg_march<.., COSTIN>); otherwise K2 writes it and pass 1 reads it back
-    if (fuse_cost_now) HIP_OK(adc_launch_cost_records(h));
-    else HIP_OK(adc_launch_cost(h, h->vol_a));
-    HIP_OK(adc_launch_arms_rest(h));
-    MARK(2, h->heavy);
     } // (!from_aggregation)
     h->fuse_cost = fuse_cost_now ? 1 : 0;
     h->fuse_agg_so = 1; // (the launcher decides: short-arm plan, arms <= 4, segmented row passes)
@@ -489,7 +470,6 @@ static void collect_timings(adc_handle* h)
         if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = -1.f;
         h->stage_ms[i] = ms;
     }
-    { const float t = h->stage_ms[0]; h->stage_ms[0] = h->stage_ms[1]; h->stage_ms[1] = t; } // run_heavy: the "arms" stage runs in front of "cost"
     float tot = 0.f;
     // average duration of a REGULAR aggregation pass (read V + write V); a fused first pass (write-only) is left out
     const int first = h->agg_first_fused ? 1 : 0;
@@ -526,10 +506,8 @@ static hipError_t enqueue_output(adc_handle* h)
 static void abort_match(adc_handle* h)
 {
     if (h->heavy) hipStreamSynchronize(h->heavy);
-    if (h->up_stream) hipStreamSynchronize(h->up_stream);
     if (h->stream) hipStreamSynchronize(h->stream);
     (void)hipGetLastError();
-    h->up_right_src = nullptr;
     h->match_pending = 0;
     h->irv_pending = 0;
     h->so_agg_fused = 0;
@@ -579,24 +557,30 @@ static int match_async_impl(adc_handle* h, const uint8_t* left, const uint8_t* r
     // soon as the call returns, so they always stage the inputs (a DMA still in flight would read the refilled pixels).  The
     // OUTPUT map of a registered range is written in place by every entry point (it is the caller's until adc_wait anyway).
     const bool reg_in = sync_call && host_registered(left, P * 3) && host_registered(right, P * 3);
-    // The LEFT image goes first; run_heavy sends the right one on the handle's second stream once the kernels that need only the
-    // left image are enqueued (arms, support counts, aggregation records: they run while the right image is on the bus).  The
-    // second stream first waits for everything the handle has enqueued so far (the previous Match's readers of img_r).
-    if (ADC_HIP(hipEventRecord(h->ev_up_gate, h->stream)) != hipSuccess || ADC_HIP(hipStreamWaitEvent(h->up_stream, h->ev_up_gate, 0)) != hipSuccess) {
-        set_error("adc_match: upload gate", hipGetLastError());
-        abort_match(h);
-        return 2;
+    // (Round 6, measured and NOT adopted: left image first, the kernels that need only the left image -- arms, support counts,
+    // aggregation records -- enqueued, the right image on a second stream behind an event.  Pageable buffers: no gain; buffers the
+    // caller registered: 192 -> 180 pairs/s -- the cross-stream dependency costs more than the ~0.1 ms of overlap it buys,
+    // profiles/r6_ab_upload_overlap.txt.)
+    const uint8_t *lsrc = left, *rsrc = right;
+    if (!(reg_in || direct)) { // staging: the second image is copied while the first one is on the bus
+        memcpy(h->pin_in, left, P * 3);
+        lsrc = h->pin_in;
     }
-    const uint8_t* lsrc = left;
-    if (!(reg_in || direct)) { memcpy(h->pin_in, left, P * 3); lsrc = h->pin_in; } // staging (pageable source of an asynchronous call)
     // (reg_in / direct: DMA from the caller's memory -- page-locked by the caller: asynchronous; pageable: the runtime stages)
     if (ADC_HIP(hipMemcpyAsync(h->img_l, lsrc, P * 3, hipMemcpyHostToDevice, h->stream)) != hipSuccess) {
         set_error("adc_match: upload of the left image", hipGetLastError());
         abort_match(h);
         return 2;
     }
-    h->up_right_src = right;
-    h->up_right_stage = (reg_in || direct) ? 0 : 1;
+    if (!(reg_in || direct)) {
+        memcpy(h->pin_in + P * 3, right, P * 3);
+        rsrc = h->pin_in + P * 3;
+    }
+    if (ADC_HIP(hipMemcpyAsync(h->img_r, rsrc, P * 3, hipMemcpyHostToDevice, h->stream)) != hipSuccess) {
+        set_error("adc_match: upload of the right image", hipGetLastError());
+        abort_match(h);
+        return 2;
+    }
     if (run_pipeline(h) != hipSuccess) { abort_match(h); return 2; }
     h->async_dst = disp;
     h->async_dst_direct = host_registered(disp, P * 4) ? 1 : (direct ? 2 : 0);

@@ -219,3 +219,53 @@ ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t
     if (r.okm != 0u) r.same = irv_same_key_mask(r.k0, r.k1, r.k2, r.k3, r.okm, &r.first);
     return r;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SLACK BUDGETS (round 6).  In the heavy rounds of the chain four out of five re-evaluations end in the state the entry already
+// had: something in its region changed, but not enough to flip a vote (tools/irv_joint_rounds.py: 0.61 M evaluations for 0.1 M state
+// changes).  An evaluation therefore also computes how many region pixels would have to change before its outcome CAN change.  One
+// pixel's state change moves the cumulative histogram of a level by at most -1 in one bin and +1 in another, so after at most k
+// pixel changes a level with count c, top bin m and runner-up m2 has c' in [c - k, c + k], every bin within +-k, and
+//     a FAILING level keeps failing  if  c + k <= ts                         (count > ts stays false)
+//                                    or  c - k >= 1 and fl((m + k) / (c - k)) <= th   (the ratio test stays false: float division is monotone)
+//     the PASSING level keeps its bin if  c - k > ts,  m - k >= 1,  fl((m - k) / (c + k)) > th  and  m - k > m2 + k
+// (multistep_refiner.cpp:199-214 is `max > 0 && count > ts && max * 1.0f / count > th`, first maximum = lowest bin on ties).  The
+// entry's budget K = the largest such k over the levels up to the deciding one; K = 0 ("any change -> evaluate again") is always
+// valid, and every value below the true bound is (the tests are monotone in k): the closed forms below round DOWN and are then
+// checked with the reference's own float expression.  The change tiles say WHERE something changed in the previous kernel; a
+// bit per pixel says which pixels did, and an entry whose tiles were hit counts the changed pixels inside the bounding RECTANGLE
+// of its region (a superset of the region, no arm lookups: every load independent), subtracts them from its budget and is only
+// re-evaluated when the budget is used up.  Exactness: every state change of a region pixel since the entry's last evaluation is
+// counted at least once (changes of the kernel the entry was evaluated in are counted in the next one, whether its gather saw
+// them or not), so an entry that is skipped would vote what it voted.
+ADC_HD bool irv_ratio_gt(int m, int c, float th) { return (float)m * 1.0f / (float)c > th; } // the reference's expression (adc_vote_decide)
+ADC_HD int irv_level_slack(bool pass, int c, int m, int m2, int ts, float th)
+{
+    const float den = 1.0f + th;
+    int K;
+    if (!pass) {
+        const int k1 = ts - c; // c + k <= ts
+        int kf = -1;           // the ratio test stays false
+        if (c >= 1 && den > 0.0f) {
+            const float x = (th * (float)c - (float)m) / den;
+            kf = x >= 0.0f ? adc_imin((int)x, c - 1) : -1;
+            for (int guard = 0; guard < 4 && kf >= 0 && irv_ratio_gt(m + kf, c - kf, th); guard++) kf--;
+            if (kf >= 0 && irv_ratio_gt(m + kf, c - kf, th)) kf = -1;
+        }
+        K = adc_imax(k1, kf);
+    } else {
+        int kc = 0;
+        if (den > 0.0f) {
+            const float x = ((float)m - th * (float)c) / den;
+            kc = x >= 1.0f ? (int)x : 0;
+            for (int guard = 0; guard < 4 && kc >= 1 && !irv_ratio_gt(m - kc, c + kc, th); guard++) kc--;
+            if (kc >= 1 && !irv_ratio_gt(m - kc, c + kc, th)) kc = 0;
+        }
+        K = adc_imin(adc_imin(c - ts - 1, (m - m2 - 1) >> 1), adc_imin(kc, m - 1));
+    }
+    return adc_imax(0, adc_imin(K, 0xFFFF));
+}
+// per-pixel change bitmap: IRV_PX_PLANES planes of H rows x pitch dwords (bit x & 31 of dword x >> 5; the padding dwords stay 0).
+// Kernel k sets bits in plane k % 3, reads plane (k + 2) % 3 (its predecessor's) and clears plane (k + 1) % 3 for its successor.
+#define IRV_PX_PLANES 3
+ADC_HD int irv_px_pitch(int W) { return ((W + 31) >> 5) + 4; } // (+4: a 16-byte load that starts at a row's last word stays inside the row)

@@ -103,6 +103,35 @@ __device__ __forceinline__ bool irv_box_dirty(const uint8_t* __restrict__ chg_rd
     return dirty;
 }
 
+// Slack budgets (irv_plan.h, bottom): how many pixels of the bounding rectangle [xa, xb] x [ya, yb] of an entry's region changed their
+// state in the previous kernel?  One bit per pixel, rows of `pitch` dwords; the rectangle is at most 69 pixels wide, i.e. within the
+// four dwords from xa >> 5 on: one 16-byte load per row, the same four masks for every row, four v_bcnt (with accumulate) per row;
+// four rows per trip, no load depends on another.  Lanes without work pass ya > yb.
+__device__ __forceinline__ int irv_rect_changes(const uint32_t* __restrict__ px_rd, int pitch, int xa, int xb, int ya, int yb)
+{
+    const int sh = xa & 31, n = xb - xa + 1; // bits sh .. sh + n - 1 of the 128-bit window
+    uint32_t m[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int lo = adc_imax(sh - 32 * j, 0), hi = adc_imin(sh + n - 32 * j, 32); // bits [lo, hi) of dword j
+        m[j] = hi > lo ? ((hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+    }
+    const uint32_t base = (uint32_t)(xa >> 5);
+    int cnt = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int r = ya; r <= yb; r += 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const uint4*>(px_rd + (uint32_t)(adc_imin(r + u, yb) * pitch) + base);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = __popc(v[u].x & m[0]) + __popc(v[u].y & m[1]) + __popc(v[u].z & m[2]) + __popc(v[u].w & m[3]);
+            cnt += r + u <= yb ? c : 0;
+        }
+    }
+    return cnt;
+}
+
 // Wave-wide maximum / sum of non-negative ints in 6 DPP steps (row rotations, then the two row broadcasts of gfx9); the
 // result is valid in lane 63 and returned wave-uniform.  (__shfl_xor is a ds_bpermute: ~100 cycles per step.)
 #define IRV_DPP(V, CTRL, RMASK) __builtin_amdgcn_update_dpp(0, (V), (CTRL), (RMASK), 0xf, false)
@@ -162,7 +191,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                                                 const uint32_t* __restrict__ bbox32, const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
                                                 int D, int min_region, int chg_bytes, int tpitch, int irv_ts, float irv_th,
                                                 int32_t* __restrict__ evals_arr, int seg_cap, int xcd_mode, int32_t* wg_n /* entries per workgroup segment */,
-                                                unsigned long long* listed_bits /* bit p: pixel p goes on the work list (BEGIN -> BEGIN2) */)
+                                                unsigned long long* listed_bits /* bit p: pixel p goes on the work list (BEGIN -> BEGIN2) */,
+                                                uint32_t* px_chg /* per-pixel change bitmap, IRV_PX_PLANES planes (slack budgets) */, int px_pitch,
+                                                int use_slack)
 {
     IRV_TR(8);
     IRV_T(0);
@@ -182,6 +213,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     const uint32_t stamp = (uint32_t)(k % 255) + 1u;
     const uint8_t* chg_rd = chg + (size_t)((k + 1) & 1) * chg_bytes;
     uint8_t* chg_wr = chg + (size_t)(k & 1) * chg_bytes;
+    const uint32_t px_words = (uint32_t)px_pitch * (uint32_t)H; // dwords of one bitmap plane
+    const uint32_t* px_rd = px_chg + (size_t)((k + 2) % IRV_PX_PLANES) * px_words;
+    uint32_t* px_wr = px_chg + (size_t)(k % IRV_PX_PLANES) * px_words;
     // Slots behind the end of the list hold IRV_LIST_END (see irv_plan.h): a wave that finds nothing else skips this phase.
     uint32_t spec_state = 0u;
     bool spec_box = false;
@@ -226,8 +260,10 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         // the no-op kernels behind the end of the chain (the budget's surplus) then find no entry and skip the state / tile
         // round trip: the first batch of the segment becomes end markers
         if (pl.act == IRV_FINAL_WB) seg[threadIdx.x].x = IRV_LIST_END;
-        if (pl.act == IRV_BEGIN) // clear both change-tile planes (bytes, written as dwords)
+        if (pl.act == IRV_BEGIN) { // clear both change-tile planes (bytes, written as dwords) and the per-pixel change planes
             for (int t = blockIdx.x * T + threadIdx.x; t < chg_bytes / 2; t += gridDim.x * T) reinterpret_cast<uint32_t*>(chg)[t] = 0u;
+            for (uint32_t t = blockIdx.x * T + threadIdx.x; t < IRV_PX_PLANES * px_words; t += gridDim.x * T) px_chg[t] = 0u;
+        }
         // one coalesced pass over the image: state map / working copy (BEGIN), fills (FINAL)
         const int P = W * H;
         for (int c0 = blockIdx.x * T; c0 < P; c0 += gridDim.x * T) {
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                     tot += c;
                 }
                 if (li) // everything a round needs to know about the entry in ONE 16-byte load
-                    seg[mine + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(p, (int)arms32[p], (int)bbox32[p], p / W);
+                    seg[mine + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(p, (int)arms32[p], (int)(bbox32[p] & 0xFFFF0000u), p / W); // (low half of z: the slack budget, 0)
                 __syncthreads();
                 if (threadIdx.x == 0) base += tot;
                 __syncthreads();
@@ -322,7 +358,12 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     int* hist = lds_dyn + wave * (IRV_LEVELS * D);
     int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * IRV_LEVELS * D + 3) & ~3)); // (16-byte aligned whatever D is)
     __shared__ int pcount[IRV_MAXW];
+    __shared__ int pidx[IRV_MAXW * 64]; // segment index of a pool item (its slack budget is written back there)
     const int sub = lane >> 2, bslot = lane & 3;
+    if (use_slack) { // the per-pixel change plane the NEXT kernel writes (read by this kernel's predecessor: free now)
+        uint32_t* px_clr = px_chg + (size_t)((k + 1) % IRV_PX_PLANES) * px_words;
+        for (uint32_t t = blockIdx.x * T + threadIdx.x; t < px_words; t += gridDim.x * T) px_clr[t] = 0u;
+    }
     const __amdgpu_buffer_rsrc_t st_rs = __builtin_amdgcn_make_buffer_rsrc(st16, 0, (SP * H + 64) * 2, 0x00020000);
     const int ng = __builtin_amdgcn_readfirstlane(ngv); // entries of this workgroup's segment, in evaluation order
     int evals = 0;
@@ -346,14 +387,27 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, have ? adc_imin(W - 1, x + mr) / IRV_TILE : -1,
                                 adc_imax(0, y - top) / IRV_TILE, adc_imin(H - 1, y + bot) / IRV_TILE, want4);
         }
-        const bool dirty = i < ng && (round == 0 || box);
+        bool dirty = i < ng && (round == 0 || box);
+        if (use_slack && round != 0) { // (uniform) slack budgets, irv_plan.h: an entry whose tiles were hit counts the pixels of its region's
+            // bounding rectangle that changed in the previous kernel, and is evaluated again only when they use its budget up
+            const bool cand = dirty;
+            const int p = cand ? ent.x : 0, y = cand ? ent.w : 0, x = p - y * W;
+            const int top = (int)(((uint32_t)ent.y >> 16) & 255u), bot = (int)((uint32_t)ent.y >> 24);
+            const int ml = (int)(((uint32_t)ent.z >> 16) & 255u), mr = (int)((uint32_t)ent.z >> 24);
+            const int used = irv_rect_changes(px_rd, px_pitch, x - ml, x + mr, cand ? y - top : 1, cand ? y + bot : 0);
+            const int budget = (int)((uint32_t)ent.z & 0xFFFFu);
+            dirty = cand && used > budget;
+            if (cand && !dirty && used > 0) seg[i].z = (int)(((uint32_t)ent.z & 0xFFFF0000u) | (uint32_t)(budget - used));
+        }
         IRV_T(2);
         // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
         // consumers find pool item t by a prefix sum over the (<= 16) counts
         const unsigned long long dm = __ballot(dirty);
         if (lane == 0) pcount[wave] = __popcll(dm);
-        if (dirty) // {pixel, arms, state | read box << 16, row}
+        if (dirty) { // {pixel, arms, state | read box << 16, row}
             pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)((mystate & 0xFFFFu) | ((uint32_t)ent.z & 0xFFFF0000u)), ent.w);
+            pidx[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = i;
+        }
         __syncthreads();
         const int cnt_l = lane < WPB ? pcount[lane] : 0;
         const int incl = irv_row_prefix(cnt_l); // inclusive prefix over the first 16 lanes
@@ -364,6 +418,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             evals++;
             const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
             const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
+            const int eidx = __builtin_amdgcn_readfirstlane(pidx[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]);
             const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
             const uint32_t pz = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z);
             const uint32_t cur = pz & 0xFFFFu; // (only this wave writes the entry in this round)
@@ -443,6 +498,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             for (int it = 0; it < IRV_LEVELS; it++) present |= (__ballot((lvls >> it) & 1u) != 0ull ? 1u : 0u) << it;
             uint32_t ns = IRV_BIN_MASK | ((uint32_t)lp << IRV_LIST_SHIFT); // no iteration's vote passes: invalid
             int below = -1;
+            // slack budget of this outcome (irv_plan.h): the minimum over the levels up to the deciding one; levels without new pixels
+            // repeat their predecessor's histogram (same slack), leading empty levels are failing levels with c = m = 0
+            int K = (present & 1u) ? 0xFFFF : irv_level_slack(false, 0, 0, 0, irv_ts, irv_th);
 #pragma clang loop unroll(disable)
             for (int it = 0; it < IRV_LEVELS; it++) {
                 if (!((present >> it) & 1u)) continue; // (uniform)
@@ -457,7 +515,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 key = irv_wave_max(key);
                 cnt = irv_wave_sum(cnt);
                 const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
-                if (adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT) {
+                const bool pass = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
+                if (use_slack) K = adc_imin(K, irv_level_slack(pass, cnt, bh, cnt - bh, irv_ts, irv_th)); // (runner-up <= everything outside the top bin)
+                if (pass) {
                     ns = (uint32_t)bbin | ((uint32_t)it << IRV_F_SHIFT) | ((uint32_t)lp << IRV_LIST_SHIFT);
                     break;
                 }
@@ -468,9 +528,11 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 if ((present >> it) & 1u) // (uniform)
                     for (int b = lane; b < D; b += 64) hist[it * D + b] = 0;
             IRV_T(7);
+            if (lane == 0 && use_slack) seg[eidx].z = (int)((pz & 0xFFFF0000u) | (uint32_t)K);
             if (lane == 0 && ns != cur) { // bin and iteration in ONE store; both matter to the votes that see this pixel
                 st16[(uint32_t)(y * SP + x)] = (uint16_t)ns;
                 chg_wr[(uint32_t)((y / IRV_TILE) * tpitch + x / IRV_TILE)] = (uint8_t)stamp;
+                if (use_slack) atomicOr(&px_wr[(uint32_t)(y * px_pitch + (x >> 5))], 1u << (x & 31));
                 *acc = 1;
             }
         }
@@ -552,6 +614,12 @@ size_t adc_irv_list_entries(int W, int H, int D, int grid) // (room for either l
 {
     return (size_t)grid * (size_t)adc_imax((int)irv_seg_cap(W, H, grid, irv_wpb(D), 0), (int)irv_seg_cap(W, H, grid, irv_wpb(D), 1));
 }
+static int irv_use_slack()
+{
+    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK"); return e ? atoi(e) : 1; }();
+    return v;
+}
+size_t adc_irv_px_words(int W, int H) { return (size_t)IRV_PX_PLANES * irv_px_pitch(W) * H + 16; }
 static hipError_t irv_launch(adc_handle* h, int k0, int count)
 {
     const AdcParams& p = h->p;
@@ -564,7 +632,7 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count)
                            reinterpret_cast<const uint32_t*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
                            p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr,
                            (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, h->irv_xcd_mode), h->irv_xcd_mode, h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
-                           reinterpret_cast<unsigned long long*>(h->elig));
+                           reinterpret_cast<unsigned long long*>(h->elig), h->irv_px, irv_px_pitch(p.W), irv_use_slack());
     return hipGetLastError();
 }
 

@@ -11,8 +11,10 @@
 #include <vector>
 #include "../../adcensus_amd/csrc/irv_plan.h"
 
-extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
-                               int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats)
+// use_slack: the slack budgets of round 6 (irv_plan.h, bottom): per-pixel change planes, a budget per entry (low half of the entry's
+// box word), changed pixels counted over the bounding rectangle of the region -- as in the kernel
+extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
+                                int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, int use_slack, long* out_stats)
 {
     const int P = W * H, SP = (W + 7) & ~7, T = IRV_TILE;
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
@@ -23,6 +25,7 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
     std::vector<uint16_t> st((size_t)SP * H + 64, 0xFFFF);
     std::vector<int32_t> ctrl(IRV_CTRL_INTS, 0), hist((size_t)IRV_LEVELS * D);
     std::vector<int32_t> chg(2 * (size_t)tiles_x * tiles_y, 0); // two planes (round parity)
+    std::vector<uint8_t> px((size_t)IRV_PX_PLANES * P, 0);       // per-pixel change planes (a byte per pixel here, a bit in the kernel)
     std::vector<Ent> list((size_t)cap * G, Ent{IRV_LIST_END, 0, 0, 0});
     std::vector<int> wg_n(G, 0);
     std::vector<uint8_t> listed_bit(P, 0);
@@ -49,7 +52,7 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
         int32_t* acc = &ctrl[IRV_ACC + (k & 63)];
         kernels++;
         if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
-            if (pl.act == IRV_BEGIN) std::fill(chg.begin(), chg.end(), 0);
+            if (pl.act == IRV_BEGIN) { std::fill(chg.begin(), chg.end(), 0); std::fill(px.begin(), px.end(), 0); }
             for (int p = 0; p < P; p++) { // one pass over the image (any order)
                 const int y = p / W, x = p - y * W;
                 const size_t i16 = (size_t)y * SP + x;
@@ -102,6 +105,9 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
             const int32_t want = ((k + 254) % 255) + 1, stamp = (k % 255) + 1; // stamps and planes go by KERNEL index
             const int32_t* chg_rd = chg.data() + (size_t)((k + 1) & 1) * tiles_x * tiles_y;
             int32_t* chg_wr = chg.data() + (size_t)(k & 1) * tiles_x * tiles_y;
+            const uint8_t* px_rd = px.data() + (size_t)((k + 2) % IRV_PX_PLANES) * P;
+            uint8_t* px_wr = px.data() + (size_t)(k % IRV_PX_PLANES) * P;
+            if (use_slack) std::fill(px.begin() + (size_t)((k + 1) % IRV_PX_PLANES) * P, px.begin() + (size_t)((k + 1) % IRV_PX_PLANES + 1) * P, 0);
             // workgroups in a shuffled order; a workgroup takes its segment batch by batch, pools the dirty entries of the batch
             // in list order and its WPB waves take consecutive pool items: groups of WPB items, each group in a shuffled order
             std::vector<int> wgs(G);
@@ -112,7 +118,7 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
                     std::vector<int> todo;
                     std::vector<uint16_t> seen;
                     for (long i = b0; i < std::min((long)wg_n[g], b0 + BT); i++) {
-                        const Ent& e = list[(size_t)g * cap + i];
+                        Ent& e = list[(size_t)g * cap + i];
                         const int p = e.p, y = e.y, x = p - y * W;
                         bool dirty = round == 0;
                         if (!dirty) {
@@ -121,6 +127,14 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
                             const int ty0 = std::max(0, y - top) / T, ty1 = std::min(H - 1, y + bot) / T;
                             for (int ty = ty0; ty <= ty1; ty++)
                                 for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want; // byte stamps (k_voting.hip)
+                            if (dirty && use_slack) { // changed pixels inside the region's bounding rectangle against the entry's budget
+                                int used = 0;
+                                for (int yy = y - top; yy <= y + bot; yy++)
+                                    for (int xx = x - ml; xx <= x + mr; xx++) used += px_rd[(size_t)yy * W + xx];
+                                const int budget = e.box & 0xFFFF;
+                                dirty = used > budget;
+                                if (!dirty && used > 0) e.box = (int)(((uint32_t)e.box & 0xFFFF0000u) | (uint32_t)(budget - used));
+                            }
                         }
                         if (dirty) { todo.push_back((int)i); seen.push_back(st[(size_t)y * SP + x]); } // (phase 1 reads the entry's own state)
                     }
@@ -154,20 +168,26 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
                                 }
                             }
                             uint32_t ns = IRV_BIN_MASK | ((uint32_t)lp << IRV_LIST_SHIFT);
+                            int K = 0xFFFF;
                             for (int it = 0; it < IRV_LEVELS; it++) {
                                 if (it) for (int b = 0; b < D; b++) hist[(size_t)it * D + b] += hist[(size_t)(it - 1) * D + b];
                                 // the kernel's key: count << 11 | (2047 - bin), maximum = highest count, lowest bin on ties
                                 int key = 0, cnt = 0;
                                 for (int b = 0; b < D; b++) { const int hv = hist[(size_t)it * D + b]; cnt += hv; if (hv > 0) key = std::max(key, (hv << 11) | (0x7FF - b)); }
                                 const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
+                                // (every level here, the kernel only those that add pixels: a level without new pixels repeats its
+                                // predecessor's histogram and slack; leading empty levels have c = m = 0 in both)
+                                K = std::min(K, irv_level_slack(adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT, cnt, bh, cnt - bh, irv_ts, irv_th));
                                 if (adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT) {
                                     ns = (uint32_t)bbin | ((uint32_t)it << IRV_F_SHIFT) | ((uint32_t)lp << IRV_LIST_SHIFT);
                                     break;
                                 }
                             }
+                            if (use_slack) list[(size_t)g * cap + todo[t]].box = (int)(((uint32_t)e.box & 0xFFFF0000u) | (uint32_t)K);
                             if (ns != cur) {
                                 st[(size_t)y * SP + x] = (uint16_t)ns;
                                 chg_wr[(y / T) * tiles_x + x / T] = stamp;
+                                if (use_slack) px_wr[(size_t)y * W + x] = 1;
                                 *acc = 1;
                             }
                         }
@@ -181,6 +201,40 @@ extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t*
     }
     if (out_stats) { out_stats[0] = fin[5]; out_stats[1] = fin[6]; out_stats[2] = kernels; }
     return fin[0] == IRV_DONE ? fin[5] : -2;
+}
+
+extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
+                               int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats)
+{
+    return emul_irv_chain2(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, 1, out_stats);
+}
+
+// The closed forms of irv_level_slack (irv_plan.h) against the definition: for random (pass, c, m, m2, ts, th) the returned K must
+// satisfy the level's own tests at K (the budget is VALID), and K + 1 must fail one of them or K be at most 2 below the largest valid
+// value (the budget is not wastefully small).  Returns invalid * 1000000 + loose.
+static bool slack_holds(bool pass, int c, int m, int m2, int ts, float th, int k)
+{
+    if (!pass) return (c + k <= ts) || (c - k >= 1 && !((float)(m + k) * 1.0f / (float)(c - k) > th));
+    return (c - k > ts) && (m - k >= 1) && ((float)(m - k) * 1.0f / (float)(c + k) > th) && (m - k > m2 + k);
+}
+extern "C" long emul_irv_slack_check(unsigned seed, long trials)
+{
+    srand(seed);
+    long invalid = 0, loose = 0;
+    for (long t = 0; t < trials; t++) {
+        const int ts = rand() % 60 - 5;
+        const float th = (float)(rand() % 1000) / 1000.0f;
+        const int c = rand() % 400, m = c ? 1 + rand() % c : 0, m2 = std::min(m, c - m > 0 ? rand() % (c - m + 1) : 0);
+        const bool pass = m > 0 && c > ts && (float)m * 1.0f / (float)c > th;
+        const int K = irv_level_slack(pass, c, m, m2, ts, th);
+        if (K > 0 && !slack_holds(pass, c, m, m2, ts, th, K)) invalid++;
+        for (int k = 1; k < K; k++) if (!slack_holds(pass, c, m, m2, ts, th, k)) { invalid++; break; } // (monotone: everything below K holds too)
+        int best = 0;
+        while (best < 5000 && slack_holds(pass, c, m, m2, ts, th, best + 1)) best++;
+        if (K > best) invalid++;
+        if (best - K > 2 && K < 0xFFFF) loose++;
+    }
+    return invalid * 1000000 + loose;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -410,6 +410,12 @@ def test_refiner_parallel_forms(emul, dumps, name):
                                      C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, groups, wpb, stats)
         assert rounds >= 0, rounds
         assert same(d, o["disp_after_irv"])
+        # the same chain without the slack budgets of round 6 (ADC_IRV_SLACK=0): same result, never fewer evaluations
+        emul.emul_irv_chain2.restype = C.c_long
+        d0, stats0 = o["disp_after_lr"].copy(), (C.c_long * 3)()
+        assert emul.emul_irv_chain2(P(d0), P(o["outlier_label"]), P(o["arms"]), P(o["sup_count_h"]), w, h, dmin, D, opt.irv_ts,
+                                    C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, groups, wpb, 0, stats0) >= 0
+        assert same(d0, o["disp_after_irv"])
     a, b = o["disp_after_irv"].copy(), np.empty((h, w), np.float32)
     ms = max(abs(opt.max_disparity), abs(opt.min_disparity))
     emul.emul_interpolate(P(a), P(b), P(o["outlier_label"]), P(left), w, h, 1, ms)
@@ -564,6 +570,16 @@ def test_voting_tiles_partition_the_image(emul):
                 assert emul.emul_irv_tile_partition(w, h, g, wpb, xcd) == 0, (w, h, g, wpb, xcd)
 
 
+def test_voting_slack_budget_closed_forms(emul):
+    """irv_plan.h: irv_level_slack -- the budget of a vote level (how many region pixels may change before the level's outcome can)
+    -- is VALID (the level's tests hold at K and below) on a million random levels, and within 2 of the largest valid value."""
+    emul.emul_irv_slack_check.restype = C.c_long
+    for seed in (1, 2, 3):
+        r = emul.emul_irv_slack_check(seed, C.c_long(400000))
+        assert r // 1000000 == 0, r  # no invalid budget, ever
+        assert r % 1000000 <= 4000, r  # (loose ones: float rounding right at the threshold)
+
+
 def test_voting_packed_halfword_helpers(emul):
     """irv_plan.h: irv_decode_block (eligible / final / invalid-bin / same-bin masks of 8 packed state halfwords by SWAR
     carries) and the change-tile row test (byte masks from a nibble expansion, any-zero-byte trick) agree with per-pixel
@@ -571,3 +587,34 @@ def test_voting_packed_halfword_helpers(emul):
     emul.emul_irv_swar_check.restype = C.c_long
     for seed in (1, 2):
         assert emul.emul_irv_swar_check(seed, C.c_long(1000000)) == 0
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_voting_chain_slack_budgets_random_cases(emul, port_oracle, case):
+    """Round 6: the voting chain with slack budgets (an entry is re-evaluated only when enough pixels of its region's bounding
+    rectangle changed to possibly flip its vote, irv_plan.h) on randomly drawn geometries / option sets -- thresholds `irv_ts`
+    0..45 and `irv_th` 0.05..0.8 move the budgets through their whole range, arm limits 4..40 the rectangles -- under shuffled
+    schedules and three work-list layouts: the result must be the reference's region voting (multistep_refiner.cpp:153-227)."""
+    from adcensus_amd import workloads
+    from oracle import pyoracle
+    rng = np.random.default_rng(6000 + case)
+    w, h = int(rng.integers(60, 260)), int(rng.integers(40, 160))
+    D = int(rng.choice([16, 32, 64, 100]))
+    dmin = int(rng.choice([0, 0, -7, 5]))
+    left, right = (workloads.structured_pair(w, h, D, seed=500 + case) if case % 3 else workloads.quantized_noise_pair(w, h, D, seed=500 + case))
+    opt = pyoracle.Option(min_disparity=dmin, max_disparity=dmin + D, irv_ts=int(rng.choice([0, 3, 8, 20, 45])),
+                          irv_th=float(rng.choice([0.05, 0.2, 0.4, 0.6, 0.8])), cross_L1=int(rng.choice([4, 10, 34, 40])),
+                          cross_L2=int(rng.choice([2, 8, 17])), lrcheck_thres=float(rng.choice([0.5, 1.0, 2.0])))
+    o = port_oracle.run(left, right, opt)
+    L = max(0, min(opt.cross_L1, 255))
+    emul.emul_irv_chain2.restype = C.c_long
+    evals = {}
+    for slack in (1, 0):
+        for seed, groups, wpb in ((11, 2, 4), (12, 8, 1), (13, 16, 2)):
+            d, stats = o["disp_after_lr"].copy(), (C.c_long * 3)()
+            r = emul.emul_irv_chain2(P(d), P(o["outlier_label"]), P(o["arms"]), P(o["sup_count_h"]), w, h, dmin, D, opt.irv_ts,
+                                     C.c_float(opt.irv_th), opt.irv_ts if L <= 127 else -1, seed, groups, wpb, slack, stats)
+            assert r >= 0, r
+            assert same(d, o["disp_after_irv"]), (case, slack, seed)
+            evals[(slack, seed)] = stats[1]
+    assert sum(v for (s, _), v in evals.items() if s == 1) <= sum(v for (s, _), v in evals.items() if s == 0)

@@ -444,3 +444,148 @@ extern "C" long irv_joint_bands(float* out, const float* d0, const uint8_t* labe
     for (int p = 0; p < P; p++) if (label[p] != 0) out[p] = f[p] < 5 ? (float)(b[p] + dmin) : ADC_INVALID_FLOAT;
     return rounds;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: SLACK BUDGETS.  In the heavy rounds ~80 % of the re-evaluations end in the decision the entry already had: something in the
+// region changed, but not enough to flip a vote.  An evaluation therefore also computes how many region pixels would have to change
+// before its decision CAN change: per level with cumulative histogram (count c, top bin m, runner-up m2), after at most k pixel changes
+//     a failing level keeps failing  if  c + k <= ts  or  (c - k >= 1 and fl((m + k) / (c - k)) <= th)
+//     the passing level keeps its bin if  c - k > ts  and fl((m - k) / (c + k)) > th  and  m - k > m2 + k
+// (every pixel change moves a level's histogram by at most -1 in one bin and +1 in another; float division is monotone).  K = the
+// largest k for which every level up to the deciding one holds.  Change tiles COUNT the changes of a round; an entry subtracts the
+// counts of its bounding box from its budget round by round and is only re-evaluated when the budget is used up.  Same band schedule
+// as irv_joint_bands.  slack_mode 0 = off (any change -> dirty), 1 = on with the true runner-up, 2 = on with m2 := c - m (no second
+// reduction).  cap = largest budget an entry can hold (8 bits on the GPU: 255).
+namespace {
+inline bool lvl_pass(int m, int c, int ts, float th) { return m > 0 && c > ts && (float)m * 1.0f / (float)c > th; }
+inline int lvl_slack(bool pass, int c, int m, int m2, int ts, float th, int cap)
+{
+    int k = 0;
+    for (; k < cap; k++) { // (largest k that still holds: test k + 1)
+        const int kk = k + 1;
+        bool ok;
+        if (!pass) ok = (c + kk <= ts) || (c - kk >= 1 && (float)(m + kk) * 1.0f / (float)(c - kk) <= th);
+        else ok = (c - kk > ts) && (m - kk >= 1) && ((float)(m - kk) * 1.0f / (float)(c + kk) > th) && (m - kk > m2 + kk);
+        if (!ok) break;
+    }
+    return k;
+}
+}
+extern "C" long irv_joint_bands_slack(float* out, const float* d0, const uint8_t* label, const uint8_t* arms, int W, int H, int dmin, int D,
+                                      int irv_ts, float irv_th, int R, int slack_mode, int cap, long* evals_per_round, long* changes_per_round,
+                                      long* slack_hist /*[cap + 1]*/, long max_rounds)
+{
+    const int P = W * H;
+    std::vector<uint8_t> f(P, 5);
+    std::vector<int> b(P, -1);
+    for (int p = 0; p < P; p++)
+        if (label[p] == 0 && d0[p] != ADC_INVALID_FLOAT) { f[p] = 0; b[p] = (int)(lroundf(d0[p]) - dmin); }
+    const int TW = (W + 7) / 8, TH = (H + 7) / 8;
+    std::vector<int> tcnt_prev((size_t)TW * TH, 0), tcnt_now((size_t)TW * TH, 0), budget(P, -1);
+    std::vector<uint8_t> dirty(P), pchg_prev(P, 0), pchg_now(P, 0); // (slack_mode 3: per-pixel change map, counted over the exact region)
+    std::vector<int> add((size_t)5 * D);
+    struct Upd { int p; uint8_t f; int b; };
+    std::vector<Upd> upd;
+    long rounds = 0;
+    for (;; rounds++) {
+        long evals = 0, changes = 0;
+        std::fill(tcnt_now.begin(), tcnt_now.end(), 0);
+        std::fill(pchg_now.begin(), pchg_now.end(), 0);
+        for (int p = 0; p < P; p++) {
+            dirty[p] = 0;
+            if (label[p] == 0) continue;
+            const int y = p / W, x = p - y * W;
+            const uint8_t* arm = arms + (size_t)p * 4;
+            bool dt = rounds == 0;
+            if (!dt) {
+                int ml = 0, mr = 0;
+                for (int t = -(int)arm[2]; t <= (int)arm[3]; t++) {
+                    const uint8_t* arm2 = arms + ((size_t)(y + t) * W + x) * 4;
+                    ml = std::max(ml, (int)arm2[0]); mr = std::max(mr, (int)arm2[1]);
+                }
+                int s = 0;
+                if (slack_mode == 5 || slack_mode == 6) { // exact count over the region's bounding RECTANGLE (no arm lookups: all loads independent)
+                    for (int t = -(int)arm[2]; t <= (int)arm[3]; t++)
+                        for (int q = -ml; q <= mr; q++) s += pchg_prev[(size_t)(y + t) * W + x + q];
+                } else if (slack_mode >= 3) {
+                    for (int t = -(int)arm[2]; t <= (int)arm[3]; t++) {
+                        const uint8_t* arm2 = arms + ((size_t)(y + t) * W + x) * 4;
+                        for (int q = -(int)arm2[0]; q <= (int)arm2[1]; q++) s += pchg_prev[(size_t)(y + t) * W + x + q];
+                    }
+                } else
+                for (int ty = (y - arm[2]) / 8; ty <= (y + arm[3]) / 8; ty++)
+                    for (int tx = (x - ml) / 8; tx <= (x + mr) / 8; tx++) s += tcnt_prev[(size_t)ty * TW + tx];
+                if (s > 0) {
+                    if (!slack_mode) dt = true;
+                    else { budget[p] -= s; dt = budget[p] < 0; }
+                }
+            }
+            dirty[p] = dt;
+        }
+        for (int j = 0; j < R; j++) {
+            upd.clear();
+            for (int r0 = 0; r0 < H; r0 += R) {
+                const int y = r0 + j;
+                if (y >= H) continue;
+                for (int x = 0; x < W; x++) {
+                    const int p = y * W + x;
+                    if (!dirty[p]) continue;
+                    const int list = label[p] == ADC_LABEL_MISMATCH ? 0 : 1;
+                    const uint8_t* arm = arms + (size_t)p * 4;
+                    evals++;
+                    std::fill(add.begin(), add.end(), 0);
+                    for (int t = -(int)arm[2]; t <= (int)arm[3]; t++) {
+                        const int yt = y + t;
+                        const uint8_t* arm2 = arms + ((size_t)yt * W + x) * 4;
+                        for (int s = -(int)arm2[0]; s <= (int)arm2[1]; s++) {
+                            const int q = yt * W + x + s;
+                            if (q == p) continue;
+                            const int fq = f[q];
+                            if (fq >= 5) continue;
+                            const int ql = label[q];
+                            int tq;
+                            if (ql == 0) tq = 0;
+                            else {
+                                const int qlist = ql == ADC_LABEL_MISMATCH ? 0 : 1;
+                                if (qlist == list) tq = q < p ? fq : fq + 1;
+                                else tq = list == 0 ? fq + 1 : fq;
+                            }
+                            if (tq >= 5) continue;
+                            const int bq = b[q];
+                            if (bq >= 0 && bq < D) add[(size_t)tq * D + bq]++;
+                        }
+                    }
+                    int nf = 5, nb = -1, K = cap;
+                    for (int it = 0; it < 5; it++) {
+                        if (it) for (int d = 0; d < D; d++) add[(size_t)it * D + d] += add[(size_t)(it - 1) * D + d];
+                        const int* hist = &add[(size_t)it * D];
+                        int bh = 0, bb = 0x7fffffff, cnt = 0, second = 0;
+                        for (int d = 0; d < D; d++) { cnt += hist[d]; if (hist[d] > bh) { bh = hist[d]; bb = d; } }
+                        for (int d = 0; d < D; d++) if (d != bb && hist[d] > second) second = hist[d];
+                        if (slack_mode == 2 || slack_mode == 4 || slack_mode == 6) second = cnt - bh;
+                        const float nv = adc_vote_decide(bb, bh, cnt, dmin, irv_ts, irv_th);
+                        const bool pass = nv != ADC_INVALID_FLOAT;
+                        K = std::min(K, lvl_slack(pass, cnt, bh, second, irv_ts, irv_th, cap));
+                        if (pass) { nf = it; nb = (int)(lroundf(nv) - dmin); break; }
+                    }
+                    budget[p] = K;
+                    if (slack_hist) slack_hist[K]++;
+                    if (nf != f[p] || nb != b[p]) upd.push_back(Upd{p, (uint8_t)nf, nb});
+                }
+            }
+            for (const Upd& u : upd) {
+                f[u.p] = u.f; b[u.p] = u.b;
+                changes++;
+                tcnt_now[(size_t)((u.p / W) / 8) * TW + (u.p % W) / 8]++;
+                pchg_now[u.p] = 1;
+            }
+        }
+        if (rounds < max_rounds) { evals_per_round[rounds] = evals; changes_per_round[rounds] = changes; }
+        tcnt_prev.swap(tcnt_now);
+        pchg_prev.swap(pchg_now);
+        if (changes == 0) { rounds++; break; }
+    }
+    memcpy(out, d0, (size_t)P * 4);
+    for (int p = 0; p < P; p++) if (label[p] != 0) out[p] = f[p] < 5 ? (float)(b[p] + dmin) : ADC_INVALID_FLOAT;
+    return rounds;
+}
