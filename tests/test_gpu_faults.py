@@ -38,9 +38,9 @@ def test_hip_failures_surface_as_false_and_leave_the_object_usable(hip):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("FAULT_PROBE ")][-1]
     o = json.loads(line[len("FAULT_PROBE "):])
-    assert o["create_calls"] >= 60 and o["match_calls"] >= 20, o  # (the hook really sits on the paths: allocations, launches, copies)
+    assert o["create_calls"] >= 60 and o["match_calls"] >= 10, o  # (the hook really sits on the paths: allocations, launches, copies)
     assert o["create_not_failed"] == [] and o["create_leaks"] == [] and o["create_past_end_ok"], o
-    assert o["match_picks"] >= 20 and o["match_not_failed"] == [] and o["match_wrong_after"] == [], o
+    assert o["match_picks"] >= 10 and o["match_not_failed"] == [] and o["match_wrong_after"] == [], o
     assert o["async_bad"] == [], o
     # farm: submit #2 failed (nonzero), every other pair was delivered with the right map
     assert o["farm_rc"][2] != 0 and [rc for i, rc in enumerate(o["farm_rc"]) if i != 2] == [0] * 5, o
