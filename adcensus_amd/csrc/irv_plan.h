@@ -233,8 +233,8 @@ ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t
 // entry's budget K = the largest such k over the levels up to the deciding one; K = 0 ("any change -> evaluate again") is always
 // valid, and every value below the true bound is (the tests are monotone in k): the closed forms below round DOWN and are then
 // checked with the reference's own float expression.  The change tiles say WHERE something changed in the previous kernel; a
-// bit per pixel says which pixels did, and an entry whose tiles were hit counts the changed pixels inside the bounding RECTANGLE
-// of its region (a superset of the region, no arm lookups: every load independent), subtracts them from its budget and is only
+// bit per pixel says which pixels did, and an entry whose tiles were hit counts the changed pixels inside its region (row by row:
+// the bitmap words of the row and the row's arms, every load independent of the others), subtracts them from its budget and is only
 // re-evaluated when the budget is used up.  Exactness: every state change of a region pixel since the entry's last evaluation is
 // counted at least once (changes of the kernel the entry was evaluated in are counted in the next one, whether its gather saw
 // them or not), so an entry that is skipped would vote what it voted.

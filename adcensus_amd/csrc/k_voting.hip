@@ -103,33 +103,13 @@ __device__ __forceinline__ bool irv_box_dirty(const uint8_t* __restrict__ chg_rd
     return dirty;
 }
 
-// Slack budgets (irv_plan.h, bottom): how many pixels of the bounding rectangle [xa, xb] x [ya, yb] of an entry's region changed their
-// state in the previous kernel?  One bit per pixel, rows of `pitch` dwords; the rectangle is at most 69 pixels wide, i.e. within the
-// four dwords from xa >> 5 on: one 16-byte load per row, the same four masks for every row, four v_bcnt (with accumulate) per row;
-// four rows per trip, no load depends on another.  Lanes without work pass ya > yb.
-__device__ __forceinline__ int irv_rect_changes(const uint32_t* __restrict__ px_rd, int pitch, int xa, int xb, int ya, int yb)
+// Slack budgets (irv_plan.h, bottom): bits [lo, hi) of a 64-bit word, 0 <= lo, hi <= 64 -- the span of a region row inside the 128-bit
+// window of the per-pixel change bitmap a vote's lane reads for that row
+__device__ __forceinline__ unsigned long long irv_mask64(int lo, int hi)
 {
-    const int sh = xa & 31, n = xb - xa + 1; // bits sh .. sh + n - 1 of the 128-bit window
-    uint32_t m[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int lo = adc_imax(sh - 32 * j, 0), hi = adc_imin(sh + n - 32 * j, 32); // bits [lo, hi) of dword j
-        m[j] = hi > lo ? ((hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
-    }
-    const uint32_t base = (uint32_t)(xa >> 5);
-    int cnt = 0;
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (int r = ya; r <= yb; r += 4) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const uint4*>(px_rd + (uint32_t)(adc_imin(r + u, yb) * pitch) + base);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int c = __popc(v[u].x & m[0]) + __popc(v[u].y & m[1]) + __popc(v[u].z & m[2]) + __popc(v[u].w & m[3]);
-            cnt += r + u <= yb ? c : 0;
-        }
-    }
-    return cnt;
+    if (hi <= lo) return 0ull;
+    const unsigned long long up = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    return up & ~((1ull << lo) - 1ull); // (lo < hi <= 64: the shift is defined)
 }
 
 // Wave-wide maximum / sum of non-negative ints in 6 DPP steps (row rotations, then the two row broadcasts of gfx9); the
@@ -214,7 +194,6 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     const uint8_t* chg_rd = chg + (size_t)((k + 1) & 1) * chg_bytes;
     uint8_t* chg_wr = chg + (size_t)(k & 1) * chg_bytes;
     const uint32_t px_words = (uint32_t)px_pitch * (uint32_t)H; // dwords of one bitmap plane
-    const uint32_t* px_rd = px_chg + (size_t)((k + 2) % IRV_PX_PLANES) * px_words;
     uint32_t* px_wr = px_chg + (size_t)(k % IRV_PX_PLANES) * px_words;
     // Slots behind the end of the list hold IRV_LIST_END (see irv_plan.h): a wave that finds nothing else skips this phase.
     uint32_t spec_state = 0u;
@@ -358,13 +337,15 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     int* hist = lds_dyn + wave * (IRV_LEVELS * D);
     int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * IRV_LEVELS * D + 3) & ~3)); // (16-byte aligned whatever D is)
     __shared__ int pcount[IRV_MAXW];
-    __shared__ int pidx[IRV_MAXW * 64]; // segment index of a pool item (its slack budget is written back there)
+    __shared__ int pidx[IRV_MAXW * 64], pbud[IRV_MAXW * 64]; // segment index of a pool item and its slack budget (written back there)
     const int sub = lane >> 2, bslot = lane & 3;
     if (use_slack) { // the per-pixel change plane the NEXT kernel writes (read by this kernel's predecessor: free now)
         uint32_t* px_clr = px_chg + (size_t)((k + 1) % IRV_PX_PLANES) * px_words;
         for (uint32_t t = blockIdx.x * T + threadIdx.x; t < px_words; t += gridDim.x * T) px_clr[t] = 0u;
     }
     const __amdgpu_buffer_rsrc_t st_rs = __builtin_amdgcn_make_buffer_rsrc(st16, 0, (SP * H + 64) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t px_rs = __builtin_amdgcn_make_buffer_rsrc(px_chg, 0, (int)(IRV_PX_PLANES * px_words * 4u + 64u), 0x00020000);
+    const uint32_t px_rd_off = (uint32_t)((k + 2) % IRV_PX_PLANES) * px_words * 4u, px_wr_off = (uint32_t)(k % IRV_PX_PLANES) * px_words * 4u;
     const int ng = __builtin_amdgcn_readfirstlane(ngv); // entries of this workgroup's segment, in evaluation order
     int evals = 0;
     if (ng > 0) // the wave's histograms start empty; every vote clears the rows it has touched behind itself
@@ -387,18 +368,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, have ? adc_imin(W - 1, x + mr) / IRV_TILE : -1,
                                 adc_imax(0, y - top) / IRV_TILE, adc_imin(H - 1, y + bot) / IRV_TILE, want4);
         }
-        bool dirty = i < ng && (round == 0 || box);
-        if (use_slack && round != 0) { // (uniform) slack budgets, irv_plan.h: an entry whose tiles were hit counts the pixels of its region's
-            // bounding rectangle that changed in the previous kernel, and is evaluated again only when they use its budget up
-            const bool cand = dirty;
-            const int p = cand ? ent.x : 0, y = cand ? ent.w : 0, x = p - y * W;
-            const int top = (int)(((uint32_t)ent.y >> 16) & 255u), bot = (int)((uint32_t)ent.y >> 24);
-            const int ml = (int)(((uint32_t)ent.z >> 16) & 255u), mr = (int)((uint32_t)ent.z >> 24);
-            const int used = irv_rect_changes(px_rd, px_pitch, x - ml, x + mr, cand ? y - top : 1, cand ? y + bot : 0);
-            const int budget = (int)((uint32_t)ent.z & 0xFFFFu);
-            dirty = cand && used > budget;
-            if (cand && !dirty && used > 0) seg[i].z = (int)(((uint32_t)ent.z & 0xFFFF0000u) | (uint32_t)(budget - used));
-        }
+        const bool dirty = i < ng && (round == 0 || box);
         IRV_T(2);
         // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
         // consumers find pool item t by a prefix sum over the (<= 16) counts
@@ -407,6 +377,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         if (dirty) { // {pixel, arms, state | read box << 16, row}
             pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)((mystate & 0xFFFFu) | ((uint32_t)ent.z & 0xFFFF0000u)), ent.w);
             pidx[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = i;
+            pbud[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = (int)((uint32_t)ent.z & 0xFFFFu);
         }
         __syncthreads();
         const int cnt_l = lane < WPB ? pcount[lane] : 0;
@@ -415,10 +386,10 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         const int total = __builtin_amdgcn_readlane(incl, 15);
         IRV_T(3);
         for (int t = wave; t < total; t += WPB) {
-            evals++;
             const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
             const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
             const int eidx = __builtin_amdgcn_readfirstlane(pidx[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]);
+            const int ebud = __builtin_amdgcn_readfirstlane(pbud[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]);
             const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
             const uint32_t pz = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z);
             const uint32_t cur = pz & 0xFFFFu; // (only this wave writes the entry in this round)
@@ -429,6 +400,14 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
             // the read box: blocks blkL .. blkR cover the widest row of the region
             const int blkL = (x - (int)((pz >> 16) & 255u)) >> 3, blkR = (x + (int)(pz >> 24)) >> 3;
+            // Slack budget (irv_plan.h, bottom): the entry's tiles were hit, but did ENOUGH pixels of its region change to possibly flip
+            // its vote?  Lane r counts, over the span of region row r, the bits of the previous kernel's change plane (complete) and of
+            // this kernel's (as far as the XCD's L2 has them: what the sweep down the band has just changed) -- same round trip as the
+            // arms and the first state blocks.  Within the budget: no vote; the previous kernel's changes come off the budget (this
+            // kernel's are the next kernel's "previous").  Regions of more than 64 rows (arms beyond 31 up AND down) always vote.
+            const bool slack_now = use_slack && round != 0 && nrows <= 64; // (uniform)
+            const int wx0 = ((x - (int)((pz >> 16) & 255u)) >> 5) << 5;     // pixel of bit 0 of the 128-bit bitmap window of every region row
+            bool skipped = false;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int rbase = 0; rbase < nrows; rbase += 64) {
                 // the H arms of (up to 64) region rows (lane r holds row rbase + r; handed to the row slots with a shuffle) AND
@@ -442,6 +421,31 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 {
                     const bool in0 = sub < rend && blkL + bslot <= blkR;
                     vfirst = irv_ld_state(st_rs, in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own);
+                }
+                if (slack_now) {
+                    irv_u32x4 cp = {0u, 0u, 0u, 0u}, cc = {0u, 0u, 0u, 0u};
+                    if (myr < nrows) {
+                        const uint32_t off = (uint32_t)((y - top + myr) * px_pitch + (wx0 >> 5)) * 4u; // bytes into a plane
+                        cp = __builtin_amdgcn_raw_buffer_load_b128(px_rs, (int)(px_rd_off + off), 0, 0);
+                        cc = __builtin_amdgcn_raw_buffer_load_b128(px_rs, (int)(px_wr_off + off), 0, IRV_LOAD_CPOL);
+                    }
+                    int lo = x - (int)(a2 & 255u) - wx0, hi = x + (int)((a2 >> 8) & 255u) - wx0 + 1; // bits [lo, hi) of the window
+                    unsigned long long m0 = irv_mask64(adc_imin(lo, 64), adc_imin(hi, 64)), m1 = irv_mask64(adc_imax(lo - 64, 0), adc_imax(hi - 64, 0));
+                    if (myr == top) { // a pixel does not vote for itself: its own change does not count
+                        const int sb = x - wx0;
+                        if (sb < 64) m0 &= ~(1ull << sb); else m1 &= ~(1ull << (sb - 64));
+                    }
+                    int c2 = 0;
+                    if (myr < nrows)
+                        c2 = (__popcll(((unsigned long long)cp.x | ((unsigned long long)cp.y << 32)) & m0) + __popcll(((unsigned long long)cp.z | ((unsigned long long)cp.w << 32)) & m1)) |
+                             ((__popcll(((unsigned long long)cc.x | ((unsigned long long)cc.y << 32)) & m0) + __popcll(((unsigned long long)cc.z | ((unsigned long long)cc.w << 32)) & m1)) << 16);
+                    c2 = irv_wave_sum(c2); // (<= 64 rows x 69 pixels per half)
+                    const int usedp = c2 & 0xFFFF, usedc = c2 >> 16;
+                    if (usedp + usedc <= ebud) {
+                        if (lane == 0 && usedp > 0) seg[eidx].z = (int)((pz & 0xFFFF0000u) | (uint32_t)(ebud - usedp));
+                        skipped = true;
+                        break;
+                    }
                 }
                 IRV_T(4);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
@@ -489,6 +493,8 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                     }
                 }
             }
+            if (skipped) continue; // (uniform)
+            evals++;
             IRV_T(6);
             // The votes of the iterations, lowest first, on the CUMULATIVE histograms (row `it` += the last non-empty row below it);
             // an iteration that adds no pixel repeats the previous decision (which failed).  First maximum (lowest bin on ties)

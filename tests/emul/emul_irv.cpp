@@ -12,7 +12,7 @@
 #include "../../adcensus_amd/csrc/irv_plan.h"
 
 // use_slack: the slack budgets of round 6 (irv_plan.h, bottom): per-pixel change planes, a budget per entry (low half of the entry's
-// box word), changed pixels counted over the bounding rectangle of the region -- as in the kernel
+// box word), changed pixels counted over the region -- as in the kernel
 extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                 int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, int use_slack, long* out_stats)
 {
@@ -127,18 +127,9 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                             const int ty0 = std::max(0, y - top) / T, ty1 = std::min(H - 1, y + bot) / T;
                             for (int ty = ty0; ty <= ty1; ty++)
                                 for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want; // byte stamps (k_voting.hip)
-                            if (dirty && use_slack) { // changed pixels inside the region's bounding rectangle against the entry's budget
-                                int used = 0;
-                                for (int yy = y - top; yy <= y + bot; yy++)
-                                    for (int xx = x - ml; xx <= x + mr; xx++) used += px_rd[(size_t)yy * W + xx];
-                                const int budget = e.box & 0xFFFF;
-                                dirty = used > budget;
-                                if (!dirty && used > 0) e.box = (int)(((uint32_t)e.box & 0xFFFF0000u) | (uint32_t)(budget - used));
-                            }
                         }
                         if (dirty) { todo.push_back((int)i); seen.push_back(st[(size_t)y * SP + x]); } // (phase 1 reads the entry's own state)
                     }
-                    total_evals += (long)todo.size();
                     for (size_t c0 = 0; c0 < todo.size(); c0 += WPB) {
                         std::vector<size_t> grp;
                         for (size_t c = c0; c < std::min(todo.size(), c0 + WPB); c++) grp.push_back(c);
@@ -148,6 +139,26 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                             const int p = e.p, y = e.y, x = p - y * W;
                             const uint32_t cur = seen[t];
                             const int lp = (int)(cur >> IRV_LIST_SHIFT);
+                            if (use_slack && round != 0) { // the slack test at the entry's TURN (k_voting.hip): changed pixels of the region in
+                                // the previous kernel's plane and in this kernel's so far, against the entry's budget; regions of more than 64
+                                // rows always vote; the entry's own pixel does not count
+                                const uint8_t* pa = arms + (size_t)p * 4;
+                                const int nrows = (int)pa[2] + (int)pa[3] + 1, budget = e.box & 0xFFFF;
+                                int usedp = 0, usedc = 0;
+                                for (int yy = y - (int)pa[2]; yy <= y + (int)pa[3]; yy++) {
+                                    const uint8_t* a2 = arms + ((size_t)yy * W + x) * 4;
+                                    for (int xx = x - (int)a2[0]; xx <= x + (int)a2[1]; xx++) {
+                                        if (yy == y && xx == x) continue;
+                                        usedp += px_rd[(size_t)yy * W + xx];
+                                        usedc += px_wr[(size_t)yy * W + xx];
+                                    }
+                                }
+                                if (nrows <= 64 && usedp + usedc <= budget) {
+                                    if (usedp > 0) list[(size_t)g * cap + todo[t]].box = (int)(((uint32_t)e.box & 0xFFFF0000u) | (uint32_t)(budget - usedp));
+                                    continue;
+                                }
+                            }
+                            total_evals++;
                             std::fill(hist.begin(), hist.end(), 0);
                             const uint8_t* arm = arms + (size_t)p * 4;
                             for (int dy = -(int)arm[2]; dy <= (int)arm[3]; dy++) {
