@@ -93,7 +93,7 @@ struct adc_handle {
     float *disp_l, *disp_r, *disp_tmp;
     uint8_t* label;
     uint8_t* elig;       // scratch: invalid mask of the LR check (byte per pixel), then the voting chain's bitmap of the pixels on its work list
-    uint8_t* irv_bbox;   // uchar4 per pixel: widest H arms {left, right} over the rows y-top..y and over ALL region rows (k_irv_bbox): read box / dirty box of a vote
+    uint8_t* irv_bbox;   // uchar4 per pixel: widest H arms {left, right} over ALL region rows (k_sup_counts): read box / dirty box of a vote
     int32_t* vote_list;  // work list of the voting chain: int4 entries, one segment per workgroup in evaluation order (irv_plan.h)
     int32_t* vote_evals_arr; // evaluation counter per wave of the chain's grid (statistics), then the entries per workgroup segment
     int32_t* interp_list;     // target list of the interpolation (its own buffers: the voting chain may be CONTINUED after
@@ -194,6 +194,7 @@ hipError_t adc_launch_cost_records(adc_handle* h);
 int adc_agg_small_L(const adc_handle* h);
 hipError_t adc_launch_arms(adc_handle* h); // arms, support counts, colour-difference maps (= _left + _rest)
 hipError_t adc_launch_arms_left(adc_handle* h); // what needs only the left image: packed pixels, arms, maxima, support counts
+hipError_t adc_launch_sup_counts(adc_handle* h); // support counts + region boxes from the arms in HBM (debug surface)
 hipError_t adc_launch_arms_rest(adc_handle* h); // what reads both images: colour-step maps (+ paper mode: right-image arms)
 hipError_t adc_launch_aggregate_tail(adc_handle* h); // the dividing H pass adc_launch_aggregate left to the scanline stage, as a launch of its own
 hipError_t adc_launch_records(adc_handle* h); // arms + counts -> packed aggregation records

@@ -1007,7 +1007,8 @@ int adc_debug_run(adc_handle* h, int stage, int arg)
     case ADC_RUN_REGION_VOTING: // arg > 0: launch budget (kernels) of this run, e.g. 4 to force the continuation path
         if (arg < 0) { h->irv_budget = -arg; return 0; } // test hook: only set the budget of the NEXT Match's chain (continuation inside adc_wait)
         if (arg > 0) h->irv_budget = arg;
-        e = adc_run_region_voting(h);
+        e = adc_launch_sup_counts(h); // (the region boxes of the votes come out of the arms stage; here the arms may have been written by the test)
+        if (e == hipSuccess) e = adc_run_region_voting(h);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) { int cont = 0; e = adc_voting_finish(h, &cont); }
         break;

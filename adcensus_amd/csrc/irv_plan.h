@@ -231,35 +231,44 @@ ADC_HD IrvBlock irv_decode_block(uint32_t vx, uint32_t vy, uint32_t vz, uint32_t
 //     the PASSING level keeps its bin if  c - k > ts,  m - k >= 1,  fl((m - k) / (c + k)) > th  and  m - k > m2 + k
 // (multistep_refiner.cpp:199-214 is `max > 0 && count > ts && max * 1.0f / count > th`, first maximum = lowest bin on ties).  The
 // entry's budget K = the largest such k over the levels up to the deciding one; K = 0 ("any change -> evaluate again") is always
-// valid, and every value below the true bound is (the tests are monotone in k): the closed forms below round DOWN and are then
-// checked with the reference's own float expression.  The change tiles say WHERE something changed in the previous kernel; a
+// valid, and every value below the true bound is (the tests are monotone in k): the closed forms below round DOWN with a margin
+// (tests/emul/emul_irv.cpp: emul_irv_slack_check proves them against the reference's own float expression).  The change tiles say WHERE something changed in the previous kernel; a
 // bit per pixel says which pixels did, and an entry whose tiles were hit counts the changed pixels inside its region (row by row:
 // the bitmap words of the row and the row's arms, every load independent of the others), subtracts them from its budget and is only
 // re-evaluated when the budget is used up.  Exactness: every state change of a region pixel since the entry's last evaluation is
 // counted at least once (changes of the kernel the entry was evaluated in are counted in the next one, whether its gather saw
 // them or not), so an entry that is skipped would vote what it voted.
-ADC_HD bool irv_ratio_gt(int m, int c, float th) { return (float)m * 1.0f / (float)c > th; } // the reference's expression (adc_vote_decide)
-ADC_HD int irv_level_slack(bool pass, int c, int m, int m2, int ts, float th)
+// Division-free form (a vote computes it for every level it decides): thresholds moved by 2^-20 relative -- 16 times the rounding of
+// the reference's float division -- so that the REAL inequalities  (m + k) <= tl (c - k)  /  (m - k) >= th (c + k)  imply the
+// float tests; solved for k with a precomputed 1 / (1 + t); the float evaluation of the bound is off by < 0.01 for counts up to
+// 69 x 69, one is subtracted.  K = 0 is always valid, and so is every value below the true bound (the tests are monotone in k).
+struct IrvSlackK { float tl, rl, th, rh; int ok; };
+ADC_HD IrvSlackK irv_slack_consts(float irv_th)
 {
-    const float den = 1.0f + th;
+    IrvSlackK s;
+    s.tl = irv_th * (1.0f - 9.5367431640625e-07f); // 1 - 2^-20
+    s.th = irv_th * (1.0f + 9.5367431640625e-07f);
+    s.ok = irv_th >= 0.0f && irv_th <= 4.0f;       // (anything else -- incl. NaN: no ratio-based slack at all)
+    s.rl = s.ok ? 1.0f / (1.0f + s.tl) : 0.0f;
+    s.rh = s.ok ? 1.0f / (1.0f + s.th) : 0.0f;
+    return s;
+}
+ADC_HD int irv_level_slack(bool pass, int c, int m, int m2, int ts, const IrvSlackK& q)
+{
     int K;
     if (!pass) {
         const int k1 = ts - c; // c + k <= ts
-        int kf = -1;           // the ratio test stays false
-        if (c >= 1 && den > 0.0f) {
-            const float x = (th * (float)c - (float)m) / den;
-            kf = x >= 0.0f ? adc_imin((int)x, c - 1) : -1;
-            for (int guard = 0; guard < 4 && kf >= 0 && irv_ratio_gt(m + kf, c - kf, th); guard++) kf--;
-            if (kf >= 0 && irv_ratio_gt(m + kf, c - kf, th)) kf = -1;
+        int kf = -1;           // the ratio test stays false: (m + k) <= tl (c - k)
+        if (q.ok && c >= 1) {
+            const float x = (q.tl * (float)c - (float)m) * q.rl;
+            kf = x >= 1.0f ? adc_imin((int)x - 1, c - 1) : -1;
         }
         K = adc_imax(k1, kf);
     } else {
-        int kc = 0;
-        if (den > 0.0f) {
-            const float x = ((float)m - th * (float)c) / den;
-            kc = x >= 1.0f ? (int)x : 0;
-            for (int guard = 0; guard < 4 && kc >= 1 && !irv_ratio_gt(m - kc, c + kc, th); guard++) kc--;
-            if (kc >= 1 && !irv_ratio_gt(m - kc, c + kc, th)) kc = 0;
+        int kc = 0; // the ratio test stays true: (m - k) >= th (c + k)
+        if (q.ok) {
+            const float x = ((float)m - q.th * (float)c) * q.rh;
+            kc = x >= 1.0f ? (int)x - 1 : 0;
         }
         K = adc_imin(adc_imin(c - ts - 1, (m - m2 - 1) >> 1), adc_imin(kc, m - 1));
     }

@@ -72,18 +72,24 @@ __global__ __launch_bounds__(256) void k_build_arms(const uint32_t* __restrict__
 // Support counts (cross_aggregator.cpp:271-325):
 //   id 0 (horizontal first): cnt = sum_{t=-top..bottom} (left+right+1)(x, y+t)
 //   id 1 (vertical first)  : cnt = sum_{t=-left..right} (top+bottom+1)(x+t, y)
+// The walk over the pixel's region rows also yields the widest H arms of those rows -- the bounding box of the cross region, which
+// the region-voting chain wants per work-list entry (k_voting.hip: read box of a vote, change tiles to watch): bbox[p] = {0, 0, widest
+// left arm, widest right arm} (round 6: a kernel of its own, 48 us at 1080p, before).
 __global__ __launch_bounds__(256) void k_sup_counts(const uchar4* __restrict__ arms, uint16_t* __restrict__ sup_h,
-                                                    uint16_t* __restrict__ sup_v, int W, int H)
+                                                    uint16_t* __restrict__ sup_v, int W, int H, uchar4* __restrict__ bbox)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const uchar4 a = arms[(size_t)y * W + x];
-    int ch = 0, cv = 0;
+    int ch = 0, cv = 0, mla = 0, mra = 0;
     for (int t = -(int)a.z; t <= (int)a.w; t++) {
         const uchar4 q = arms[(size_t)(y + t) * W + x];
         ch += (int)q.x + (int)q.y + 1;
+        mla = adc_imax(mla, (int)q.x);
+        mra = adc_imax(mra, (int)q.y);
     }
+    bbox[(size_t)y * W + x] = make_uchar4(0, 0, (unsigned char)mla, (unsigned char)mra);
     for (int t = -(int)a.x; t <= (int)a.y; t++) {
         const uchar4 q = arms[(size_t)y * W + x + t];
         cv += (int)q.z + (int)q.w + 1;
@@ -162,7 +168,17 @@ hipError_t adc_launch_arms_left(adc_handle* h)
     hipLaunchKernelGGL(k_build_arms, grid, block, 0, h->heavy, h->bgrx_l, reinterpret_cast<uchar4*>(h->arms), p.W, p.H,
                        p.opt.cross_L1, p.opt.cross_L2, p.opt.cross_t1, p.opt.cross_t2, h->armmax);
     hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->heavy, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
-                       p.W, p.H);
+                       p.W, p.H, reinterpret_cast<uchar4*>(h->irv_bbox));
+    return hipGetLastError();
+}
+// Support counts + region boxes alone, from the arms in HBM (debug surface: a stage test writes the arms and runs the region voting
+// without the arms stage in front of it)
+hipError_t adc_launch_sup_counts(adc_handle* h)
+{
+    const AdcParams& p = h->p;
+    dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(k_sup_counts, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms), h->sup_h, h->sup_v,
+                       p.W, p.H, reinterpret_cast<uchar4*>(h->irv_bbox));
     return hipGetLastError();
 }
 // ... and the part that reads BOTH images: the colour-step maps of the scanline penalties (scanline_optimizer.cpp:114-126), and

@@ -50,28 +50,10 @@ extern "C" int adc_debug_irv_timing(long long* out, int which, int n)
 #define IRV_TR(slot) do { } while (0)
 #endif
 
-// Boxes of a pixel's vote (computed once per Match; arms do not change).  The cross region of p spans rows y-top..y+bottom.
-//   dependency box: only pixels that PRECEDE p in raster order can influence its vote, i.e. rows y-top..y; its horizontal
-//     extent is the widest H arm of those rows                                                      -> {ml, mr}
-//   read box: the widest H arms over ALL region rows -- the rectangle whose state blocks a vote requests together with the row
-//     arms, in the same memory round trip (the row arms then only mask)                             -> {ml_all, mr_all}
-// bbox[p] = {ml, mr, ml_all, mr_all}; it becomes word z of the pixel's work-list entry unchanged.
-__global__ __launch_bounds__(256) void k_irv_bbox(const uchar4* __restrict__ arms, uchar4* __restrict__ bbox, int W, int H)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const uchar4 a = arms[(size_t)y * W + x];
-    int ml = 0, mr = 0, mla = 0, mra = 0;
-    for (int t = -(int)a.z; t <= (int)a.w; t++) {
-        const uchar4 q = arms[(size_t)(y + t) * W + x];
-        mla = adc_imax(mla, (int)q.x);
-        mra = adc_imax(mra, (int)q.y);
-        if (t == 0) { ml = mla; mr = mra; }
-    }
-    bbox[(size_t)y * W + x] = make_uchar4((unsigned char)ml, (unsigned char)mr, (unsigned char)mla, (unsigned char)mra);
-}
-
+// Box of a pixel's vote: bbox[p] = {-, -, ml_all, mr_all} = the widest H arms over ALL region rows -- the rectangle whose state
+// blocks a vote requests together with the row arms, in the same memory round trip (the row arms then only mask), and whose change
+// tiles decide whether the entry is looked at again.  Written by k_sup_counts (k_arms.hip), whose walk over the region rows yields it
+// for free; it becomes the high half of word z of the pixel's work-list entry.
 // Did a pixel of the tile box [tx0, tx1] x [ty0, ty1] change in the round whose stamp is want4 (replicated byte)?  A
 // tile row of the box = 16 bytes from a dword-aligned column; bytes outside the box are forced non-zero (nk = ~byte
 // mask per dword, from a 16-bit byte-valid mask) before the any-zero-byte test of (word ^ stamp); three tile rows are
@@ -110,6 +92,45 @@ __device__ __forceinline__ unsigned long long irv_mask64(int lo, int hi)
     if (hi <= lo) return 0ull;
     const unsigned long long up = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
     return up & ~((1ull << lo) - 1ull); // (lo < hi <= 64: the shift is defined)
+}
+
+// ... and, per LANE (phase 1 of a round: one entry per lane), the changed pixels of an entry's whole region in one plane of the bitmap:
+// per row ONE 16-byte load of the bitmap and the row's arms (both addresses known up front: no load depends on another), IRV_RC_ROWS rows
+// per trip (more rows in flight cost registers: the round kernel must stay at 64 VGPRs without scratch).  The entry's own pixel does
+// not count (a pixel does not vote for itself).  Lanes without work pass ya > yb.
+#ifndef IRV_RC_ROWS
+#define IRV_RC_ROWS 1
+#endif
+__device__ __forceinline__ int irv_region_changes(const uint32_t* __restrict__ px, int pitch, const uint32_t* __restrict__ arms32, int W,
+                                                  int x, int y, int xa, int ya, int yb)
+{
+    const uint32_t base = (uint32_t)(xa >> 5);
+    const int x0 = (int)(base << 5); // pixel of bit 0 of the window
+    int cnt = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int r = ya; r <= yb; r += IRV_RC_ROWS) {
+        uint4 v[IRV_RC_ROWS];
+        uint32_t a[IRV_RC_ROWS];
+#pragma unroll
+        for (int u = 0; u < IRV_RC_ROWS; u++) {
+            const int rr = adc_imin(r + u, yb);
+            v[u] = *reinterpret_cast<const uint4*>(px + (uint32_t)(rr * pitch) + base);
+            a[u] = arms32[(uint32_t)(rr * W + x)];
+        }
+#pragma unroll
+        for (int u = 0; u < IRV_RC_ROWS; u++) {
+            const int lo = x - (int)(a[u] & 255u) - x0, hi = x + (int)((a[u] >> 8) & 255u) - x0 + 1; // bits [lo, hi) of the 128-bit window
+            unsigned long long m0 = irv_mask64(adc_imin(lo, 64), adc_imin(hi, 64)), m1 = irv_mask64(adc_imax(lo - 64, 0), adc_imax(hi - 64, 0));
+            if (r + u == y) {
+                const int sb = x - x0;
+                if (sb < 64) m0 &= ~(1ull << sb); else m1 &= ~(1ull << (sb - 64));
+            }
+            const int c = __popcll(((unsigned long long)v[u].x | ((unsigned long long)v[u].y << 32)) & m0) +
+                          __popcll(((unsigned long long)v[u].z | ((unsigned long long)v[u].w << 32)) & m1);
+            cnt += r + u <= yb ? c : 0;
+        }
+    }
+    return cnt;
 }
 
 // Wave-wide maximum / sum of non-negative ints in 6 DPP steps (row rotations, then the two row broadcasts of gfx9); the
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                                                 int32_t* __restrict__ evals_arr, int seg_cap, int xcd_mode, int32_t* wg_n /* entries per workgroup segment */,
                                                 unsigned long long* listed_bits /* bit p: pixel p goes on the work list (BEGIN -> BEGIN2) */,
                                                 uint32_t* px_chg /* per-pixel change bitmap, IRV_PX_PLANES planes (slack budgets) */, int px_pitch,
-                                                int use_slack)
+                                                int use_slack, int slack_r, int slack_fmin)
 {
     IRV_TR(8);
     IRV_T(0);
@@ -333,6 +354,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     // stamp aliasing a kernel 510 launches earlier can only cause a redundant evaluation, never a missed one).  Phase 2: the
     // dirty entries of the workgroup are pooled in LDS.  Phase 3: wave w evaluates pool entries w, w + waves, ...
     const int round = pl.s.round;
+    const IrvSlackK sq = irv_slack_consts(irv_th); // (uniform: thresholds and reciprocals of the division-free slack bounds)
     extern __shared__ int lds_dyn[]; // [waves][IRV_LEVELS][D] histograms, then the pool: [waves][64] int4
     int* hist = lds_dyn + wave * (IRV_LEVELS * D);
     int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * IRV_LEVELS * D + 3) & ~3)); // (16-byte aligned whatever D is)
@@ -368,7 +390,29 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             box = irv_box_dirty(chg_rd, tpitch, adc_imax(0, x - ml) / IRV_TILE, have ? adc_imin(W - 1, x + mr) / IRV_TILE : -1,
                                 adc_imax(0, y - top) / IRV_TILE, adc_imin(H - 1, y + bot) / IRV_TILE, want4);
         }
-        const bool dirty = i < ng && (round == 0 || box);
+        bool dirty = i < ng && (round == 0 || box);
+        int bud = 0x10000; // pool item's budget word: bit 16 = "must vote" (round 0; the previous kernel's changes have used the budget up)
+        if (use_slack && round != 0) { // (uniform) slack budgets, irv_plan.h
+            bud = (int)((uint32_t)ent.z & 0xFFFFu) | 0x20000; // bit 17: the previous kernel's changes are not counted yet (done at the entry's turn)
+            // A wave with MANY entries whose tiles were hit (a heavy round: pool items are what a round's time is made of) filters them
+            // here, one entry per lane: count the pixels of the region that changed in the previous kernel.  Budget used up: the entry
+            // votes.  Budget left >= slack_r: it is not looked at in this round.  In between: it goes into the pool as a "maybe" and, at
+            // its turn in the sweep, counts what THIS kernel has changed in its region so far (the cascade down a band lives on that: the
+            // first form, without the maybes, cost 40 % more rounds).  A wave with few hits (the tail rounds) skips the per-lane walk
+            // -- it is a chain of up to 69 dependent trips -- and lets the turn count both planes.
+            if (__popcll(__ballot(dirty)) >= slack_fmin) { // (wave-uniform)
+                const bool cand = dirty;
+                const int p = cand ? ent.x : 0, y = cand ? ent.w : 0, x = p - y * W;
+                const int top = (int)(((uint32_t)ent.y >> 16) & 255u), bot = (int)((uint32_t)ent.y >> 24);
+                const int ml = (int)(((uint32_t)ent.z >> 16) & 255u);
+                const int used = irv_region_changes(px_chg + (size_t)((k + 2) % IRV_PX_PLANES) * px_words, px_pitch, arms32, W, x, y, x - ml,
+                                                    cand ? y - top : 1, cand ? y + bot : 0);
+                const int rem = (int)((uint32_t)ent.z & 0xFFFFu) - used;
+                dirty = cand && rem < slack_r;
+                bud = rem < 0 ? 0x10000 : rem;
+                if (cand && rem >= 0 && used > 0) seg[i].z = (int)(((uint32_t)ent.z & 0xFFFF0000u) | (uint32_t)rem);
+            }
+        }
         IRV_T(2);
         // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
         // consumers find pool item t by a prefix sum over the (<= 16) counts
@@ -377,7 +421,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         if (dirty) { // {pixel, arms, state | read box << 16, row}
             pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)((mystate & 0xFFFFu) | ((uint32_t)ent.z & 0xFFFF0000u)), ent.w);
             pidx[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = i;
-            pbud[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = (int)((uint32_t)ent.z & 0xFFFFu);
+            pbud[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = bud;
         }
         __syncthreads();
         const int cnt_l = lane < WPB ? pcount[lane] : 0;
@@ -400,12 +444,14 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
             // the read box: blocks blkL .. blkR cover the widest row of the region
             const int blkL = (x - (int)((pz >> 16) & 255u)) >> 3, blkR = (x + (int)(pz >> 24)) >> 3;
-            // Slack budget (irv_plan.h, bottom): the entry's tiles were hit, but did ENOUGH pixels of its region change to possibly flip
-            // its vote?  Lane r counts, over the span of region row r, the bits of the previous kernel's change plane (complete) and of
-            // this kernel's (as far as the XCD's L2 has them: what the sweep down the band has just changed) -- same round trip as the
-            // arms and the first state blocks.  Within the budget: no vote; the previous kernel's changes come off the budget (this
-            // kernel's are the next kernel's "previous").  Regions of more than 64 rows (arms beyond 31 up AND down) always vote.
-            const bool slack_now = use_slack && round != 0 && nrows <= 64; // (uniform)
+            // Slack budget (irv_plan.h, bottom), a "maybe" of phase 1: the previous kernel's changes left it a small budget -- have the
+            // pixels THIS kernel has changed in its region so far (as far as the XCD's L2 has them: what the sweep down the band has just
+            // done) used it up?  Lane r counts over the span of region row r, same round trip as the arms and the first state blocks.
+            // Within the budget: no vote (this kernel's changes are the next kernel's "previous": they come off the budget there).
+            // Regions of more than 64 rows (arms beyond 31 up AND down) always vote.
+            const bool slack_now = use_slack && !(ebud & 0x10000) && nrows <= 64; // (uniform) a "maybe" of phase 1
+            const bool need_prev = (ebud & 0x20000) != 0;                         // ... whose wave did not count the previous kernel's changes
+            const int ebudv = ebud & 0xFFFF;
             const int wx0 = ((x - (int)((pz >> 16) & 255u)) >> 5) << 5;     // pixel of bit 0 of the 128-bit bitmap window of every region row
             bool skipped = false;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
@@ -423,13 +469,13 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                     vfirst = irv_ld_state(st_rs, in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own);
                 }
                 if (slack_now) {
-                    irv_u32x4 cp = {0u, 0u, 0u, 0u}, cc = {0u, 0u, 0u, 0u};
+                    irv_u32x4 cc = {0u, 0u, 0u, 0u}, cp = {0u, 0u, 0u, 0u};
                     if (myr < nrows) {
                         const uint32_t off = (uint32_t)((y - top + myr) * px_pitch + (wx0 >> 5)) * 4u; // bytes into a plane
-                        cp = __builtin_amdgcn_raw_buffer_load_b128(px_rs, (int)(px_rd_off + off), 0, 0);
                         cc = __builtin_amdgcn_raw_buffer_load_b128(px_rs, (int)(px_wr_off + off), 0, IRV_LOAD_CPOL);
+                        if (need_prev) cp = __builtin_amdgcn_raw_buffer_load_b128(px_rs, (int)(px_rd_off + off), 0, 0);
                     }
-                    int lo = x - (int)(a2 & 255u) - wx0, hi = x + (int)((a2 >> 8) & 255u) - wx0 + 1; // bits [lo, hi) of the window
+                    const int lo = x - (int)(a2 & 255u) - wx0, hi = x + (int)((a2 >> 8) & 255u) - wx0 + 1; // bits [lo, hi) of the window
                     unsigned long long m0 = irv_mask64(adc_imin(lo, 64), adc_imin(hi, 64)), m1 = irv_mask64(adc_imax(lo - 64, 0), adc_imax(hi - 64, 0));
                     if (myr == top) { // a pixel does not vote for itself: its own change does not count
                         const int sb = x - wx0;
@@ -437,12 +483,12 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                     }
                     int c2 = 0;
                     if (myr < nrows)
-                        c2 = (__popcll(((unsigned long long)cp.x | ((unsigned long long)cp.y << 32)) & m0) + __popcll(((unsigned long long)cp.z | ((unsigned long long)cp.w << 32)) & m1)) |
-                             ((__popcll(((unsigned long long)cc.x | ((unsigned long long)cc.y << 32)) & m0) + __popcll(((unsigned long long)cc.z | ((unsigned long long)cc.w << 32)) & m1)) << 16);
+                        c2 = (__popcll(((unsigned long long)cc.x | ((unsigned long long)cc.y << 32)) & m0) + __popcll(((unsigned long long)cc.z | ((unsigned long long)cc.w << 32)) & m1)) |
+                             ((__popcll(((unsigned long long)cp.x | ((unsigned long long)cp.y << 32)) & m0) + __popcll(((unsigned long long)cp.z | ((unsigned long long)cp.w << 32)) & m1)) << 16);
                     c2 = irv_wave_sum(c2); // (<= 64 rows x 69 pixels per half)
-                    const int usedp = c2 & 0xFFFF, usedc = c2 >> 16;
-                    if (usedp + usedc <= ebud) {
-                        if (lane == 0 && usedp > 0) seg[eidx].z = (int)((pz & 0xFFFF0000u) | (uint32_t)(ebud - usedp));
+                    const int usedc = c2 & 0xFFFF, usedp = c2 >> 16;
+                    if (usedc + usedp <= ebudv) { // what changed fits the budget: no vote (this kernel's changes come off the budget next round)
+                        if (lane == 0 && usedp > 0) seg[eidx].z = (int)((pz & 0xFFFF0000u) | (uint32_t)(ebudv - usedp));
                         skipped = true;
                         break;
                     }
@@ -506,7 +552,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             int below = -1;
             // slack budget of this outcome (irv_plan.h): the minimum over the levels up to the deciding one; levels without new pixels
             // repeat their predecessor's histogram (same slack), leading empty levels are failing levels with c = m = 0
-            int K = (present & 1u) ? 0xFFFF : irv_level_slack(false, 0, 0, 0, irv_ts, irv_th);
+            int K = (present & 1u) ? 0xFFFF : irv_level_slack(false, 0, 0, 0, irv_ts, sq);
 #pragma clang loop unroll(disable)
             for (int it = 0; it < IRV_LEVELS; it++) {
                 if (!((present >> it) & 1u)) continue; // (uniform)
@@ -522,7 +568,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 cnt = irv_wave_sum(cnt);
                 const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
                 const bool pass = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-                if (use_slack) K = adc_imin(K, irv_level_slack(pass, cnt, bh, cnt - bh, irv_ts, irv_th)); // (runner-up <= everything outside the top bin)
+                if (use_slack) K = adc_imin(K, irv_level_slack(pass, cnt, bh, cnt - bh, irv_ts, sq)); // (runner-up <= everything outside the top bin)
                 if (pass) {
                     ns = (uint32_t)bbin | ((uint32_t)it << IRV_F_SHIFT) | ((uint32_t)lp << IRV_LIST_SHIFT);
                     break;
@@ -625,6 +671,19 @@ static int irv_use_slack()
     static const int v = [] { const char* e = getenv("ADC_IRV_SLACK"); return e ? atoi(e) : 1; }();
     return v;
 }
+// entries whose budget, after the previous kernel's changes, is still >= this are not looked at in a round; the ones below it are
+// "maybes" (k_irv_u, phase 1).  0 = none (cheapest rounds, but the in-kernel cascade stops at them: more rounds); large = all.
+static int irv_slack_r()
+{
+    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK_R"); return e ? atoi(e) : 4; }();
+    return v;
+}
+// a wave filters its entries in phase 1 when at least this many of its 64 had their tiles hit (65 = never: every hit entry is a "maybe")
+static int irv_slack_fmin()
+{
+    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK_FMIN"); return e ? atoi(e) : 16; }();
+    return v;
+}
 size_t adc_irv_px_words(int W, int H) { return (size_t)IRV_PX_PLANES * irv_px_pitch(W) * H + 16; }
 static hipError_t irv_launch(adc_handle* h, int k0, int count)
 {
@@ -638,7 +697,7 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count)
                            reinterpret_cast<const uint32_t*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
                            p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr,
                            (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, h->irv_xcd_mode), h->irv_xcd_mode, h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
-                           reinterpret_cast<unsigned long long*>(h->elig), h->irv_px, irv_px_pitch(p.W), irv_use_slack());
+                           reinterpret_cast<unsigned long long*>(h->elig), h->irv_px, irv_px_pitch(p.W), irv_use_slack(), irv_slack_r(), irv_slack_fmin());
     return hipGetLastError();
 }
 
@@ -648,9 +707,6 @@ hipError_t adc_run_region_voting(adc_handle* h)
 {
     const AdcParams& p = h->p;
     hipError_t e;
-    dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(k_irv_bbox, grid, block, 0, h->stream, reinterpret_cast<const uchar4*>(h->arms),
-                       reinterpret_cast<uchar4*>(h->irv_bbox), p.W, p.H);
     if ((e = hipMemsetAsync(h->vote_counters, 0, IRV_CTRL_INTS * sizeof(int32_t), h->stream)) != hipSuccess) return e;
     if (h->irv_budget < 4) h->irv_budget = 4;
     if ((e = irv_launch(h, 0, h->irv_budget)) != hipSuccess) return e;
