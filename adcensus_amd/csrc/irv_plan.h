@@ -113,28 +113,47 @@ ADC_HD int irv_bands(int H) { return (H + IRV_BAND - 1) / IRV_BAND; }
 // own XCD (the L2s of different XCDs are not coherent inside a kernel), and workgroup g runs on XCD g % 8: so a whole BAND belongs
 // to one XCD -- band b to XCD b % 8 -- and its tiles are dealt out over the G / 8 workgroups of that XCD.  (G % 8 != 0: plain
 // round-robin; still exact, the sweep just sees less of itself.)
-//   tile index inside the XCD:  u = (b / 8) * tiles_x + tx;   workgroup = (b % 8) + 8 * (u % (G / 8))
-ADC_HD int irv_xcd_units(int W, int H, int xcd) { return ((irv_bands(H) - xcd + 7) / 8) * irv_tiles_x(W); } // tiles of the bands b % 8 == xcd
+//   band index inside the XCD: bi = b / 8;   workgroup = (b % 8) + 8 * ((bi * (tiles_x + IRV_SKEW) + tx) % (G / 8))
+// IRV_SKEW (round 6): without it a workgroup owns the SAME columns in every band of its XCD (1920 columns = 15 x 128), and the
+// invalid regions of an image are tall -- occlusion bands along depth edges -- so the workgroups whose columns run through them held
+// up to twice the average list (1080p structured pair: 360 entries against a mean of 184) and set the time of every heavy round; with
+// the columns shifted by 37 from band to band the longest list is 242.
+#ifndef IRV_SKEW
+#define IRV_SKEW 37
+#endif
+ADC_HD int irv_xcd_bands(int H, int xcd) { return (irv_bands(H) - xcd + 7) / 8; } // bands b with b % 8 == xcd
+// first column of workgroup m (inside its XCD, `per` workgroups) in band bi, and how many columns it has there
+ADC_HD int irv_band_first(int tiles_x, int per, int m, int bi)
+{
+    const long v = (long)bi * (tiles_x + IRV_SKEW);
+    return (int)((((long)m - v) % per + per) % per);
+}
+ADC_HD int irv_band_count(int tiles_x, int per, int r) { return r < tiles_x ? (tiles_x - 1 - r) / per + 1 : 0; }
 ADC_HD int irv_wg_tiles(int W, int H, int G, int g, int xcd)
 {
     if (!xcd || G % 8 != 0) { const int n = irv_tiles_x(W) * irv_bands(H); return g < n ? (n - g + G - 1) / G : 0; }
-    const int per = G / 8, m = g / 8, n = irv_xcd_units(W, H, g % 8);
-    return m < n ? (n - m + per - 1) / per : 0;
+    const int per = G / 8, m = g / 8, tiles_x = irv_tiles_x(W), nb = irv_xcd_bands(H, g % 8);
+    int n = 0;
+    for (int bi = 0; bi < nb; bi++) n += irv_band_count(tiles_x, per, irv_band_first(tiles_x, per, m, bi));
+    return n;
 }
-// the k-th tile of workgroup g: *band, *tx
+// the k-th tile of workgroup g: *band, *tx  (k < irv_wg_tiles; bands in ascending order, columns ascending inside a band)
 ADC_HD void irv_wg_tile(int W, int H, int G, int g, int k, int xcd, int* band, int* tx)
 {
     const int tiles_x = irv_tiles_x(W);
     if (!xcd || G % 8 != 0) { const int t = g + k * G; *band = t / tiles_x; *tx = t % tiles_x; return; }
-    const int u = g / 8 + k * (G / 8);
-    *band = (u / tiles_x) * 8 + g % 8;
-    *tx = u % tiles_x;
-    (void)H;
+    const int per = G / 8, m = g / 8, nb = irv_xcd_bands(H, g % 8);
+    for (int bi = 0; bi < nb; bi++) {
+        const int r = irv_band_first(tiles_x, per, m, bi), n = irv_band_count(tiles_x, per, r);
+        if (k < n) { *band = bi * 8 + g % 8; *tx = r + k * per; return; }
+        k -= n;
+    }
+    *band = 0; *tx = 0; // (not reached for k < irv_wg_tiles)
 }
 ADC_HD long irv_seg_cap(int W, int H, int G, int WPB, int xcd)
 {
     const long most = (!xcd || G % 8 != 0) ? ((long)irv_tiles_x(W) * irv_bands(H) + G - 1) / G
-                                 : ((long)((irv_bands(H) + 7) / 8) * irv_tiles_x(W) + G / 8 - 1) / (G / 8); // tiles of the busiest workgroup
+                                 : (long)((irv_bands(H) + 7) / 8) * ((irv_tiles_x(W) + G / 8 - 1) / (G / 8)); // tiles of the busiest workgroup (upper bound)
     const long per = most * IRV_BAND * IRV_TCOLS, batch = 64L * WPB;
     return ((per + batch - 1) / batch) * batch;
 }

@@ -37,16 +37,18 @@
 
 #ifdef IRV_TIMING // diagnosis build (tools/build_variant.sh): where does a kernel of the chain spend its time?
 // wave 0 of every 64th workgroup stamps s_memtime at the stage boundaries (drained loads) and s_memrealtime at entry / exit
-__device__ long long g_irv_t[8][8192][10];
+__device__ long long g_irv_t[8][8192][12]; // [sampled workgroup][kernel][8 cycle stamps, entry / exit real time, pool items, votes of wave 0]
 #define IRV_TSEL ((blockIdx.x & 63) == 0 && blockIdx.x < 512 && threadIdx.x < 64)
 #define IRV_T(slot) do { if (IRV_TSEL) { long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (threadIdx.x == 0 && k < 8192) g_irv_t[blockIdx.x >> 6][k][slot] = t_; } } while (0)
+#define IRV_TV(slot, val) do { if (IRV_TSEL && threadIdx.x == 0 && k < 8192) g_irv_t[blockIdx.x >> 6][k][slot] = (long long)(val); } while (0)
 #define IRV_TR(slot) do { if (IRV_TSEL) { long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (threadIdx.x == 0 && k < 8192) g_irv_t[blockIdx.x >> 6][k][slot] = t_; } } while (0)
 extern "C" int adc_debug_irv_timing(long long* out, int which, int n)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_irv_t), (size_t)n * 10 * sizeof(long long), (size_t)which * 8192 * 10 * sizeof(long long));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_irv_t), (size_t)n * 12 * sizeof(long long), (size_t)which * 8192 * 12 * sizeof(long long));
 }
 #else
 #define IRV_T(slot) do { } while (0)
+#define IRV_TV(slot, val) do { } while (0)
 #define IRV_TR(slot) do { } while (0)
 #endif
 
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         const int excl = incl - cnt_l;
         const int total = __builtin_amdgcn_readlane(incl, 15);
         IRV_T(3);
+        IRV_TV(10, total);
         for (int t = wave; t < total; t += WPB) {
             const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
             const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
@@ -590,6 +593,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         }
     }
     if (lane == 0 && evals) evals_arr[gw] += evals;
+    IRV_TV(11, evals);
     IRV_TR(9);
 }
 
