@@ -114,12 +114,14 @@ ADC_HD int irv_bands(int H) { return (H + IRV_BAND - 1) / IRV_BAND; }
 // to one XCD -- band b to XCD b % 8 -- and its tiles are dealt out over the G / 8 workgroups of that XCD.  (G % 8 != 0: plain
 // round-robin; still exact, the sweep just sees less of itself.)
 //   band index inside the XCD: bi = b / 8;   workgroup = (b % 8) + 8 * ((bi * (tiles_x + IRV_SKEW) + tx) % (G / 8))
-// IRV_SKEW (round 6): without it a workgroup owns the SAME columns in every band of its XCD (1920 columns = 15 x 128), and the
-// invalid regions of an image are tall -- occlusion bands along depth edges -- so the workgroups whose columns run through them held
-// up to twice the average list (1080p structured pair: 360 entries against a mean of 184) and set the time of every heavy round; with
-// the columns shifted by 37 from band to band the longest list is 242.
+// IRV_SKEW (round 6, measured, default 0): without it a workgroup owns the SAME columns in every band of its XCD (1920 columns =
+// 15 x 128), and the invalid regions of an image are tall -- occlusion bands along depth edges -- so the workgroups whose columns run
+// through them hold up to twice the average list (1080p structured pair: 360 entries against a mean of 184; 242 with the columns
+// shifted by 37 from band to band).  Balanced lists made every heavy round ~35 % shorter -- and the chain 37 -> 49 rounds long: the
+// workgroups then run at the same pace, and a vote finds fewer of this kernel's fills in its rows (the slow workgroups of the
+// unbalanced layout see their neighbours' work finished).  Refine stage 3.48 -> 3.72 ms (profiles/r6_k8_experiments.txt).
 #ifndef IRV_SKEW
-#define IRV_SKEW 37
+#define IRV_SKEW 0
 #endif
 ADC_HD int irv_xcd_bands(int H, int xcd) { return (irv_bands(H) - xcd + 7) / 8; } // bands b with b % 8 == xcd
 // first column of workgroup m (inside its XCD, `per` workgroups) in band bi, and how many columns it has there

@@ -101,13 +101,20 @@ __device__ __forceinline__ unsigned long long irv_mask64(int lo, int hi)
 // per trip (more rows in flight cost registers: the round kernel must stay at 64 VGPRs without scratch).  The entry's own pixel does
 // not count (a pixel does not vote for itself).  Lanes without work pass ya > yb.
 #ifndef IRV_RC_ROWS
-#define IRV_RC_ROWS 1
+#define IRV_RC_ROWS 4
+#endif
+#ifndef IRV_RC_EXACT
+#define IRV_RC_EXACT 0 // 1: every row with its own arms (fewer entries survive the filter, but an arms load and two 64-bit masks per row)
 #endif
 __device__ __forceinline__ int irv_region_changes(const uint32_t* __restrict__ px, int pitch, const uint32_t* __restrict__ arms32, int W,
-                                                  int x, int y, int xa, int ya, int yb)
+                                                  int x, int y, int xa, int xb, int ya, int yb)
 {
     const uint32_t base = (uint32_t)(xa >> 5);
     const int x0 = (int)(base << 5); // pixel of bit 0 of the window
+    // (default: the bounding RECTANGLE of the region -- a superset, so the count is an upper bound: still exact, a few more entries
+    // vote; the masks are the same for every row and no arms are fetched)
+    const int rlo = xa - x0, rhi = xb - x0 + 1;
+    const unsigned long long rm0 = irv_mask64(adc_imin(rlo, 64), adc_imin(rhi, 64)), rm1 = irv_mask64(adc_imax(rlo - 64, 0), adc_imax(rhi - 64, 0));
     int cnt = 0;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int r = ya; r <= yb; r += IRV_RC_ROWS) {
@@ -117,21 +124,23 @@ __device__ __forceinline__ int irv_region_changes(const uint32_t* __restrict__ p
         for (int u = 0; u < IRV_RC_ROWS; u++) {
             const int rr = adc_imin(r + u, yb);
             v[u] = *reinterpret_cast<const uint4*>(px + (uint32_t)(rr * pitch) + base);
-            a[u] = arms32[(uint32_t)(rr * W + x)];
+            if (IRV_RC_EXACT) a[u] = arms32[(uint32_t)(rr * W + x)];
         }
 #pragma unroll
         for (int u = 0; u < IRV_RC_ROWS; u++) {
-            const int lo = x - (int)(a[u] & 255u) - x0, hi = x + (int)((a[u] >> 8) & 255u) - x0 + 1; // bits [lo, hi) of the 128-bit window
-            unsigned long long m0 = irv_mask64(adc_imin(lo, 64), adc_imin(hi, 64)), m1 = irv_mask64(adc_imax(lo - 64, 0), adc_imax(hi - 64, 0));
-            if (r + u == y) {
-                const int sb = x - x0;
-                if (sb < 64) m0 &= ~(1ull << sb); else m1 &= ~(1ull << (sb - 64));
+            unsigned long long m0 = rm0, m1 = rm1;
+            if (IRV_RC_EXACT) {
+                const int lo = x - (int)(a[u] & 255u) - x0, hi = x + (int)((a[u] >> 8) & 255u) - x0 + 1; // bits [lo, hi) of the 128-bit window
+                m0 = irv_mask64(adc_imin(lo, 64), adc_imin(hi, 64));
+                m1 = irv_mask64(adc_imax(lo - 64, 0), adc_imax(hi - 64, 0));
             }
             const int c = __popcll(((unsigned long long)v[u].x | ((unsigned long long)v[u].y << 32)) & m0) +
                           __popcll(((unsigned long long)v[u].z | ((unsigned long long)v[u].w << 32)) & m1);
             cnt += r + u <= yb ? c : 0;
         }
     }
+    // the entry's own pixel does not count (a pixel does not vote for itself)
+    if (ya <= yb) cnt -= (int)((px[(uint32_t)(y * pitch) + (uint32_t)(x >> 5)] >> (x & 31)) & 1u);
     return cnt;
 }
 
@@ -406,8 +415,8 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 const bool cand = dirty;
                 const int p = cand ? ent.x : 0, y = cand ? ent.w : 0, x = p - y * W;
                 const int top = (int)(((uint32_t)ent.y >> 16) & 255u), bot = (int)((uint32_t)ent.y >> 24);
-                const int ml = (int)(((uint32_t)ent.z >> 16) & 255u);
-                const int used = irv_region_changes(px_chg + (size_t)((k + 2) % IRV_PX_PLANES) * px_words, px_pitch, arms32, W, x, y, x - ml,
+                const int ml = (int)(((uint32_t)ent.z >> 16) & 255u), mr = (int)((uint32_t)ent.z >> 24);
+                const int used = irv_region_changes(px_chg + (size_t)((k + 2) % IRV_PX_PLANES) * px_words, px_pitch, arms32, W, x, y, x - ml, x + mr,
                                                     cand ? y - top : 1, cand ? y + bot : 0);
                 const int rem = (int)((uint32_t)ent.z & 0xFFFFu) - used;
                 dirty = cand && rem < slack_r;

@@ -151,14 +151,14 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                             int nh = 0;
                             const long w0 = b0 + ((i - b0) / 64) * 64;
                             for (long j = w0; j < std::min(w0 + 64, std::min((long)wg_n[g], b0 + BT)); j++) nh += hit[j - b0];
-                            if (nh >= slack_fmin && dirty) { // the wave filters: changed pixels of the region in the previous kernel's plane
+                            if (nh >= slack_fmin && dirty) { // the wave filters: changed pixels of the region's bounding RECTANGLE in the previous
+                                // kernel's plane (a superset of the region: an upper bound of the count; no arm lookups), without the entry's own pixel
                                 const uint8_t* pa = arms + (size_t)p * 4;
+                                const int ml = (e.box >> 16) & 255, mr = (e.box >> 24) & 255;
                                 int used = 0;
-                                for (int yy = y - (int)pa[2]; yy <= y + (int)pa[3]; yy++) {
-                                    const uint8_t* a2 = arms + ((size_t)yy * W + x) * 4;
-                                    for (int xx = x - (int)a2[0]; xx <= x + (int)a2[1]; xx++)
+                                for (int yy = y - (int)pa[2]; yy <= y + (int)pa[3]; yy++)
+                                    for (int xx = x - ml; xx <= x + mr; xx++)
                                         if (!(yy == y && xx == x)) used += px_rd[(size_t)yy * W + xx];
-                                }
                                 const int rem = (e.box & 0xFFFF) - used;
                                 dirty = rem < slack_r;
                                 bud = rem < 0 ? 0x10000 : rem;
