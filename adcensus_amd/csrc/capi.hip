@@ -181,6 +181,7 @@ static hipError_t alloc_all(adc_handle* h)
     h->chg_pitch = (((p.W + 7) / 8 + 3) & ~3) + 16;
     const size_t tiles = (size_t)h->chg_pitch * ((p.H + 7) / 8) + 64;
     HIP_OK(hipMalloc(&h->chg_a, 2 * tiles)); // two planes (round parity)
+    HIP_OK(hipMalloc(&h->irv_cold, 64));
     HIP_OK(hipMalloc(&h->irv_px, adc_irv_px_words(p.W, p.H) * sizeof(uint32_t)));
     HIP_OK(hipMemset(h->irv_px, 0, adc_irv_px_words(p.W, p.H) * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&h->edge, P));
@@ -315,7 +316,7 @@ void adc_destroy(adc_handle* h)
     void* bufs[] = {h->img_l_own, h->img_r_own, h->gray_l, h->gray_r, h->census_l, h->census_r, h->arms, h->sup_h, h->sup_v,
                     h->armmax, h->rec_h, h->rec_v, h->rec2_h, h->rec2_v, h->agg_sink, h->so_cls, h->so_seam, h->cdiff_lh, h->cdiff_lv, h->cdiff_rh, h->cdiff_rv, h->vol_a, h->vol_b, h->lut_ad, h->lut_census,
                     h->ray_sincos, h->ray_tab, h->bgrx_l, h->cost_rrec, h->cost_lrec, h->med_hand, h->med_sink, h->disp_l, h->disp_r, h->disp_tmp, h->label, h->elig, h->irv_bbox, h->vote_list, h->vote_evals_arr, h->interp_list, h->interp_counters, h->itp_cells, h->st16, h->disp_vote, h->vote_counters,
-                    h->chg_a, h->irv_px, h->edge, h->arms_r, h->bgrx_r, h->armmax_r, h->vol_c};
+                    h->chg_a, h->irv_px, h->irv_cold, h->edge, h->arms_r, h->bgrx_r, h->armmax_r, h->vol_c};
     for (void* b : bufs) if (b) hipFree(b);
     if (h->pin_in) hipHostFree(h->pin_in);
     if (h->pin_out) hipHostFree(h->pin_out);

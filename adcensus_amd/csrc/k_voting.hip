@@ -31,6 +31,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 
 #include "irv_plan.h"
@@ -87,8 +88,8 @@ __device__ __forceinline__ bool irv_box_dirty(const uint8_t* __restrict__ chg_rd
     return dirty;
 }
 
-// Slack budgets (irv_plan.h, bottom): bits [lo, hi) of a 64-bit word, 0 <= lo, hi <= 64 -- the span of a region row inside the 128-bit
-// window of the per-pixel change bitmap a vote's lane reads for that row
+// Slack budgets (irv_plan.h, bottom): bits [lo, hi) of a 64-bit word, 0 <= lo, hi <= 64 -- one half of a row span inside the 128-bit
+// window of the per-pixel change bitmap
 __device__ __forceinline__ unsigned long long irv_mask64(int lo, int hi)
 {
     if (hi <= lo) return 0ull;
@@ -103,10 +104,13 @@ __device__ __forceinline__ unsigned long long irv_mask64(int lo, int hi)
 #ifndef IRV_RC_ROWS
 #define IRV_RC_ROWS 4
 #endif
+#ifndef IRV_RC_INLINE
+#define IRV_RC_INLINE __forceinline__
+#endif
 #ifndef IRV_RC_EXACT
 #define IRV_RC_EXACT 0 // 1: every row with its own arms (fewer entries survive the filter, but an arms load and two 64-bit masks per row)
 #endif
-__device__ __forceinline__ int irv_region_changes(const uint32_t* __restrict__ px, int pitch, const uint32_t* __restrict__ arms32, int W,
+__device__ IRV_RC_INLINE int irv_region_changes(const uint32_t* __restrict__ px, int pitch, const uint32_t* __restrict__ arms32, int W,
                                                   int x, int y, int xa, int xb, int ya, int yb)
 {
     const uint32_t base = (uint32_t)(xa >> 5);
@@ -197,15 +201,24 @@ __device__ __forceinline__ uint4 irv_ld_state(__amdgpu_buffer_rsrc_t rs, uint32_
 // pooled in LDS and dealt out to its waves round-robin, so a round takes ceil(pool / waves) votes per wave -- without
 // the pooling a tail round is as slow as the unluckiest wave (3-4 votes of ~3 us each where the average is 0.2).
 #define IRV_MAXW 16
-__global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, int k, const uint8_t* __restrict__ label, float* __restrict__ disp,
-                                                float* disp_io, /* the pipeline's map: read by the first BEGIN, written by FINAL (no copies) */
-                                                const uint16_t* __restrict__ sup_h, uint16_t* st16, int4* list, uint8_t* chg,
-                                                const uint32_t* __restrict__ bbox32, const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
-                                                int D, int min_region, int chg_bytes, int tpitch, int irv_ts, float irv_th,
-                                                int32_t* __restrict__ evals_arr, int seg_cap, int xcd_mode, int32_t* wg_n /* entries per workgroup segment */,
-                                                unsigned long long* listed_bits /* bit p: pixel p goes on the work list (BEGIN -> BEGIN2) */,
+// What only the BEGIN / BEGIN2 / FINAL kernels of a chain touch lives in a small block in device memory (IrvCold, filled per launch
+// of a chain): as kernel arguments these six pointers stayed in scalar registers through the ROUND kernels' vote loop, which then
+// spilled scalars into vector lanes -- 279 v_readlane in the hot loop, refine stage +0.5 ms (round 6, measured).
+struct IrvCold {
+    const uint8_t* label;
+    float* disp;     // the chain's working copy of the map
+    float* disp_io;  // the pipeline's map: read by the first BEGIN, written by FINAL (no copies)
+    const uint16_t* sup_h;
+    const uint32_t* bbox32;
+    unsigned long long* listed_bits; // bit p: pixel p goes on the work list (BEGIN -> BEGIN2)
+    int min_region, xcd_mode;
+};
+__global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, int k, const IrvCold* cold, uint16_t* st16, int4* list, uint8_t* chg,
+                                                const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
+                                                int D, int chg_bytes, int tpitch, int irv_ts, float irv_th,
+                                                int32_t* __restrict__ evals_arr, int seg_cap, int32_t* wg_n /* entries per workgroup segment */,
                                                 uint32_t* px_chg /* per-pixel change bitmap, IRV_PX_PLANES planes (slack budgets) */, int px_pitch,
-                                                int use_slack, int slack_r, int slack_fmin)
+                                                int use_slack)
 {
     IRV_TR(8);
     IRV_T(0);
@@ -250,6 +263,11 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     if (pl.act == IRV_DONE) return;
     int32_t* acc = ctrl + IRV_ACC + (k & 63);
     if (pl.act == IRV_BEGIN || pl.act == IRV_FINAL_WB) {
+        const uint8_t* label = cold->label;
+        float *disp = cold->disp, *disp_io = cold->disp_io;
+        const uint16_t* sup_h = cold->sup_h;
+        unsigned long long* listed_bits = cold->listed_bits;
+        const int min_region = cold->min_region;
         // evaluation statistics: every wave counts in its own slot (a same-address atomic per wave and round cost more
         // than the votes of a tail round: they retire at ~8 ns each); cleared by the first kernel, summed by the last
         if (pl.act == IRV_BEGIN)
@@ -313,6 +331,9 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         return;
     }
     if (pl.act == IRV_BEGIN2) {
+        const uint32_t* bbox32 = cold->bbox32;
+        const unsigned long long* listed_bits = cold->listed_bits;
+        const int xcd_mode = cold->xcd_mode;
         // The workgroup walks ITS tiles (irv_plan.h: tile t belongs to workgroup t % G) row by row and compacts the listed pixels
         // into its segment in the order (row inside the band, tile, column) -- the order in which the rounds evaluate them.
         __shared__ int wcnt[IRV_MAXW];
@@ -365,20 +386,17 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
     // stamp aliasing a kernel 510 launches earlier can only cause a redundant evaluation, never a missed one).  Phase 2: the
     // dirty entries of the workgroup are pooled in LDS.  Phase 3: wave w evaluates pool entries w, w + waves, ...
     const int round = pl.s.round;
-    const IrvSlackK sq = irv_slack_consts(irv_th); // (uniform: thresholds and reciprocals of the division-free slack bounds)
     extern __shared__ int lds_dyn[]; // [waves][IRV_LEVELS][D] histograms, then the pool: [waves][64] int4
     int* hist = lds_dyn + wave * (IRV_LEVELS * D);
     int4* pool = reinterpret_cast<int4*>(lds_dyn + ((WPB * IRV_LEVELS * D + 3) & ~3)); // (16-byte aligned whatever D is)
     __shared__ int pcount[IRV_MAXW];
-    __shared__ int pidx[IRV_MAXW * 64], pbud[IRV_MAXW * 64]; // segment index of a pool item and its slack budget (written back there)
+    __shared__ int pidx[IRV_MAXW * 64]; // segment index of a pool item (its new slack budget is written back there)
     const int sub = lane >> 2, bslot = lane & 3;
     if (use_slack) { // the per-pixel change plane the NEXT kernel writes (read by this kernel's predecessor: free now)
         uint32_t* px_clr = px_chg + (size_t)((k + 1) % IRV_PX_PLANES) * px_words;
         for (uint32_t t = blockIdx.x * T + threadIdx.x; t < px_words; t += gridDim.x * T) px_clr[t] = 0u;
     }
     const __amdgpu_buffer_rsrc_t st_rs = __builtin_amdgcn_make_buffer_rsrc(st16, 0, (SP * H + 64) * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t px_rs = __builtin_amdgcn_make_buffer_rsrc(px_chg, 0, (int)(IRV_PX_PLANES * px_words * 4u + 64u), 0x00020000);
-    const uint32_t px_rd_off = (uint32_t)((k + 2) % IRV_PX_PLANES) * px_words * 4u, px_wr_off = (uint32_t)(k % IRV_PX_PLANES) * px_words * 4u;
     const int ng = __builtin_amdgcn_readfirstlane(ngv); // entries of this workgroup's segment, in evaluation order
     int evals = 0;
     if (ng > 0) // the wave's histograms start empty; every vote clears the rows it has touched behind itself
@@ -402,27 +420,21 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                                 adc_imax(0, y - top) / IRV_TILE, adc_imin(H - 1, y + bot) / IRV_TILE, want4);
         }
         bool dirty = i < ng && (round == 0 || box);
-        int bud = 0x10000; // pool item's budget word: bit 16 = "must vote" (round 0; the previous kernel's changes have used the budget up)
-        if (use_slack && round != 0) { // (uniform) slack budgets, irv_plan.h
-            bud = (int)((uint32_t)ent.z & 0xFFFFu) | 0x20000; // bit 17: the previous kernel's changes are not counted yet (done at the entry's turn)
-            // A wave with MANY entries whose tiles were hit (a heavy round: pool items are what a round's time is made of) filters them
-            // here, one entry per lane: count the pixels of the region that changed in the previous kernel.  Budget used up: the entry
-            // votes.  Budget left >= slack_r: it is not looked at in this round.  In between: it goes into the pool as a "maybe" and, at
-            // its turn in the sweep, counts what THIS kernel has changed in its region so far (the cascade down a band lives on that: the
-            // first form, without the maybes, cost 40 % more rounds).  A wave with few hits (the tail rounds) skips the per-lane walk
-            // -- it is a chain of up to 69 dependent trips -- and lets the turn count both planes.
-            if (__popcll(__ballot(dirty)) >= slack_fmin) { // (wave-uniform)
-                const bool cand = dirty;
-                const int p = cand ? ent.x : 0, y = cand ? ent.w : 0, x = p - y * W;
-                const int top = (int)(((uint32_t)ent.y >> 16) & 255u), bot = (int)((uint32_t)ent.y >> 24);
-                const int ml = (int)(((uint32_t)ent.z >> 16) & 255u), mr = (int)((uint32_t)ent.z >> 24);
-                const int used = irv_region_changes(px_chg + (size_t)((k + 2) % IRV_PX_PLANES) * px_words, px_pitch, arms32, W, x, y, x - ml, x + mr,
-                                                    cand ? y - top : 1, cand ? y + bot : 0);
-                const int rem = (int)((uint32_t)ent.z & 0xFFFFu) - used;
-                dirty = cand && rem < slack_r;
-                bud = rem < 0 ? 0x10000 : rem;
-                if (cand && rem >= 0 && used > 0) seg[i].z = (int)(((uint32_t)ent.z & 0xFFFF0000u) | (uint32_t)rem);
-            }
+        if (use_slack && round != 0) { // (uniform) slack budgets, irv_plan.h: an entry whose tiles were hit counts, one entry per lane, the pixels
+            // of its region's bounding rectangle that changed in the previous kernel.  Budget used up: the entry votes again.  Otherwise it
+            // is not looked at in this round (pool items are what a heavy round's time is made of) and the count comes off its budget.
+            // (Measured and dropped, profiles/r6_k8_experiments.txt: entries with a small remaining budget kept as "maybes" that count this
+            // kernel's changes at their turn in the sweep -- fewer rounds, but every maybe is a pool item and the vote loop ran out of
+            // scalar registers; the same at the turn for everything: 48 % fewer votes, no shorter rounds.)
+            const bool cand = dirty;
+            const int p = cand ? ent.x : 0, y = cand ? ent.w : 0, x = p - y * W;
+            const int top = (int)(((uint32_t)ent.y >> 16) & 255u), bot = (int)((uint32_t)ent.y >> 24);
+            const int ml = (int)(((uint32_t)ent.z >> 16) & 255u), mr = (int)((uint32_t)ent.z >> 24);
+            const int used = irv_region_changes(px_chg + (size_t)((k + 2) % IRV_PX_PLANES) * px_words, px_pitch, arms32, W, x, y, x - ml, x + mr,
+                                                cand ? y - top : 1, cand ? y + bot : 0);
+            const int rem = (int)((uint32_t)ent.z & 0xFFFFu) - used;
+            dirty = cand && rem < 0;
+            if (cand && rem >= 0 && used > 0) seg[i].z = (int)(((uint32_t)ent.z & 0xFFFF0000u) | (uint32_t)rem);
         }
         IRV_T(2);
         // pool: every wave puts its dirty entries into its own 64 slots and publishes the count -- ONE barrier; the
@@ -432,7 +444,6 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
         if (dirty) { // {pixel, arms, state | read box << 16, row}
             pool[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = make_int4(ent.x, ent.y, (int)((mystate & 0xFFFFu) | ((uint32_t)ent.z & 0xFFFF0000u)), ent.w);
             pidx[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = i;
-            pbud[wave * 64 + __popcll(dm & ((1ull << lane) - 1ull))] = bud;
         }
         __syncthreads();
         const int cnt_l = lane < WPB ? pcount[lane] : 0;
@@ -445,7 +456,6 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             const int sw = __popcll(__ballot(lane < WPB && incl <= t)); // the wave whose slots hold item t
             const int4 pe = pool[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]; // (one LDS address for the whole wave: a broadcast read)
             const int eidx = __builtin_amdgcn_readfirstlane(pidx[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]);
-            const int ebud = __builtin_amdgcn_readfirstlane(pbud[sw * 64 + (t - __builtin_amdgcn_readlane(excl, sw))]);
             const int p = __builtin_amdgcn_readfirstlane(pe.x), armsp = __builtin_amdgcn_readfirstlane(pe.y), y = __builtin_amdgcn_readfirstlane(pe.w);
             const uint32_t pz = (uint32_t)__builtin_amdgcn_readfirstlane(pe.z);
             const uint32_t cur = pz & 0xFFFFu; // (only this wave writes the entry in this round)
@@ -456,16 +466,6 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             const uint32_t own = (uint32_t)(y * SP + x) & ~7u; // the entry's own block: address of masked-out loads
             // the read box: blocks blkL .. blkR cover the widest row of the region
             const int blkL = (x - (int)((pz >> 16) & 255u)) >> 3, blkR = (x + (int)(pz >> 24)) >> 3;
-            // Slack budget (irv_plan.h, bottom), a "maybe" of phase 1: the previous kernel's changes left it a small budget -- have the
-            // pixels THIS kernel has changed in its region so far (as far as the XCD's L2 has them: what the sweep down the band has just
-            // done) used it up?  Lane r counts over the span of region row r, same round trip as the arms and the first state blocks.
-            // Within the budget: no vote (this kernel's changes are the next kernel's "previous": they come off the budget there).
-            // Regions of more than 64 rows (arms beyond 31 up AND down) always vote.
-            const bool slack_now = use_slack && !(ebud & 0x10000) && nrows <= 64; // (uniform) a "maybe" of phase 1
-            const bool need_prev = (ebud & 0x20000) != 0;                         // ... whose wave did not count the previous kernel's changes
-            const int ebudv = ebud & 0xFFFF;
-            const int wx0 = ((x - (int)((pz >> 16) & 255u)) >> 5) << 5;     // pixel of bit 0 of the 128-bit bitmap window of every region row
-            bool skipped = false;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int rbase = 0; rbase < nrows; rbase += 64) {
                 // the H arms of (up to 64) region rows (lane r holds row rbase + r; handed to the row slots with a shuffle) AND
@@ -479,31 +479,6 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 {
                     const bool in0 = sub < rend && blkL + bslot <= blkR;
                     vfirst = irv_ld_state(st_rs, in0 ? (uint32_t)((y - top + rbase + sub) * SP + (blkL + bslot) * 8) : own);
-                }
-                if (slack_now) {
-                    irv_u32x4 cc = {0u, 0u, 0u, 0u}, cp = {0u, 0u, 0u, 0u};
-                    if (myr < nrows) {
-                        const uint32_t off = (uint32_t)((y - top + myr) * px_pitch + (wx0 >> 5)) * 4u; // bytes into a plane
-                        cc = __builtin_amdgcn_raw_buffer_load_b128(px_rs, (int)(px_wr_off + off), 0, IRV_LOAD_CPOL);
-                        if (need_prev) cp = __builtin_amdgcn_raw_buffer_load_b128(px_rs, (int)(px_rd_off + off), 0, 0);
-                    }
-                    const int lo = x - (int)(a2 & 255u) - wx0, hi = x + (int)((a2 >> 8) & 255u) - wx0 + 1; // bits [lo, hi) of the window
-                    unsigned long long m0 = irv_mask64(adc_imin(lo, 64), adc_imin(hi, 64)), m1 = irv_mask64(adc_imax(lo - 64, 0), adc_imax(hi - 64, 0));
-                    if (myr == top) { // a pixel does not vote for itself: its own change does not count
-                        const int sb = x - wx0;
-                        if (sb < 64) m0 &= ~(1ull << sb); else m1 &= ~(1ull << (sb - 64));
-                    }
-                    int c2 = 0;
-                    if (myr < nrows)
-                        c2 = (__popcll(((unsigned long long)cc.x | ((unsigned long long)cc.y << 32)) & m0) + __popcll(((unsigned long long)cc.z | ((unsigned long long)cc.w << 32)) & m1)) |
-                             ((__popcll(((unsigned long long)cp.x | ((unsigned long long)cp.y << 32)) & m0) + __popcll(((unsigned long long)cp.z | ((unsigned long long)cp.w << 32)) & m1)) << 16);
-                    c2 = irv_wave_sum(c2); // (<= 64 rows x 69 pixels per half)
-                    const int usedc = c2 & 0xFFFF, usedp = c2 >> 16;
-                    if (usedc + usedp <= ebudv) { // what changed fits the budget: no vote (this kernel's changes come off the budget next round)
-                        if (lane == 0 && usedp > 0) seg[eidx].z = (int)((pz & 0xFFFF0000u) | (uint32_t)(ebudv - usedp));
-                        skipped = true;
-                        break;
-                    }
                 }
                 IRV_T(4);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
@@ -551,7 +526,6 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                     }
                 }
             }
-            if (skipped) continue; // (uniform)
             evals++;
             IRV_T(6);
             // The votes of the iterations, lowest first, on the CUMULATIVE histograms (row `it` += the last non-empty row below it);
@@ -564,6 +538,7 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             int below = -1;
             // slack budget of this outcome (irv_plan.h): the minimum over the levels up to the deciding one; levels without new pixels
             // repeat their predecessor's histogram (same slack), leading empty levels are failing levels with c = m = 0
+            const IrvSlackK sq = irv_slack_consts(irv_th); // (per vote, not kept across the loop: scalar registers are scarce here)
             int K = (present & 1u) ? 0xFFFF : irv_level_slack(false, 0, 0, 0, irv_ts, sq);
 #pragma clang loop unroll(disable)
             for (int it = 0; it < IRV_LEVELS; it++) {
@@ -684,33 +659,29 @@ static int irv_use_slack()
     static const int v = [] { const char* e = getenv("ADC_IRV_SLACK"); return e ? atoi(e) : 1; }();
     return v;
 }
-// entries whose budget, after the previous kernel's changes, is still >= this are not looked at in a round; the ones below it are
-// "maybes" (k_irv_u, phase 1).  0 = none (cheapest rounds, but the in-kernel cascade stops at them: more rounds); large = all.
-static int irv_slack_r()
-{
-    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK_R"); return e ? atoi(e) : 4; }();
-    return v;
-}
-// a wave filters its entries in phase 1 when at least this many of its 64 had their tiles hit (65 = never: every hit entry is a "maybe")
-static int irv_slack_fmin()
-{
-    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK_FMIN"); return e ? atoi(e) : 16; }();
-    return v;
-}
 size_t adc_irv_px_words(int W, int H) { return (size_t)IRV_PX_PLANES * irv_px_pitch(W) * H + 16; }
 static hipError_t irv_launch(adc_handle* h, int k0, int count)
 {
+    if (k0 == 0) { // the block of rarely used arguments of this chain (stream-ordered: in front of the chain's first kernel)
+        IrvCold c;
+        c.label = h->label; c.disp = h->disp_vote; c.disp_io = h->disp_l; c.sup_h = h->sup_h;
+        c.bbox32 = reinterpret_cast<const uint32_t*>(h->irv_bbox); c.listed_bits = reinterpret_cast<unsigned long long*>(h->elig);
+        c.min_region = irv_min_region(h); c.xcd_mode = h->irv_xcd_mode;
+        static_assert(sizeof(IrvCold) <= 64, "adc_handle::irv_cold / irv_cold_host hold 64 bytes");
+        memcpy(h->irv_cold_host, &c, sizeof(c));
+        const hipError_t e = hipMemcpyAsync(h->irv_cold, h->irv_cold_host, sizeof(IrvCold), hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) return e;
+    }
     const AdcParams& p = h->p;
     const int tpitch = h->chg_pitch, chg_bytes = tpitch * ((p.H + IRV_TILE - 1) / IRV_TILE);
     const int wpb = irv_wpb(p.D);
     const size_t lds = (size_t)((wpb * IRV_LEVELS * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
     for (int i = 0; i < count; i++)
-        hipLaunchKernelGGL(k_irv_u, dim3((unsigned)h->irv_grid), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i, h->label,
-                           h->disp_vote, h->disp_l, h->sup_h, h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
-                           reinterpret_cast<const uint32_t*>(h->irv_bbox), reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch,
-                           p.dmin, p.D, irv_min_region(h), chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th, h->vote_evals_arr,
-                           (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, h->irv_xcd_mode), h->irv_xcd_mode, h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
-                           reinterpret_cast<unsigned long long*>(h->elig), h->irv_px, irv_px_pitch(p.W), irv_use_slack(), irv_slack_r(), irv_slack_fmin());
+        hipLaunchKernelGGL(k_irv_u, dim3((unsigned)h->irv_grid), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i,
+                           reinterpret_cast<const IrvCold*>(h->irv_cold), h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
+                           reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch, p.dmin, p.D, chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th,
+                           h->vote_evals_arr, (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, h->irv_xcd_mode), h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
+                           h->irv_px, irv_px_pitch(p.W), irv_use_slack());
     return hipGetLastError();
 }
 

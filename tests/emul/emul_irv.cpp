@@ -16,8 +16,6 @@
 extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                 int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, int use_slack, long* out_stats)
 {
-    const int slack_r = use_slack > 0 ? (use_slack >> 8) & 255 : 0, slack_fmin = use_slack > 0 ? (use_slack >> 16) & 255 : 0;
-    use_slack = use_slack != 0; // (use_slack = 1 | slack_r << 8 | slack_fmin << 16: the kernel's ADC_IRV_SLACK_R / ADC_IRV_SLACK_FMIN)
     const int P = W * H, SP = (W + 7) & ~7, T = IRV_TILE;
     const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
     const int G = groups > 0 ? groups : 2, WPB = wpb > 0 ? wpb : 4; // the (emulated) grid: decides the list layout
@@ -117,23 +115,8 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
             for (int g = G; g > 1; g--) std::swap(wgs[g - 1], wgs[rand() % g]);
             for (int g : wgs)
                 for (long b0 = 0; b0 < wg_n[g]; b0 += BT) {
-                    std::vector<int> todo, tbud;
+                    std::vector<int> todo;
                     std::vector<uint16_t> seen;
-                    // phase 1 is done wave by wave (64 consecutive entries of the batch): a wave with >= slack_fmin hit entries filters them
-                    std::vector<uint8_t> hit;
-                    for (long i = b0; i < std::min((long)wg_n[g], b0 + BT); i++) {
-                        const Ent& e = list[(size_t)g * cap + i];
-                        const int p = e.p, y = e.y, x = p - y * W;
-                        bool dirty = round == 0;
-                        if (!dirty) {
-                            const int top = (e.arms >> 16) & 255, bot = (e.arms >> 24) & 255, ml = (e.box >> 16) & 255, mr = (e.box >> 24) & 255;
-                            const int tx0 = std::max(0, x - ml) / T, tx1 = std::min(W - 1, x + mr) / T;
-                            const int ty0 = std::max(0, y - top) / T, ty1 = std::min(H - 1, y + bot) / T;
-                            for (int ty = ty0; ty <= ty1; ty++)
-                                for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want;
-                        }
-                        hit.push_back(dirty);
-                    }
                     for (long i = b0; i < std::min((long)wg_n[g], b0 + BT); i++) {
                         Ent& e = list[(size_t)g * cap + i];
                         const int p = e.p, y = e.y, x = p - y * W;
@@ -145,27 +128,20 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                             for (int ty = ty0; ty <= ty1; ty++)
                                 for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want; // byte stamps (k_voting.hip)
                         }
-                        int bud = 0x10000; // bit 16: must vote
-                        if (use_slack && round != 0) {
-                            bud = (e.box & 0xFFFF) | 0x20000; // bit 17: the previous kernel's changes are counted at the entry's turn
-                            int nh = 0;
-                            const long w0 = b0 + ((i - b0) / 64) * 64;
-                            for (long j = w0; j < std::min(w0 + 64, std::min((long)wg_n[g], b0 + BT)); j++) nh += hit[j - b0];
-                            if (nh >= slack_fmin && dirty) { // the wave filters: changed pixels of the region's bounding RECTANGLE in the previous
-                                // kernel's plane (a superset of the region: an upper bound of the count; no arm lookups), without the entry's own pixel
-                                const uint8_t* pa = arms + (size_t)p * 4;
-                                const int ml = (e.box >> 16) & 255, mr = (e.box >> 24) & 255;
-                                int used = 0;
-                                for (int yy = y - (int)pa[2]; yy <= y + (int)pa[3]; yy++)
-                                    for (int xx = x - ml; xx <= x + mr; xx++)
-                                        if (!(yy == y && xx == x)) used += px_rd[(size_t)yy * W + xx];
-                                const int rem = (e.box & 0xFFFF) - used;
-                                dirty = rem < slack_r;
-                                bud = rem < 0 ? 0x10000 : rem;
-                                if (rem >= 0 && used > 0) e.box = (int)(((uint32_t)e.box & 0xFFFF0000u) | (uint32_t)rem);
-                            }
+                        if (dirty && use_slack && round != 0) { // phase 1 (k_voting.hip): changed pixels of the region's bounding RECTANGLE in the
+                            // previous kernel's plane (a superset of the region: an upper bound; no arm lookups), without the entry's own pixel,
+                            // against the entry's budget
+                            const uint8_t* pa = arms + (size_t)p * 4;
+                            const int ml = (e.box >> 16) & 255, mr = (e.box >> 24) & 255;
+                            int used = 0;
+                            for (int yy = y - (int)pa[2]; yy <= y + (int)pa[3]; yy++)
+                                for (int xx = x - ml; xx <= x + mr; xx++)
+                                    if (!(yy == y && xx == x)) used += px_rd[(size_t)yy * W + xx];
+                            const int rem = (e.box & 0xFFFF) - used;
+                            dirty = rem < 0;
+                            if (rem >= 0 && used > 0) e.box = (int)(((uint32_t)e.box & 0xFFFF0000u) | (uint32_t)rem);
                         }
-                        if (dirty) { todo.push_back((int)i); tbud.push_back(bud); seen.push_back(st[(size_t)y * SP + x]); } // (phase 1 reads the entry's own state)
+                        if (dirty) { todo.push_back((int)i); seen.push_back(st[(size_t)y * SP + x]); } // (phase 1 reads the entry's own state)
                     }
                     for (size_t c0 = 0; c0 < todo.size(); c0 += WPB) {
                         std::vector<size_t> grp;
@@ -176,26 +152,6 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                             const int p = e.p, y = e.y, x = p - y * W;
                             const uint32_t cur = seen[t];
                             const int lp = (int)(cur >> IRV_LIST_SHIFT);
-                            if (use_slack && !(tbud[t] & 0x10000)) { // a "maybe": the slack test at the entry's TURN (k_voting.hip) -- changed pixels
-                                // of the region in this kernel's plane so far (and in the previous kernel's when the wave did not filter),
-                                // against the budget; regions of more than 64 rows always vote; the entry's own pixel does not count
-                                const uint8_t* pa = arms + (size_t)p * 4;
-                                const int nrows = (int)pa[2] + (int)pa[3] + 1, budget = tbud[t] & 0xFFFF;
-                                const bool need_prev = (tbud[t] & 0x20000) != 0;
-                                int usedp = 0, usedc = 0;
-                                for (int yy = y - (int)pa[2]; yy <= y + (int)pa[3]; yy++) {
-                                    const uint8_t* a2 = arms + ((size_t)yy * W + x) * 4;
-                                    for (int xx = x - (int)a2[0]; xx <= x + (int)a2[1]; xx++) {
-                                        if (yy == y && xx == x) continue;
-                                        if (need_prev) usedp += px_rd[(size_t)yy * W + xx];
-                                        usedc += px_wr[(size_t)yy * W + xx];
-                                    }
-                                }
-                                if (nrows <= 64 && usedp + usedc <= budget) {
-                                    if (usedp > 0) list[(size_t)g * cap + todo[t]].box = (int)(((uint32_t)e.box & 0xFFFF0000u) | (uint32_t)(budget - usedp));
-                                    continue;
-                                }
-                            }
                             total_evals++;
                             std::fill(hist.begin(), hist.end(), 0);
                             const uint8_t* arm = arms + (size_t)p * 4;
@@ -255,7 +211,7 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
 extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats)
 {
-    return emul_irv_chain2(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, 1 | (4 << 8) | (16 << 16), out_stats);
+    return emul_irv_chain2(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, 1, out_stats);
 }
 
 // The closed forms of irv_level_slack (irv_plan.h) against the definition: for random (pass, c, m, m2, ts, th) the returned K must
