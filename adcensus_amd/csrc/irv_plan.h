@@ -270,30 +270,30 @@ ADC_HD IrvSlackK irv_slack_consts(float irv_th)
     s.tl = irv_th * (1.0f - 9.5367431640625e-07f); // 1 - 2^-20
     s.th = irv_th * (1.0f + 9.5367431640625e-07f);
     s.ok = irv_th >= 0.0f && irv_th <= 4.0f;       // (anything else -- incl. NaN: no ratio-based slack at all)
+    // (a reciprocal accurate to an ulp is plenty: the bounds subtract one for errors of < 0.01)
+#if defined(__HIP_DEVICE_COMPILE__)
+    s.rl = s.ok ? __builtin_amdgcn_rcpf(1.0f + s.tl) : 0.0f;
+    s.rh = s.ok ? __builtin_amdgcn_rcpf(1.0f + s.th) : 0.0f;
+#else
     s.rl = s.ok ? 1.0f / (1.0f + s.tl) : 0.0f;
     s.rh = s.ok ? 1.0f / (1.0f + s.th) : 0.0f;
+#endif
     return s;
 }
+// (Branch-free on purpose: as nested conditionals inside the vote loop of k_irv_u this function cost the kernel the scalar registers
+// of its execution masks -- 37 spill reloads per vote, measured.)
 ADC_HD int irv_level_slack(bool pass, int c, int m, int m2, int ts, const IrvSlackK& q)
 {
-    int K;
-    if (!pass) {
-        const int k1 = ts - c; // c + k <= ts
-        int kf = -1;           // the ratio test stays false: (m + k) <= tl (c - k)
-        if (q.ok && c >= 1) {
-            const float x = (q.tl * (float)c - (float)m) * q.rl;
-            kf = x >= 1.0f ? adc_imin((int)x - 1, c - 1) : -1;
-        }
-        K = adc_imax(k1, kf);
-    } else {
-        int kc = 0; // the ratio test stays true: (m - k) >= th (c + k)
-        if (q.ok) {
-            const float x = ((float)m - q.th * (float)c) * q.rh;
-            kc = x >= 1.0f ? (int)x - 1 : 0;
-        }
-        K = adc_imin(adc_imin(c - ts - 1, (m - m2 - 1) >> 1), adc_imin(kc, m - 1));
-    }
-    return adc_imax(0, adc_imin(K, 0xFFFF));
+    const float cf = (float)c, mf = (float)m;
+    // a failing level: c + k <= ts, or the ratio test stays false: (m + k) <= tl (c - k)
+    const float xf = q.ok ? (q.tl * cf - mf) * q.rl : 0.0f;
+    const int kf = (c >= 1 && xf >= 1.0f) ? adc_imin((int)xf - 1, c - 1) : -1;
+    const int kfail = adc_imax(ts - c, kf);
+    // the passing level: c - k > ts, m - k >= 1, m - k > m2 + k, and the ratio test stays true: (m - k) >= th (c + k)
+    const float xp = q.ok ? (mf - q.th * cf) * q.rh : 0.0f;
+    const int kc = xp >= 1.0f ? (int)xp - 1 : 0;
+    const int kpass = adc_imin(adc_imin(c - ts - 1, (m - m2 - 1) >> 1), adc_imin(kc, m - 1));
+    return adc_imax(0, adc_imin(pass ? kpass : kfail, 0xFFFF));
 }
 // per-pixel change bitmap: IRV_PX_PLANES planes of H rows x pitch dwords (bit x & 31 of dword x >> 5; the padding dwords stay 0).
 // Kernel k sets bits in plane k % 3, reads plane (k + 2) % 3 (its predecessor's) and clears plane (k + 1) % 3 for its successor.

@@ -213,7 +213,10 @@ struct IrvCold {
     unsigned long long* listed_bits; // bit p: pixel p goes on the work list (BEGIN -> BEGIN2)
     int min_region, xcd_mode;
 };
-__global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, int k, const IrvCold* cold, uint16_t* st16, int4* list, uint8_t* chg,
+// (Register budget: 64 vector registers = 8 waves per SIMD, the whole grid co-resident.  `__launch_bounds__(1024, 8)` also caps the SCALAR
+// registers at 80 -- the slack bounds of round 6 then made the vote loop spill scalars into vector lanes, 37 reloads per vote; with the
+// caps spelled out separately the kernel may use 102 scalars and still runs 8 waves per SIMD.)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8), amdgpu_num_vgpr(64), amdgpu_num_sgpr(102))) void k_irv_u(int32_t* __restrict__ ctrl, int k, const IrvCold* cold, uint16_t* st16, int4* list, uint8_t* chg,
                                                 const uint32_t* __restrict__ arms32, int W, int H, int SP, int dmin,
                                                 int D, int chg_bytes, int tpitch, int irv_ts, float irv_th,
                                                 int32_t* __restrict__ evals_arr, int seg_cap, int32_t* wg_n /* entries per workgroup segment */,
@@ -538,7 +541,11 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
             int below = -1;
             // slack budget of this outcome (irv_plan.h): the minimum over the levels up to the deciding one; levels without new pixels
             // repeat their predecessor's histogram (same slack), leading empty levels are failing levels with c = m = 0
-            const IrvSlackK sq = irv_slack_consts(irv_th); // (per vote, not kept across the loop: scalar registers are scarce here)
+            // (computed in VECTOR registers on purpose -- every lane the same values: as scalar code these bounds cost the vote loop ~40 scalar
+            // registers it does not have: 37 spill reloads per vote, refine stage +0.27 ms, measured)
+            float thv = irv_th;
+            asm volatile("" : "+v"(thv));
+            const IrvSlackK sq = irv_slack_consts(thv);
             int K = (present & 1u) ? 0xFFFF : irv_level_slack(false, 0, 0, 0, irv_ts, sq);
 #pragma clang loop unroll(disable)
             for (int it = 0; it < IRV_LEVELS; it++) {
@@ -555,7 +562,11 @@ __global__ __launch_bounds__(1024, 8) void k_irv_u(int32_t* __restrict__ ctrl, i
                 cnt = irv_wave_sum(cnt);
                 const int bh = key >> 11, bbin = 0x7FF - (key & 0x7FF);
                 const bool pass = adc_vote_decide(bbin, bh, cnt, dmin, irv_ts, irv_th) != ADC_INVALID_FLOAT;
-                if (use_slack) K = adc_imin(K, irv_level_slack(pass, cnt, bh, cnt - bh, irv_ts, sq)); // (runner-up <= everything outside the top bin)
+                if (use_slack) { // (runner-up <= everything outside the top bin)
+                    int cv = cnt, bv = bh;
+                    asm volatile("" : "+v"(cv), "+v"(bv));
+                    K = adc_imin(K, irv_level_slack(pass, cv, bv, cv - bv, irv_ts, sq));
+                }
                 if (pass) {
                     ns = (uint32_t)bbin | ((uint32_t)it << IRV_F_SHIFT) | ((uint32_t)lp << IRV_LIST_SHIFT);
                     break;
