@@ -153,7 +153,8 @@ struct adc_handle {
     int irv_overflows;   // how often adc_wait had to continue the chain (budget too small)
     float *tail_disp_l, *tail_disp_tmp; // buffer roles at the start of the stages behind the voting (for a redo)
     void* irv_cold;                  // device block of the chain's rarely used kernel arguments (64 bytes)
-    unsigned char irv_cold_host[64]; // host copy of the chain's block of rarely used kernel arguments (k_voting.hip: IrvCold)
+    unsigned char irv_cold_host[64]; // the block as it was last sent (k_voting.hip: IrvCold; staged through pin_flags[32..63])
+    int irv_cold_valid, irv_cold_flip;
     int32_t* vote_counters; // voting chain control block (state slots + accumulator ring), median progress words at [160..]
     uint32_t* irv_px;    // per-pixel change bitmap of the voting rounds, IRV_PX_PLANES planes (slack budgets, irv_plan.h)
     uint8_t* chg_a;      // change-tile map of the voting rounds: one byte stamp per 8x8 tile, row pitch chg_pitch

@@ -188,7 +188,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipHostMalloc(&h->pin_in, P * 6, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_out, P * 4, hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&h->pin_flags, 64 * sizeof(int32_t), hipHostMallocDefault));
-    memset(h->pin_flags, 0, 64 * sizeof(int32_t)); // [0] median error, [4..7] armmax + violation flag, [16..23] voting state
+    memset(h->pin_flags, 0, 64 * sizeof(int32_t)); // [0] median error, [4..7] armmax + violation flag, [16..23] voting state, [32..63] staging of the voting chain's cold block
     HIP_OK(hipMemset(h->label, 0, P));
     HIP_OK(hipMemset(h->chg_a, 0, 2 * tiles));
     HIP_OK(hipMemset(h->vol_a, 0, VB));

@@ -673,15 +673,25 @@ static int irv_use_slack()
 size_t adc_irv_px_words(int W, int H) { return (size_t)IRV_PX_PLANES * irv_px_pitch(W) * H + 16; }
 static hipError_t irv_launch(adc_handle* h, int k0, int count)
 {
-    if (k0 == 0) { // the block of rarely used arguments of this chain (stream-ordered: in front of the chain's first kernel)
+    if (k0 == 0) { // the block of rarely used arguments of this chain (stream-ordered: in front of the chain's first kernel).  Staged in
+        // PINNED memory: a copy from pageable host memory is synchronous inside the runtime (+0.19 ms per Match, measured)
         IrvCold c;
         c.label = h->label; c.disp = h->disp_vote; c.disp_io = h->disp_l; c.sup_h = h->sup_h;
         c.bbox32 = reinterpret_cast<const uint32_t*>(h->irv_bbox); c.listed_bits = reinterpret_cast<unsigned long long*>(h->elig);
         c.min_region = irv_min_region(h); c.xcd_mode = h->irv_xcd_mode;
-        static_assert(sizeof(IrvCold) <= 64, "adc_handle::irv_cold / irv_cold_host hold 64 bytes");
-        memcpy(h->irv_cold_host, &c, sizeof(c));
-        const hipError_t e = hipMemcpyAsync(h->irv_cold, h->irv_cold_host, sizeof(IrvCold), hipMemcpyHostToDevice, h->stream);
-        if (e != hipSuccess) return e;
+        static_assert(sizeof(IrvCold) <= 64, "adc_handle::irv_cold and pin_flags[32..47] hold 64 bytes");
+        if (!h->pin_flags) return hipErrorInvalidValue;
+        if (!h->irv_cold_valid || memcmp(h->irv_cold_host, &c, sizeof(c)) != 0) { // (the same block Match after Match unless buffers swapped roles)
+            // two staging slots, alternating: a slot is rewritten two changes later at the earliest -- a handle has one Match in flight,
+            // so the copy that read it has long drained
+            int32_t* slot = h->pin_flags + 32 + 16 * (h->irv_cold_flip & 1);
+            h->irv_cold_flip ^= 1;
+            memcpy(slot, &c, sizeof(c));
+            const hipError_t e = hipMemcpyAsync(h->irv_cold, slot, sizeof(IrvCold), hipMemcpyHostToDevice, h->stream);
+            if (e != hipSuccess) return e;
+            memcpy(h->irv_cold_host, &c, sizeof(c));
+            h->irv_cold_valid = 1;
+        }
     }
     const AdcParams& p = h->p;
     const int tpitch = h->chg_pitch, chg_bytes = tpitch * ((p.H + IRV_TILE - 1) / IRV_TILE);
