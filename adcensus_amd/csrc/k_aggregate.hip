@@ -21,28 +21,6 @@
 #include "k_aggregate_rr.h"
 #include "k_aggregate_rr2.h"
 
-// ------------------------------------------------------------------------------- direct (fallback)
-// One thread per volume element reading its arm span straight from global memory.  Used when the
-// LDS ring does not fit (cross_L1 > 79) and as an A/B cross-check of the marching kernel in tests.
-template <bool VERT, bool DIVIDE>
-__global__ __launch_bounds__(256) void k_agg_direct(const float* __restrict__ src, float* __restrict__ dst,
-                                                    const uchar4* __restrict__ arms, const uint16_t* __restrict__ sup,
-                                                    int W, int H, int Dp)
-{
-    const size_t total = (size_t)W * H * Dp;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t pix = i / Dp;
-        const int d = (int)(i % Dp);
-        const uchar4 a = arms[pix];
-        const int lo = VERT ? a.z : a.x, hi = VERT ? a.w : a.y;
-        const size_t stride = VERT ? (size_t)W * Dp : (size_t)Dp;
-        float acc = 0.0f;
-        for (int t = -lo; t <= hi; t++) acc += src[(size_t)((long long)pix * Dp + (long long)t * (long long)stride) + d];
-        if (DIVIDE) acc = acc / (float)sup[pix];
-        dst[i] = acc;
-    }
-}
-
 // ---------------------------------------------------------------------------------- marching ring
 // One 64-lane workgroup (= one wave) per line segment.
 //   * LDS per wave = (2L+1) x 256 B (17.25 KiB at L = 34) => 9 waves per CU, 2304 chip-wide: all 2160
@@ -726,17 +704,10 @@ static int agg_assumed_depth(const adc_handle* h, bool vert)
 // which: 0 = the host does not know the arms: launch the full-ring and the small-ring variant, the kernel decides;
 //        1 = small ring only, 2 = full ring only (the host has read armmax).  PAIR needs which == 1.
 template <bool VERT, bool DIVIDE, bool COSTIN = false, bool PAIR = false>
-static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool direct, int which = 0)
+static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, int which = 0)
 {
     const AdcParams& p = h->p;
-    const int L = adc_imax(0, adc_imin(p.opt.cross_L1, 255));
-    const size_t lds = (size_t)(2 * L + 1) * 64 * sizeof(float);
-    if (direct || lds > 150 * 1024) {
-        h->agg_kernel = "k_agg_direct (one thread per volume element, no ring)";
-        hipLaunchKernelGGL((k_agg_direct<VERT, DIVIDE>), dim3(256 * 16), dim3(256), 0, h->heavy, src, dst,
-                           reinterpret_cast<const uchar4*>(h->arms), VERT ? h->sup_h : h->sup_v, p.W, p.H, p.Dp);
-        return hipGetLastError();
-    }
+    const int L = adc_imax(0, adc_imin(p.opt.cross_L1, 255)); // (a ring of 2 * 255 + 1 entries of 256 bytes fits the 160 KiB of LDS: every arm limit marches)
     const int N = VERT ? p.H : p.W;
     const int small_L = adc_agg_small_L(h);
     // two disparities per lane with the small ring (ADC_AGG_VPL2=0 switches it off)
@@ -831,7 +802,6 @@ static hipError_t launch_pass(adc_handle* h, const float* src, float* dst, bool 
 struct AggSeq { int launches, passes; float* result; bool first_fused; };
 static hipError_t agg_sequence(adc_handle* h, int iterations, bool dry, bool first_into_cur, bool marks, AggSeq* out)
 {
-    static const bool direct = env_int("ADC_AGG_DIRECT", 0) != 0;
     static const bool pair_env = env_int("ADC_AGG_PAIR", 1) != 0;
     // pairs with the full ring: 0 (default) = never, 1 = when both rings fit into registers (k_agg_regring_pair), 2 = also
     // as two 17 KiB LDS rings per wave.  Measured on MI355X (structured 1080p pair, rocprofv3): a register-ring pair
@@ -845,7 +815,7 @@ static hipError_t agg_sequence(adc_handle* h, int iterations, bool dry, bool fir
     const int Lfull = adc_imax(0, adc_imin(h->p.opt.cross_L1, 255));
     const bool regring_fits = regring_on && Lfull >= 1 && 2 * Lfull + 1 <= AGG_RING_REGS;
     const bool lds_fits = (size_t)(2 * Lfull + 1) * 64 * sizeof(float) + (768 + 64) * sizeof(float) <= 150 * 1024;
-    const bool marching = !direct && (size_t)(2 * Lfull + 1) * 64 * sizeof(float) <= 150 * 1024;
+    const bool marching = true; // (every arm limit fits an LDS ring; round 6 dropped the one-thread-per-element fallback no geometry selected)
     const bool prof = marks && !dry && h->profiling;
     // armmax_host (valid when the pipeline / caller read the maximum arms back): pick the ring on the host
     const int small_L = adc_agg_small_L(h);
@@ -874,14 +844,14 @@ static hipError_t agg_sequence(adc_handle* h, int iterations, bool dry, bool fir
             bool swap = true;
             if (hf) {
                 // first pass of the pipeline: the matching cost is computed inside the pass (no input volume)
-                const bool fused = k == 0 && h->fuse_cost && !direct && lds_fits;
+                const bool fused = k == 0 && h->fuse_cost && lds_fits;
                 if (k == 0) first_fused = fused;
                 if (fused) {
                     swap = !first_into_cur;
-                    if (!dry) e = launch_pass<false, false, true>(h, cur, swap ? oth : cur, direct, which_h);
-                } else if (!dry) e = launch_pass<false, false>(h, cur, oth, direct, which_h);
+                    if (!dry) e = launch_pass<false, false, true>(h, cur, swap ? oth : cur, which_h);
+                } else if (!dry) e = launch_pass<false, false>(h, cur, oth, which_h);
             } else if (!dry) {
-                e = launch_pass<true, false>(h, cur, oth, direct, which_v);
+                e = launch_pass<true, false>(h, cur, oth, which_v);
             }
             if (swap) { float* t = cur; cur = oth; oth = t; }
             launch++;
@@ -903,11 +873,11 @@ static hipError_t agg_sequence(adc_handle* h, int iterations, bool dry, bool fir
                           (wsec == 1 || (wsec == 2 && (pair_full >= 2 || (pair_full == 1 && regring_fits))));
         if (!dry) {
             if (hf) {
-                if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, direct, wsec);
-                else e = launch_pass<true, true>(h, cur, oth, direct, which_v); // / sup_h
+                if (pair) e = launch_pass<true, true, false, true>(h, cur, oth, wsec);
+                else e = launch_pass<true, true>(h, cur, oth, which_v); // / sup_h
             } else {
-                if (pair) e = launch_pass<false, true, false, true>(h, cur, oth, direct, wsec);
-                else e = launch_pass<false, true>(h, cur, oth, direct, which_h); // / sup_v
+                if (pair) e = launch_pass<false, true, false, true>(h, cur, oth, wsec);
+                else e = launch_pass<false, true>(h, cur, oth, which_h); // / sup_v
             }
         }
         { float* t = cur; cur = oth; oth = t; }
@@ -1004,7 +974,7 @@ hipError_t adc_launch_aggregate_tail(adc_handle* h)
 {
     const int keep = h->armmax_valid;
     h->armmax_valid = 0;
-    const hipError_t e = launch_pass<false, true>(h, h->vol_a, h->vol_b, false, 2);
+    const hipError_t e = launch_pass<false, true>(h, h->vol_a, h->vol_b, 2);
     h->armmax_valid = keep;
     if (e == hipSuccess) { float* t = h->vol_a; h->vol_a = h->vol_b; h->vol_b = t; }
     return e;

@@ -130,48 +130,7 @@ __global__ __launch_bounds__(256) void k_interp_list(const uint8_t* __restrict__
 }
 
 // --------------------------------------------------------------------------- K9 proper interpolation
-__global__ __launch_bounds__(256) void k_interpolate(const float* __restrict__ din, float* __restrict__ dout,
-                                                     const uint8_t* __restrict__ label, const uint8_t* __restrict__ img_l,
-                                                     const double* __restrict__ sincos, int W, int H, int which,
-                                                     int max_search)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const size_t p = (size_t)y * W + x;
-    const float d0 = din[p];
-    if (!(label[p] == which && d0 == ADC_INVALID_FLOAT)) {
-        dout[p] = d0;
-        return;
-    }
-    const uint8_t* c0 = img_l + p * 3;
-    const bool mismatch = which == ADC_LABEL_MISMATCH;
-    int min_dist = 9999;
-    float best = mismatch ? 0.0f : ADC_LARGE_FLOAT;
-    bool any = false;
-    for (int s = 0; s < 16; s++) {
-        const double sina = sincos[2 * s], cosa = sincos[2 * s + 1];
-        for (int m = 1; m < max_search; m++) {
-            const int yy = (int)lround((double)y + (double)m * sina); // multistep_refiner.cpp:259-260
-            const int xx = (int)lround((double)x + (double)m * cosa);
-            if (yy < 0 || yy >= H || xx < 0 || xx >= W) break;
-            const float d = din[(size_t)yy * W + xx];
-            if (d != ADC_INVALID_FLOAT) {
-                any = true;
-                if (mismatch) { // colour-nearest, first minimum (multistep_refiner.cpp:276-289)
-                    const int dist = adc_color_dist_l1(c0, img_l + ((size_t)yy * W + xx) * 3);
-                    if (min_dist > dist) { min_dist = dist; best = d; }
-                } else { // smallest disparity (multistep_refiner.cpp:290-296)
-                    best = d < best ? d : best;
-                }
-                break;
-            }
-        }
-    }
-    dout[p] = any ? best : 0.0f; // no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
-}
-
-// Ray-parallel variant: the target pixels of the list are compacted first (k_interp_list), then 16 lanes
+// The target pixels of the list are compacted first (k_interp_list), then 16 lanes
 // work on one pixel, one ray each (4 pixels per wave); the 16 first-hits are combined with a 16-lane
 // butterfly: mismatch -> lexicographic min of (L1 colour distance, ray index) == "first minimum" of the
 // sequential scan over s; occlusion -> smallest disparity.
