@@ -347,13 +347,11 @@ hipError_t adc_launch_interpolation(adc_handle* h)
 {
     const AdcParams& p = h->p;
     const int P = p.W * p.H;
-    dim3 grid((p.W + 63) / 64, (p.H + 3) / 4, 1), block(256, 1, 1);
     const int dmaxa = p.dmax < 0 ? -p.dmax : p.dmax, dmina = p.dmin < 0 ? -p.dmin : p.dmin;
     const int max_search = dmaxa > dmina ? dmaxa : dmina; // multistep_refiner.cpp:236
-    static const bool rays = [] { const char* e = getenv("ADC_INTERP_RAYS"); return e ? atoi(e) != 0 : true; }();
     for (int k = 0; k < 2; k++) {
         const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
-        if (rays) {
+        {
             // The reference computes the fill values of a whole list from the UNCHANGED map and writes them back afterwards
             // (fill_disps, multistep_refiner.cpp:246-303): same structure here -- fill[e] per list entry (disp_tmp serves
             // as the array), then a scatter into the map in place.  No copy of the map, no buffer swap.
@@ -385,14 +383,7 @@ hipError_t adc_launch_interpolation(adc_handle* h)
                 hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_l,
                                    h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
             hipLaunchKernelGGL(k_interp_scatter, dim3(1024), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_tmp, h->disp_l);
-            continue;
-        } else {
-            hipLaunchKernelGGL(k_interpolate, grid, block, 0, h->stream, h->disp_l, h->disp_tmp, h->label, h->img_l, h->ray_sincos,
-                               p.W, p.H, which, max_search);
         }
-        float* t = h->disp_l;
-        h->disp_l = h->disp_tmp;
-        h->disp_tmp = t;
     }
     return hipGetLastError();
 }

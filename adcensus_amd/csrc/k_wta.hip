@@ -24,7 +24,9 @@ __device__ __forceinline__ void wave_argmin(float& c, int& d)
 
 #define WTA_PPW_MAX 8 // pixels per wave: their loads are all issued before the first reduction
 
-template <int VPL, bool RIGHT>
+// (left view only since round 6: the per-pixel gather form of the right view -- 128 cache lines per pixel -- was kept behind a switch
+// no geometry selected; the right view runs k_wta_right_march or k_wta_right_band)
+template <int VPL>
 __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, float* __restrict__ disp, int W, int H, int dmin,
                                              int D)
 {
@@ -40,19 +42,10 @@ __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, floa
 #pragma unroll
     for (int i = 0; i < WTA_PPW; i++) {
         const long long pix = pix0 + i < P ? pix0 + i : P - 1; // clamped: loads stay unconditional
-        const int y = (int)(pix / W), x = (int)(pix - (long long)y * W);
 #pragma unroll
         for (int k = 0; k < VPL; k++) {
             const int di = lane * VPL + k;
-            float v = ADC_LARGE_FLOAT;
-            if (!RIGHT) {
-                v = vol[(size_t)pix * Dp + di]; // padding lanes (di >= D) are masked below
-            } else {
-                const int col = x + di + dmin; // cost(xr, yr, d) = cost(xr + d, yl, d)
-                const int cc = col < 0 ? 0 : (col >= W ? W - 1 : col);
-                v = vol[((size_t)y * W + cc) * Dp + (di < Dp ? di : 0)];
-                if (col < 0 || col >= W) v = ADC_LARGE_FLOAT; // ADCensusStereo.cpp:281-283
-            }
+            const float v = vol[(size_t)pix * Dp + di]; // padding lanes (di >= D) are masked below
             c[i][k] = di < D ? v : ADC_LARGE_FLOAT;
         }
     }
@@ -70,7 +63,7 @@ __global__ __launch_bounds__(256) void k_wta(const float* __restrict__ vol, floa
         float out;
         const bool edge = (best == dmin) || (best == dmax - 1);
         if (edge) {
-            out = RIGHT ? (float)best : ADC_INVALID_FLOAT;
+            out = ADC_INVALID_FLOAT; // ADCensusStereo.cpp:228-231
         } else if (best - 1 - dmin < 0 || best + 1 - dmin >= D) {
             out = (float)best; // reference indexes out of bounds here (only when best stayed 0 and dmin != 0)
         } else {
@@ -274,7 +267,7 @@ hipError_t adc_launch_wta_left(adc_handle* h)
     const long long P = (long long)p.W * p.H;
     const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : (p.VPL == 16 ? 2 : 1)); // == k_wta's WTA_PPW
     const unsigned blocks = (unsigned)((P + 4 * wta_ppw - 1) / (4 * wta_ppw));
-#define LAUNCHL(V) hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D)
+#define LAUNCHL(V) hipLaunchKernelGGL((k_wta<V>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D)
     if (p.VPL == 1) LAUNCHL(1);
     else if (p.VPL == 2) LAUNCHL(2);
     else if (p.VPL == 4) LAUNCHL(4);
@@ -291,7 +284,6 @@ hipError_t adc_launch_wta(adc_handle* h)
     const long long P = (long long)p.W * p.H;
     const int wta_ppw = p.VPL <= 4 ? WTA_PPW_MAX : (p.VPL == 8 ? 4 : (p.VPL == 16 ? 2 : 1)); // == k_wta's WTA_PPW
     const unsigned blocks = (unsigned)((P + 4 * wta_ppw - 1) / (4 * wta_ppw));
-    static const bool band = [] { const char* e = getenv("ADC_WTA_BAND"); return e ? atoi(e) != 0 : true; }();
     // marching form of the right view (D <= 128): ADC_WTA_MARCH=0 selects the band kernel, ADC_WTA_NCU overrides the number of
     // workgroups the plan assumes to run at a time, ADC_WTA_NSEG the segments per row of the remainder rows (tests: segments on
     // small images)
@@ -300,7 +292,7 @@ hipError_t adc_launch_wta(adc_handle* h)
     static const int nseg_env = [] { const char* e = getenv("ADC_WTA_NSEG"); return e ? atoi(e) : 0; }();
     const bool left = !h->wta_left_done; // the last scanline pass of the pipeline already produced the left view
     h->wta_left_done = 0;
-    if (march_on && band && p.VPL <= 2) {
+    if (march_on && p.VPL <= 2) {
         static std::mutex attr_mu; // (per-DEVICE function attribute and CU count: see adc_launch_aggregate)
         static bool attr_set[64] = {false};
         static int ncu_dev[64];
@@ -323,8 +315,8 @@ hipError_t adc_launch_wta(adc_handle* h)
         if (left) {
             const int wl = p.VPL <= 4 ? WTA_PPW_MAX : 1;
             const unsigned bl = (unsigned)((P + 4 * wl - 1) / (4 * wl));
-            if (p.VPL == 1) hipLaunchKernelGGL((k_wta<1, false>), dim3(bl), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D);
-            else hipLaunchKernelGGL((k_wta<2, false>), dim3(bl), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D);
+            if (p.VPL == 1) hipLaunchKernelGGL((k_wta<1>), dim3(bl), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D);
+            else hipLaunchKernelGGL((k_wta<2>), dim3(bl), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D);
         }
         if (p.VPL == 1)
             hipLaunchKernelGGL((k_wta_right_march<1>), dim3((unsigned)pl.units), dim3(64 * WTAM_WAVES), lds, h->heavy, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D,
@@ -336,12 +328,9 @@ hipError_t adc_launch_wta(adc_handle* h)
     }
 #define LAUNCH(V)                                                                                                       \
     do {                                                                                                                \
-        if (left) hipLaunchKernelGGL((k_wta<V, false>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \
-        if (band)                                                                                                       \
-            hipLaunchKernelGGL((k_wta_right_band<8>), dim3((unsigned)((((p.W + 63) / 64) * p.H + 3) / 4)), dim3(256), 0, h->heavy, \
-                               h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D, p.Dp);                                        \
-        else                                                                                                            \
-            hipLaunchKernelGGL((k_wta<V, true>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D); \
+        if (left) hipLaunchKernelGGL((k_wta<V>), dim3(blocks), dim3(256), 0, h->heavy, h->vol_a, h->disp_l, p.W, p.H, p.dmin, p.D); \
+        hipLaunchKernelGGL((k_wta_right_band<8>), dim3((unsigned)((((p.W + 63) / 64) * p.H + 3) / 4)), dim3(256), 0, h->heavy,     \
+                           h->vol_a, h->disp_r, p.W, p.H, p.dmin, p.D, p.Dp);                                            \
     } while (0)
     if (p.VPL == 1) LAUNCH(1);
     else if (p.VPL == 2) LAUNCH(2);

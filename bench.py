@@ -25,7 +25,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  duration from HIP events on the handle's own stream inside the timed region; frac = achieved / 8 TB/s
                  (<= 1 by construction).  algorithmic_achieved / algorithmic_frac = the SURVEY.md 8d numerator (every
                  algorithmic pass counted with 2V + 4P [+ 2P]: exceeds the real traffic when launches fuse passes).
-                 traffic = PMC bytes per launch (profiles/r3_k4_pmc_traffic_<workload>.json; None unless that file was
+                 traffic = PMC bytes per launch (profiles/r<N>_k4_pmc_traffic_<workload>.json, newest round first; None unless that file was
                  measured on exactly these kernel sources -- SHA-256 of k_aggregate*.{hip,h}).  device_copy_GBps = a
                  device-to-device copy of one volume measured after the timed region (the practical ceiling).
   stage_roofline HBM fractions of the scanline stage (4 x (2V + 3P)), the right-view WTA (V) and the whole Match
@@ -798,7 +798,7 @@ def pmc_traffic(workload, whd):
     tags = {(1920, 1080, 128): "", (1242, 375, 128): "_1242x375"}  # (the 1080p files carry no size suffix)
     if whd not in tags:
         return None
-    for rnd in ("r5", "r4", "r3"):  # the newest measurement taken on exactly these kernel sources
+    for rnd in ("r6", "r5", "r4", "r3"):  # the newest measurement taken on exactly these kernel sources
         p = os.path.join(ROOT, "profiles", "%s_k4_pmc_traffic_%s%s.json" % (rnd, workload, tags[whd]))
         try:
             with open(p) as f:

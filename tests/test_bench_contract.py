@@ -37,7 +37,7 @@ def test_committed_bench_lines_follow_the_contract(name):
         assert k in o and isinstance(o[k], t), k
     assert "vs_baseline" in o and o["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
     assert o["unit"] == "pairs/s" and o["higher_is_better"] is True and o["scaling"] in ("weak", "strong") and o["dtype"] == "f32"
-    if not name.startswith(("r3_", "r4_", "r5_")):
+    if not name.startswith(("r3_", "r4_", "r5_", "r6_")):
         assert o["scaling"] == "weak"
     assert "workload" in o["config"] and "model" not in o["config"]
     _check_roofline(o["roofline"])
@@ -46,7 +46,7 @@ def test_committed_bench_lines_follow_the_contract(name):
     if "cpu_baseline" in o:
         c = o["cpu_baseline"]
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("reference", "port") and c["cores"] == 1
-    if name.startswith("r5_"):  # round 5: the batch is pinned to the REFERENCE CPU program's digests
+    if name.startswith(("r5_", "r6_")):  # round 5 on: the batch is pinned to the REFERENCE CPU program's digests
         fc = o["farm_check"]
         assert fc["ok"] is True and fc["reference_mismatches"] == [] and "committed_1gpu_checked" not in fc
         if o["config"]["workload"].startswith(("noise 1920x1080", "structured 1920x1080")):
@@ -58,6 +58,16 @@ def test_committed_bench_lines_follow_the_contract(name):
             assert o["mixed_stream"]["reference_mismatches"] == [] and o["mixed_stream"]["reference_checked"] > 0
         r = o["roofline"]
         assert r["frac"] <= 1.0 and abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    if name.startswith("r6_") and "match_host" in o:  # round 6: the drop-in figure and the natural-image legs are part of the line
+        mh = o["match_host"]
+        wl = o["config"]["workload"].split()[0]
+        other = "structured" if wl == "noise" else "noise"
+        assert mh[wl]["pageable"]["value"] > 0 and mh[wl]["registered"]["value"] > 0 and mh[other]["pageable"]["value"] > 0
+        assert mh[wl]["pageable"]["value"] < o["value"] * 1.05  # the host path cannot beat the resident one
+        assert o[other]["throughput_mode"]["value"] > 0 and o[other]["host_inclusive"]["value"] > 0 and "voting" in o[other]
+        if "cpu_baseline_all_cores" in o:
+            a = o["cpu_baseline_all_cores"]
+            assert a["processes"] == a["cores"] >= 2 and a["value"] > o["cpu_baseline"]["value"]
     if name.startswith(("r3_", "r4_")):  # lines of rounds 3 and 4: frac = REAL HBM bytes / time / peak (<= 1), the SURVEY 8d figure is algorithmic_frac
         r = o["roofline"]
         assert r["frac"] <= 1.0 and r["algorithmic_frac"] >= r["frac"] - 1e-9 and r["passes_per_launch"] >= 1.0
@@ -115,7 +125,7 @@ def test_pmc_traffic_helper():
     assert bench.pmc_traffic("noise", (640, 480, 64)) is None
     assert len(bench.k4_source_hash()) == 16
     for wl in ("noise", "structured"):
-        ps = [os.path.join(ROOT, "profiles", "r%d_k4_pmc_traffic_%s.json" % (rnd, wl)) for rnd in (5, 4, 3)]  # (bench.py's order)
+        ps = [os.path.join(ROOT, "profiles", "r%d_k4_pmc_traffic_%s.json" % (rnd, wl)) for rnd in (6, 5, 4, 3)]  # (bench.py's order)
         t = bench.pmc_traffic(wl, (1920, 1080, 128))
         if any(os.path.exists(p) and json.load(open(p)).get("k4_src_sha16") == bench.k4_source_hash() for p in ps):
             assert t is not None and 2.1e9 < t < 2.4e9, (wl, t)  # ~2.13 GB algorithmic + segment halos
