@@ -31,7 +31,7 @@
 // tools/irv_joint_rounds.py, 960x540 structured pair: 58 rounds instead of 195, 1.2x the evaluations.
 enum { IRV_NONE = 0, IRV_BEGIN, IRV_ROUND, IRV_FINAL_WB, IRV_DONE, IRV_BEGIN2 };
 // ctrl layout (int32): state slot s at ctrl[16*s ..]: {did, -, round, -, n, rounds_total, evals, kdone};
-// accumulator ring at ctrl[IRV_ACC + (k & 63)] (BEGIN2: list length; ROUND: "a state changed")
+// accumulator ring at ctrl[IRV_ACC + (k & 63)] (BEGIN: "a pixel is listed"; BEGIN2: list length; ROUND: "a state changed")
 #define IRV_ACC 64
 #define IRV_CTRL_INTS 160
 struct IrvState { int did, pass, round, filled_any, n, rounds, evals, kdone; }; // kdone: index of the kernel that found the chain finished (pass / filled_any: unused since round 5)
@@ -52,7 +52,9 @@ ADC_HD IrvPlan irv_plan_from(IrvState s, int prev, int k) // s: the published st
         p.act = IRV_BEGIN;
         s.pass = 0; s.round = 0; s.filled_any = 0; s.n = 0;
     } else if (s.did == IRV_BEGIN) {
-        p.act = IRV_BEGIN2;
+        // (round 6) BEGIN raises its accumulator when a pixel goes on the work list; with an EMPTY list -- a noise-like image: every
+        // invalid pixel's region is too small to ever pass a vote -- the chain is done: no list to build, no round, nothing to write back
+        p.act = prev != 0 ? IRV_BEGIN2 : IRV_DONE;
     } else if (s.did == IRV_BEGIN2) {
         p.act = IRV_ROUND;
         s.n = prev; // list length

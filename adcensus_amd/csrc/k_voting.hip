@@ -329,6 +329,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8), amd
             if (pl.act == IRV_BEGIN) { // (the 64 pixels of a wave are consecutive and start at a multiple of 64)
                 const unsigned long long m = __ballot(li);
                 if (lane == 0 && c0 + wave * 64 < P) listed_bits[(c0 + wave * 64) >> 6] = m;
+                if (lane == 0 && m != 0ull) *acc = 1; // (every wave stores the same value: no atomic; irv_plan_from ends the chain on 0)
             }
         }
         return;

@@ -67,6 +67,7 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                     const uint32_t lab = label[p];
                     const bool e = (lab == ADC_LABEL_MISMATCH || lab == ADC_LABEL_OCCLUSION) && dv == ADC_INVALID_FLOAT;
                     listed_bit[p] = e && (int)sup_h[p] > min_region;
+                    if (listed_bit[p]) *acc = 1; // (an empty work list ends the chain: irv_plan_from)
                     uint32_t bin = IRV_BIN_MASK;
                     if (dv != ADC_INVALID_FLOAT) { const long b = lroundf(dv) - dmin; if (b >= 0 && b < D) bin = (uint32_t)b; }
                     st[i16] = (uint16_t)(bin | (e ? lab << IRV_LIST_SHIFT : 0u));
