@@ -895,7 +895,7 @@ static bool so_use_dpp()
 }
 
 // Number of verified segments a row pass of this handle is cut into (1 = whole rows).  Automatic choice: enough chains for
-// two waves on every SIMD of the chip (1080 rows -> 2 x 1080, 375 rows -> 5 x 375); ADC_SO_SEG = 0 / 1 switches the segments
+// two to three waves on every SIMD of the chip (1080 rows -> 3 x 1080, 375 rows -> 5 x 375); ADC_SO_SEG = 0 / 1 switches the segments
 // off, N >= 2 forces N; ADC_SO_WARM = warm-up steps (multiple of 16; the tests use short ones to provoke seam failures).
 int adc_so_segments(const adc_handle* h, int* warm_out)
 {
@@ -905,6 +905,9 @@ int adc_so_segments(const adc_handle* h, int* warm_out)
     if (warm_out) *warm_out = warm_env;
     if (p.VPL > 2 || h->so_seg_off || !h->so_seam || seg_env == 0 || seg_env == 1) return 1;
     int n = seg_env >= 2 ? seg_env : (2048 + p.H / 2) / p.H;
+    // (round 6, same box, interleaved -- profiles/r6_ab_scanline_segments.txt: at 1080 rows three segments per row instead of two, 3240
+    // chains for 1024 SIMDs: scanline stage of the noise pair 1.990 / 1.981 -> 1.937 ms, structured 1.888 / 1.879 -> 1.873; four: 1.965)
+    if (seg_env < 2 && n == 2 && 3 * p.H <= 4096) n = 3;
     if (n > ADC_SO_MAX_SEG) n = ADC_SO_MAX_SEG;
     while (n >= 2 && !adc_so_seg_ok(p.W, n, warm_env)) n--;
     return n >= 2 ? n : 1;
