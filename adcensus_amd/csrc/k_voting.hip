@@ -298,6 +298,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8), amd
         }
         // one coalesced pass over the image: state map / working copy (BEGIN), fills (FINAL)
         const int P = W * H;
+        bool any_listed = false; // (wave-uniform)
         for (int c0 = blockIdx.x * T; c0 < P; c0 += gridDim.x * T) {
             const int p = c0 + threadIdx.x;
             bool li = false;
@@ -329,9 +330,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8), amd
             if (pl.act == IRV_BEGIN) { // (the 64 pixels of a wave are consecutive and start at a multiple of 64)
                 const unsigned long long m = __ballot(li);
                 if (lane == 0 && c0 + wave * 64 < P) listed_bits[(c0 + wave * 64) >> 6] = m;
-                if (lane == 0 && m != 0ull) *acc = 1; // (every wave stores the same value: no atomic; irv_plan_from ends the chain on 0)
+                any_listed |= m != 0ull;
             }
         }
+        // an empty work list ends the chain (irv_plan_from): ONE store per wave that found a listed pixel (the same value: no atomic)
+        if (pl.act == IRV_BEGIN && lane == 0 && any_listed) *acc = 1;
         return;
     }
     if (pl.act == IRV_BEGIN2) {
@@ -424,9 +427,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8), amd
                                 adc_imax(0, y - top) / IRV_TILE, adc_imin(H - 1, y + bot) / IRV_TILE, want4);
         }
         bool dirty = i < ng && (round == 0 || box);
-        if (use_slack && round != 0) { // (uniform) slack budgets, irv_plan.h: an entry whose tiles were hit counts, one entry per lane, the pixels
+        if (use_slack > 0 && round != 0 && __popcll(__ballot(dirty)) >= use_slack) { // (wave-uniform) slack budgets, irv_plan.h: an entry whose tiles were hit counts, one entry per lane, the pixels
             // of its region's bounding rectangle that changed in the previous kernel.  Budget used up: the entry votes again.  Otherwise it
             // is not looked at in this round (pool items are what a heavy round's time is made of) and the count comes off its budget.
+            // A wave with only a few hit entries (the tail rounds) lets them vote without asking: the walk below is a chain of up to 18
+            // dependent trips the whole workgroup then waits for at the pool barrier (tail rounds 12-13 -> 18-19 us, measured); `use_slack`
+            // is that threshold (ADC_IRV_SLACK, default 8; 0 = no budgets at all).
             // (Measured and dropped, profiles/r6_k8_experiments.txt: entries with a small remaining budget kept as "maybes" that count this
             // kernel's changes at their turn in the sweep -- fewer rounds, but every maybe is a pool item and the vote loop ran out of
             // scalar registers; the same at the turn for everything: 48 % fewer votes, no shorter rounds.)
@@ -668,7 +674,7 @@ size_t adc_irv_list_entries(int W, int H, int D, int grid) // (room for either l
 }
 static int irv_use_slack()
 {
-    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK"); return e ? atoi(e) : 8; }(); // hit entries per wave from which the wave filters; 0 = off
     return v;
 }
 size_t adc_irv_px_words(int W, int H) { return (size_t)IRV_PX_PLANES * irv_px_pitch(W) * H + 16; }

@@ -11,7 +11,7 @@
 #include <vector>
 #include "../../adcensus_amd/csrc/irv_plan.h"
 
-// use_slack: the slack budgets of round 6 (irv_plan.h, bottom): per-pixel change planes, a budget per entry (low half of the entry's
+// use_slack (0 = off, else the number of hit entries per wave from which the wave filters; the product's default is 8): the slack budgets of round 6 (irv_plan.h, bottom): per-pixel change planes, a budget per entry (low half of the entry's
 // box word), changed pixels counted over the region -- as in the kernel
 extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                 int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, int use_slack, long* out_stats)
@@ -118,6 +118,22 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                 for (long b0 = 0; b0 < wg_n[g]; b0 += BT) {
                     std::vector<int> todo;
                     std::vector<uint16_t> seen;
+                    // phase 1 is done wave by wave (64 consecutive entries of the batch): a wave filters its hit entries against their slack
+                    // budgets only when at least `use_slack` of them were hit (k_voting.hip: the tail rounds skip the walk)
+                    std::vector<uint8_t> hit;
+                    for (long i = b0; i < std::min((long)wg_n[g], b0 + BT); i++) {
+                        const Ent& e = list[(size_t)g * cap + i];
+                        const int p = e.p, y = e.y, x = p - y * W;
+                        bool dirty = round == 0;
+                        if (!dirty) {
+                            const int top = (e.arms >> 16) & 255, bot = (e.arms >> 24) & 255, ml = (e.box >> 16) & 255, mr = (e.box >> 24) & 255;
+                            const int tx0 = std::max(0, x - ml) / T, tx1 = std::min(W - 1, x + mr) / T;
+                            const int ty0 = std::max(0, y - top) / T, ty1 = std::min(H - 1, y + bot) / T;
+                            for (int ty = ty0; ty <= ty1; ty++)
+                                for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want;
+                        }
+                        hit.push_back(dirty);
+                    }
                     for (long i = b0; i < std::min((long)wg_n[g], b0 + BT); i++) {
                         Ent& e = list[(size_t)g * cap + i];
                         const int p = e.p, y = e.y, x = p - y * W;
@@ -129,7 +145,12 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
                             for (int ty = ty0; ty <= ty1; ty++)
                                 for (int tx = tx0; tx <= tx1; tx++) dirty |= chg_rd[ty * tiles_x + tx] == want; // byte stamps (k_voting.hip)
                         }
-                        if (dirty && use_slack && round != 0) { // phase 1 (k_voting.hip): changed pixels of the region's bounding RECTANGLE in the
+                        int nh = 0;
+                        {
+                            const long w0 = b0 + ((i - b0) / 64) * 64;
+                            for (long j = w0; j < std::min(w0 + 64, std::min((long)wg_n[g], b0 + BT)); j++) nh += hit[j - b0];
+                        }
+                        if (dirty && use_slack > 0 && round != 0 && nh >= use_slack) { // phase 1 (k_voting.hip): changed pixels of the region's bounding RECTANGLE in the
                             // previous kernel's plane (a superset of the region: an upper bound; no arm lookups), without the entry's own pixel,
                             // against the entry's budget
                             const uint8_t* pa = arms + (size_t)p * 4;
@@ -212,7 +233,7 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
 extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats)
 {
-    return emul_irv_chain2(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, 1, out_stats);
+    return emul_irv_chain2(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, 8, out_stats);
 }
 
 // The closed forms of irv_level_slack (irv_plan.h) against the definition: for random (pass, c, m, m2, ts, th) the returned K must

@@ -609,7 +609,7 @@ def test_voting_chain_slack_budgets_random_cases(emul, port_oracle, case):
     L = max(0, min(opt.cross_L1, 255))
     emul.emul_irv_chain2.restype = C.c_long
     evals = {}
-    for slack in (1, 0):
+    for slack in (8, 1, 40, 0):  # hit entries per wave from which the wave filters (product: 8); 0 = no budgets
         for seed, groups, wpb in ((11, 2, 4), (12, 8, 1), (13, 16, 2)):
             d, stats = o["disp_after_lr"].copy(), (C.c_long * 3)()
             r = emul.emul_irv_chain2(P(d), P(o["outlier_label"]), P(o["arms"]), P(o["sup_count_h"]), w, h, dmin, D, opt.irv_ts,
@@ -618,3 +618,4 @@ def test_voting_chain_slack_budgets_random_cases(emul, port_oracle, case):
             assert same(d, o["disp_after_irv"]), (case, slack, seed)
             evals[(slack, seed)] = stats[1]
     assert sum(v for (s, _), v in evals.items() if s == 1) <= sum(v for (s, _), v in evals.items() if s == 0)
+    assert sum(v for (s, _), v in evals.items() if s == 8) <= sum(v for (s, _), v in evals.items() if s == 0)
