@@ -430,9 +430,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8), amd
         if (use_slack > 0 && round != 0 && __popcll(__ballot(dirty)) >= use_slack) { // (wave-uniform) slack budgets, irv_plan.h: an entry whose tiles were hit counts, one entry per lane, the pixels
             // of its region's bounding rectangle that changed in the previous kernel.  Budget used up: the entry votes again.  Otherwise it
             // is not looked at in this round (pool items are what a heavy round's time is made of) and the count comes off its budget.
-            // A wave with only a few hit entries (the tail rounds) lets them vote without asking: the walk below is a chain of up to 18
-            // dependent trips the whole workgroup then waits for at the pool barrier (tail rounds 12-13 -> 18-19 us, measured); `use_slack`
-            // is that threshold (ADC_IRV_SLACK, default 8; 0 = no budgets at all).
+            // `use_slack` = hit entries per wave from which the wave filters (ADC_IRV_SLACK; 0 = no budgets at all).  Default 1: letting
+            // waves with few hits skip the walk below (a chain of up to 18 dependent trips the workgroup waits for at the pool barrier) was
+            // measured -- thresholds 1 and 4 the same, 8 / 16 / 32 slower (refine 3.22 / 3.21 / 3.28 / 3.34 / 3.53 ms).
             // (Measured and dropped, profiles/r6_k8_experiments.txt: entries with a small remaining budget kept as "maybes" that count this
             // kernel's changes at their turn in the sweep -- fewer rounds, but every maybe is a pool item and the vote loop ran out of
             // scalar registers; the same at the turn for everything: 48 % fewer votes, no shorter rounds.)
@@ -674,7 +674,7 @@ size_t adc_irv_list_entries(int W, int H, int D, int grid) // (room for either l
 }
 static int irv_use_slack()
 {
-    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK"); return e ? atoi(e) : 8; }(); // hit entries per wave from which the wave filters; 0 = off
+    static const int v = [] { const char* e = getenv("ADC_IRV_SLACK"); return e ? atoi(e) : 1; }(); // hit entries per wave from which the wave filters (measured: 1 = 4 < 8 < 16 < 32: every wave filters); 0 = off
     return v;
 }
 size_t adc_irv_px_words(int W, int H) { return (size_t)IRV_PX_PLANES * irv_px_pitch(W) * H + 16; }

@@ -11,7 +11,7 @@
 #include <vector>
 #include "../../adcensus_amd/csrc/irv_plan.h"
 
-// use_slack (0 = off, else the number of hit entries per wave from which the wave filters; the product's default is 8): the slack budgets of round 6 (irv_plan.h, bottom): per-pixel change planes, a budget per entry (low half of the entry's
+// use_slack (0 = off, else the number of hit entries per wave from which the wave filters; the product's default is 1): the slack budgets of round 6 (irv_plan.h, bottom): per-pixel change planes, a budget per entry (low half of the entry's
 // box word), changed pixels counted over the region -- as in the kernel
 extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                 int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, int use_slack, long* out_stats)
@@ -233,7 +233,7 @@ extern "C" long emul_irv_chain2(float* disp, const uint8_t* label, const uint8_t
 extern "C" long emul_irv_chain(float* disp, const uint8_t* label, const uint8_t* arms, const uint16_t* sup_h, int W, int H, int dmin,
                                int D, int irv_ts, float irv_th, int min_region, unsigned seed, int groups, int wpb, long* out_stats)
 {
-    return emul_irv_chain2(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, 8, out_stats);
+    return emul_irv_chain2(disp, label, arms, sup_h, W, H, dmin, D, irv_ts, irv_th, min_region, seed, groups, wpb, 1, out_stats);
 }
 
 // The closed forms of irv_level_slack (irv_plan.h) against the definition: for random (pass, c, m, m2, ts, th) the returned K must
