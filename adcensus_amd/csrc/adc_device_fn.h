@@ -208,6 +208,25 @@ ADC_HD int adc_itp_coldist(const uint8_t* rowd, int cw, int ch, int cx, int cy)
     return best;
 }
 
+// The ray walk's CODE MAP (round 6): one byte per pixel of the image padded by the search range `ms` on the left, on the right and
+// below (the rays point into the half plane dy >= 0: angles 0 .. 168.75 degrees, multistep_refiner.cpp:252-257; |dx|, dy < ms), so
+// that a ray position is ONE add away from the target's padded index and needs no bounds test:
+//   ADC_ITP_VALID    the pixel holds a valid disparity: the ray ends with a hit
+//   ADC_ITP_OUTSIDE  outside the image: the ray ends without one (multistep_refiner.cpp:261-263)
+//   0 .. 253         invalid pixel inside the image: adc_itp_skip(cell distance) = the steps that may be skipped behind it
+// Linear ray offsets lin[m][s] = dy * pitch + dx for 1 <= m < ms, 0 for row 0 and the ADC_ITP_LPAD rows behind the range (a trip of
+// ADC_ITP_NS steps that starts below ms, plus the largest skip, stays inside the table).
+#define ADC_ITP_VALID 255
+#define ADC_ITP_OUTSIDE 254
+#ifndef ADC_ITP_NS
+#define ADC_ITP_NS 8
+#endif
+#define ADC_ITP_LPAD 64
+ADC_HD int adc_itp_code_pitch(int W, int ms) { return (W + 2 * ms + 8 + 3) & ~3; } // (+8: k_itp_code stores whole dwords around the image's columns)
+ADC_HD int adc_itp_code_rows(int H, int ms) { return H + ms; }
+static_assert((ADC_ITP_CAP + 1 - 1) * ADC_ITP_CELL - 1 < ADC_ITP_OUTSIDE && ADC_ITP_NS + (ADC_ITP_CAP * ADC_ITP_CELL - 1) + ADC_ITP_NS <= ADC_ITP_LPAD,
+              "skip codes stay below the end codes; the table padding covers a trip behind the largest skip");
+
 // ---- WTA sub-pixel (ADCensusStereo.cpp:227-240) ----
 ADC_HD float adc_subpixel(int best, float c1, float c2, float cmin)
 {

@@ -100,6 +100,8 @@ struct adc_handle {
     int32_t* interp_counters; // the interpolation has run once, and must find its list and control block untouched)
     int32_t* ray_tab;     // [max_search][16] packed ray offsets (dy<<16 | dx&0xffff), NULL when a step is too close to a .5 tie
     int ray_tab_rows;
+    int32_t* ray_lin;     // [max_search + ADC_ITP_LPAD][16] linear ray offsets dy * itp_pitch + dx into the padded code map (same allocation as ray_tab)
+    int itp_pitch, itp_ms; // row pitch of the code map and the search range it is padded for (adc_device_fn.h)
     uint32_t* cost_rrec;  // [H][rrec_pitch] uint4 {bgrx, census lo, census hi, 0} of the RIGHT image, padded with out-of-image
                           // markers (bgrx = ~0) on both sides; cost_lrec [H][W] the same for the LEFT image (fused cost, k_aggregate.hip)
     uint32_t* cost_lrec;
@@ -161,7 +163,8 @@ struct adc_handle {
     int chg_pitch;
     uint8_t* edge;       // discontinuity adjustment edge mask
     uint8_t* itp_cells;  // interpolation: 3 byte maps of 2x2-pixel cells (cell has a valid pixel / row distance / Chebyshev distance
-                         // in cells to the nearest cell with a valid pixel): empty-space skipping of the ray walk (k_refine.hip)
+                         // in cells to the nearest cell with a valid pixel): empty-space skipping of the ray walk (k_refine.hip);
+                         // behind them the padded code map of the walk (adc_device_fn.h: ADC_ITP_VALID ...)
     // pinned staging for adc_match / adc_match_async
     uint8_t* pin_in;  // 2 * 3*W*H
     float* pin_out;   // W*H
@@ -213,7 +216,7 @@ hipError_t adc_launch_wta_left(adc_handle* h);                  // vol_a -> disp
 hipError_t adc_paper_aggregate(adc_handle* h, int iterations);  // k_paper.hip: aggregation limited by both images' arms
 hipError_t adc_paper_accumulate(adc_handle* h, float* acc, const float* src, int first, int last);
 hipError_t adc_launch_lrcheck(adc_handle* h);
-size_t adc_itp_cell_bytes(int W, int H);       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
+size_t adc_itp_cell_bytes(int W, int H, int ms);       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
 int adc_irv_probe_xcd_mode(int device);         // 1 iff workgroup g of a launch runs on XCD g % 8 on this device (probed once)
 int adc_irv_grid(size_t pixels);                // workgroups of the voting chain for an image of this size
 size_t adc_irv_waves(int grid);                // ints of the chain's statistics block (per-wave counters + per-workgroup segment lengths)

@@ -166,7 +166,14 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMemset(h->vote_evals_arr, 0, adc_irv_waves(h->irv_grid) * sizeof(int32_t)));
     HIP_OK(hipMalloc(&h->interp_list, P * 4));
     HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));
-    HIP_OK(hipMalloc(&h->itp_cells, adc_itp_cell_bytes(p.W, p.H)));
+    {
+        const int da = p.dmax < 0 ? -p.dmax : p.dmax, di = p.dmin < 0 ? -p.dmin : p.dmin;
+        h->itp_ms = da > di ? da : di; // multistep_refiner.cpp:236
+        h->itp_pitch = adc_itp_code_pitch(p.W, h->itp_ms);
+        HIP_OK(hipMalloc(&h->itp_cells, adc_itp_cell_bytes(p.W, p.H, h->itp_ms)));
+        // (everything outside the image never changes: the per-Match kernel only rewrites the image's own columns and rows)
+        HIP_OK(hipMemset(h->itp_cells, ADC_ITP_OUTSIDE, adc_itp_cell_bytes(p.W, p.H, h->itp_ms)));
+    }
     h->st16_pitch = (p.W + 7) & ~7;
     HIP_OK(hipMalloc(&h->st16, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // (an uncached allocation -- visible across XCDs inside a kernel -- measured equal)
     HIP_OK(hipMemset(h->st16, 0xFF, ((size_t)h->st16_pitch * p.H + 64) * sizeof(uint16_t))); // padding columns: invalid bin
@@ -226,9 +233,12 @@ static hipError_t upload_tables(adc_handle* h)
         const int da = o.max_disparity < 0 ? -o.max_disparity : o.max_disparity, di = o.min_disparity < 0 ? -o.min_disparity : o.min_disparity;
         const int ms = da > di ? da : di; // multistep_refiner.cpp:236
         h->ray_tab = nullptr;
+        h->ray_lin = nullptr;
         h->ray_tab_rows = 0;
         if (ms >= 1 && ms <= 30000 && h->p.W < (1 << 20) && h->p.H < (1 << 20)) {
-            std::vector<int32_t> tab((size_t)ms * 16, 0);
+            // packed offsets [ms][16], then the linear offsets into the padded code map [ms + ADC_ITP_LPAD][16] (adc_device_fn.h)
+            std::vector<int32_t> tab((size_t)ms * 16 + (size_t)(ms + ADC_ITP_LPAD) * 16, 0);
+            int32_t* lin = tab.data() + (size_t)ms * 16;
             bool safe = true;
             for (int m = 1; m < ms && safe; m++)
                 for (int s = 0; s < 16; s++) {
@@ -237,11 +247,14 @@ static hipError_t upload_tables(adc_handle* h)
                     if (ry < 1e-9 || rx < 1e-9) { safe = false; break; }
                     const long dy = lround(fy), dx = lround(fx);
                     tab[(size_t)m * 16 + s] = (int32_t)(((uint32_t)(dy & 0xffff) << 16) | (uint32_t)(dx & 0xffff));
+                    lin[(size_t)m * 16 + s] = (int32_t)(dy * h->itp_pitch + dx);
+                    if (dy < 0 || dy >= ms || dx <= -ms || dx >= ms) safe = false; // (the padding of the code map assumes it; always true)
                 }
             if (safe) {
                 HIP_OK(hipMalloc(&h->ray_tab, tab.size() * sizeof(int32_t)));
                 HIP_OK(hipMemcpy(h->ray_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
                 h->ray_tab_rows = ms;
+                h->ray_lin = h->ray_tab + (size_t)ms * 16;
             }
         }
     }

@@ -222,7 +222,9 @@ __device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_di
 // -- a step moves at most one pixel per axis (+1 for the rounding) -- so they are skipped.  Exact: only pixels proven
 // invalid (or outside the image, where the ray ends anyway) are passed over.
 #define ITP_CELL ADC_ITP_CELL
-size_t adc_itp_cell_bytes(int W, int H) { return 3 * (size_t)((W + ITP_CELL - 1) / ITP_CELL) * ((H + ITP_CELL - 1) / ITP_CELL) + 64; } // cell / row / distance maps
+// cell / row / distance maps (one byte per cell each), then -- 16-byte aligned -- the padded code map of the walk
+static size_t itp_code_offset(int W, int H) { return (3 * (size_t)((W + ITP_CELL - 1) / ITP_CELL) * ((H + ITP_CELL - 1) / ITP_CELL) + 15) & ~(size_t)15; }
+size_t adc_itp_cell_bytes(int W, int H, int ms) { return itp_code_offset(W, H) + (size_t)adc_itp_code_pitch(W, ms) * adc_itp_code_rows(H, ms) + 64; }
 __global__ __launch_bounds__(256) void k_itp_cells(const float* __restrict__ disp, uint8_t* __restrict__ cell, int W, int H, int cw, int ch)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -250,13 +252,82 @@ __global__ __launch_bounds__(256) void k_itp_coldist(const uint8_t* __restrict__
     if (c >= cw * ch) return;
     cdist[c] = (uint8_t)adc_itp_coldist(rowd, cw, ch, c % cw, c / cw);
 }
+// The code map of the walk (adc_device_fn.h): four pixels of an image row per thread, one 32-bit store; the padding around the image
+// (ADC_ITP_OUTSIDE) is written once, when the object is created.  `code` points at the map's row 0, `gx` = columns of padding on the left.
+__global__ __launch_bounds__(256) void k_itp_code(const float* __restrict__ disp, const uint8_t* __restrict__ cdist, uint8_t* __restrict__ code,
+                                                  int W, int H, int cw, int pitch, int gx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int q4 = (W + 3) >> 2; // threads per row; thread (y, k) covers the padded columns (gx & ~3) + 4k .. + 3
+    if (i >= q4 * H + H) return;
+    const int y = i / (q4 + 1), k = i - y * (q4 + 1);
+    const int c0 = (gx & ~3) + 4 * k;
+    uint32_t v = 0u;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int x = c0 + b - gx;
+        uint32_t c = ADC_ITP_OUTSIDE;
+        if (x >= 0 && x < W) c = disp[(size_t)y * W + x] != ADC_INVALID_FLOAT ? (uint32_t)ADC_ITP_VALID : (uint32_t)adc_itp_skip(cdist[(y / ITP_CELL) * cw + (x / ITP_CELL)]);
+        v |= c << (8 * b);
+    }
+    *reinterpret_cast<uint32_t*>(code + (size_t)y * pitch + c0) = v; // (pitch and c0 are multiples of 4; c0 + 3 <= gx + W + 6 < pitch: adc_itp_code_pitch)
+}
 
-template <int NS>
+// Round 6: the walk on the CODE MAP (adc_device_fn.h).  SQ counters of the round-5 kernel said 11 400 vector-ALU instructions per wave
+// against 1 000 vector loads: with 8 waves per SIMD that is 0.17 of its 0.28 ms in instruction issue alone -- table row, two sign
+// extensions, four bounds tests, a multiply-add, 64-bit addresses and the hit bookkeeping per step, ~25 instructions.  Now a step is
+// one LDS read of the linear offset (immediate offsets from one address per trip), one add, one byte gather from the padded map (no
+// bounds tests: outside the image the map says so; no separate cell-distance gather: the code of an invalid pixel IS its skip) and the
+// end test; the value and the colour of the hit are fetched once behind the walk.  (A first attempt of this round replaced the map
+// gathers by bit tests on 8x8 validity tiles -- fewer gathers, MORE instructions: 0.28 -> 0.44 ms, profiles/r6_ab_k9_code_map.txt.)
+// One trip of N steps of a ray: m = its next step, hm = the step of its hit (0: none so far).  Rays that have ended take no part in the
+// gathers (execution mask): the address unit's time goes with the lanes it serves -- measured, 0.235 -> 0.14 ms per list on the noise pair.
+template <int N>
+__device__ __forceinline__ void itp_trip(const int32_t* __restrict__ lt, const uint8_t* __restrict__ code, uint32_t pb, int s, int max_search,
+                                         bool& walking, int& m, int& hm)
+{
+    const bool w0 = walking && m < max_search;
+    uint32_t c[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) c[j] = ADC_ITP_OUTSIDE;
+    if (w0) {
+        const int32_t* row = lt + (m * 16 + s);
+#pragma unroll
+        for (int j = 0; j < N; j++) c[j] = code[pb + (uint32_t)row[j * 16]];
+    }
+    bool act = w0;
+    const int left = max_search - m; // steps left in the search range (> 0 for a walking ray)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const bool end = c[j] >= ADC_ITP_OUTSIDE || j >= left; // a hit, the image border or the end of the range
+        hm = (act && end && c[j] == ADC_ITP_VALID && j < left) ? m + j : hm;
+        act = act && !end;
+    }
+    walking = act;
+    m += act ? N + (int)c[N - 1] : 0; // (the code of the trip's last position: an invalid pixel inside the image = its skip)
+}
+// Trip lengths (same box, interleaved, refine stage of the noise pair, profiles/r6_ab_k9_code_map.txt): first trip / following trips
+// 2 / 4: 0.727 ms, 4 / 4: 0.732, 3 / 6: 0.732, 3 / 3: 0.742, 4 / 8: 0.747, 2 / 8: 0.751, 6 / 8: 0.760 (round 5's kernel: 0.99) -- at 22 % valid
+// pixels half of the rays end within two steps, and what a longer trip fetches behind the hit is wasted address-unit time.
+#ifndef ITP_NS1
+#define ITP_NS1 2 // steps of a ray's first trip ...
+#endif
+#ifndef ITP_NS2
+#define ITP_NS2 4 // ... and of the following ones (<= ADC_ITP_NS: the table's padding)
+#endif
+static_assert(ITP_NS1 <= ADC_ITP_NS && ITP_NS2 <= ADC_ITP_NS, "trip lengths");
+template <bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
                                                          const float* __restrict__ din, float* __restrict__ dout,
-                                                         const uint32_t* __restrict__ bgr, const int32_t* __restrict__ tab,
-                                                         int W, int H, int which, int max_search, const uint8_t* __restrict__ cdist, int cw)
+                                                         const uint32_t* __restrict__ bgr, const int32_t* __restrict__ tab, const int32_t* __restrict__ lin,
+                                                         int W, int which, int max_search, const uint8_t* __restrict__ code, int pitch, int gx)
 {
+    extern __shared__ int32_t lin_lds[]; // [max_search + ADC_ITP_LPAD][16]
+    if (TAB_LDS) {
+        for (int i = threadIdx.x; i < (max_search + ADC_ITP_LPAD) * 16; i += 256) lin_lds[i] = lin[i];
+        __syncthreads();
+    }
+    const int32_t* __restrict__ lt = TAB_LDS ? lin_lds : lin;
     const int n = counters[0];
     const int lane = threadIdx.x & 63;
     const int s = lane >> 2;                                   // ray index
@@ -270,42 +341,19 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
         const int p = pn;
         pn = e + nslot < n ? list[e + nslot] : 0;
         const int y = p / W, x = p - y * W;
-        float hit = ADC_INVALID_FLOAT; // first valid disparity along this ray
-        int hitq = p;
+        const uint32_t pb = (uint32_t)(y * pitch + x + gx); // the target in the padded map
+        int hm = 0;            // step of the hit (0: none)
         bool walking = live;
-        // the ray's own step counter: next step to evaluate (steps proven empty are skipped, see k_itp_cells)
-        int m = 1;
-        {
-            m += adc_itp_skip(cdist[(y / ITP_CELL) * cw + (x / ITP_CELL)]);
-        }
-        while (__any(walking && m < max_search)) {
-            int q[NS], yy[NS], xx[NS];
-            bool in[NS];
-            float d[NS];
-            const bool w0 = walking && m < max_search;
-#pragma unroll
-            for (int j = 0; j < NS; j++) {
-                const int mj = m + j < max_search ? m + j : max_search - 1; // table has max_search rows (row 0 unused)
-                const int o = tab[mj * 16 + s];
-                yy[j] = y + (o >> 16);
-                xx[j] = x + (int)(short)(o & 0xffff);
-                in[j] = (m + j < max_search) && yy[j] >= 0 && yy[j] < H && xx[j] >= 0 && xx[j] < W;
-                q[j] = (in[j] && w0) ? yy[j] * W + xx[j] : p; // finished rays re-read their own pixel (one line)
-                d[j] = din[q[j]]; // (masking the gathers of finished rays instead was measured: no change)
-            }
-            // (the cell distance at the last position of the trip, requested together with the map values)
-            const int cl = (in[NS - 1] && w0) ? (int)cdist[(yy[NS - 1] / ITP_CELL) * cw + (xx[NS - 1] / ITP_CELL)] : 0;
-            if (!w0) walking = false; // (search range exhausted)
-#pragma unroll
-            for (int j = 0; j < NS; j++) {
-                if (walking) {
-                    if (!in[j]) walking = false; // left the image (or the search range): the ray ends without a hit
-                    else if (d[j] != ADC_INVALID_FLOAT) { hit = d[j]; hitq = q[j]; walking = false; }
-                }
-            }
-            m += NS;
-            m += adc_itp_skip(cl);
-        }
+        // the ray's own step counter: next step to evaluate; the target's own code = the steps proven empty around it (a listed
+        // pixel is invalid and inside the image)
+        int m = 1 + (int)code[pb];
+        itp_trip<ITP_NS1>(lt, code, pb, s, max_search, walking, m, hm);
+        while (__any(walking && m < max_search)) itp_trip<ITP_NS2>(lt, code, pb, s, max_search, walking, m, hm);
+        // the hit: its position from the packed table, its value from the map
+        const int o = tab[hm * 16 + s]; // (row 0: no offset)
+        const int hitq = hm ? (y + (o >> 16)) * W + x + (int)(short)(o & 0xffff) : p;
+        const float hv = din[hitq];
+        const float hit = hm ? hv : ADC_INVALID_FLOAT; // first valid disparity along this ray
         // combine the 16 rays of this pixel (lanes with equal lane&3)
         float best;
         bool any;
@@ -359,24 +407,24 @@ hipError_t adc_launch_interpolation(adc_handle* h)
             if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_interp_list, dim3((P + 256 * ITP_LIST_PPT - 1) / (256 * ITP_LIST_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l,
                                h->interp_list, h->interp_counters, which, P);
-            if (h->ray_tab && max_search == h->ray_tab_rows) {
+            if (h->ray_tab && max_search == h->ray_tab_rows && max_search == h->itp_ms) {
                 if (k == 0 && !h->bgrx_valid) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
-                static const int ns = [] { const char* e = getenv("ADC_INTERP_NS"); return e ? atoi(e) : 4; }(); // ray steps per trip
+                const int cw = (p.W + ITP_CELL - 1) / ITP_CELL, ch = (p.H + ITP_CELL - 1) / ITP_CELL, nc = cw * ch;
+                uint8_t* code = h->itp_cells + itp_code_offset(p.W, p.H);
                 {
-                    const int cw = (p.W + ITP_CELL - 1) / ITP_CELL, ch = (p.H + ITP_CELL - 1) / ITP_CELL, nc = cw * ch;
                     hipLaunchKernelGGL(k_itp_cells, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->disp_l, h->itp_cells, p.W, p.H, cw, ch);
                     hipLaunchKernelGGL(k_itp_rowdist, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->itp_cells, h->itp_cells + nc, cw, ch);
                     hipLaunchKernelGGL(k_itp_coldist, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->itp_cells + nc, h->itp_cells + 2 * nc, cw, ch);
+                    hipLaunchKernelGGL(k_itp_code, dim3((((p.W + 3) / 4 + 1) * p.H + 255) / 256), dim3(256), 0, h->stream, h->disp_l, h->itp_cells + 2 * (size_t)nc,
+                                       code, p.W, p.H, cw, h->itp_pitch, h->itp_ms);
                 }
-#define INTERP_TAB(NS_)                                                                                                \
-    hipLaunchKernelGGL(k_interpolate_tab<NS_>, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters,    \
-                       h->disp_l, h->disp_tmp, h->bgrx_l, h->ray_tab, p.W, p.H, which, max_search,                         \
-                       h->itp_cells + 2 * (size_t)((p.W + ITP_CELL - 1) / ITP_CELL) * ((p.H + ITP_CELL - 1) / ITP_CELL),     \
-                       (p.W + ITP_CELL - 1) / ITP_CELL)
-                if (ns == 8) INTERP_TAB(8);
-                else if (ns == 16) INTERP_TAB(16);
-                else if (ns == 2) INTERP_TAB(2);
-                else INTERP_TAB(4);
+                const size_t lin_bytes = (size_t)(max_search + ADC_ITP_LPAD) * 16 * sizeof(int32_t);
+                const bool tab_lds = lin_bytes <= 40 * 1024; // (ranges up to 576; larger ones read the table from global memory)
+#define INTERP_TAB(L_)                                                                                                 \
+    hipLaunchKernelGGL((k_interpolate_tab<L_>), dim3(2048), dim3(256), L_ ? lin_bytes : 0, h->stream, h->interp_list, h->interp_counters, \
+                       h->disp_l, h->disp_tmp, h->bgrx_l, h->ray_tab, h->ray_lin, p.W, which, max_search, code, h->itp_pitch, h->itp_ms)
+                if (tab_lds) INTERP_TAB(true);
+                else INTERP_TAB(false);
 #undef INTERP_TAB
             }
             else

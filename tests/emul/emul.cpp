@@ -1069,6 +1069,112 @@ long emul_interpolate_skip(const float* din, float* dout, const uint8_t* label, 
     return lookups;
 }
 
+// ------------------------------------------------------------------ k_interpolate_tab on the code map (round 6)
+// The list kernel's walk as k_refine.hip runs it since round 6: ONE byte map of the image padded by the search range on the left, on
+// the right and below (adc_device_fn.h: ADC_ITP_VALID / ADC_ITP_OUTSIDE / skip of the pixel's cell), linear ray offsets, trips of
+// ns1 (first) / ns2 (following) steps without bounds tests, the skip taken from the code of the trip's last position.  The map and the table are built
+// the way k_itp_cells .. k_itp_code and upload_tables (capi.hip) build them.  Must equal emul_interpolate (the plain walk) on any
+// input.  Returns the number of map look-ups (< 0: an internal inconsistency).
+long emul_interpolate_code(const float* din, float* dout, const uint8_t* label, const uint8_t* img_l, int W, int H, int which,
+                           int max_search, int ns1, int ns2)
+{
+    const int ms = max_search;
+    if (ns1 < 1 || ns2 < 1 || ns1 > ADC_ITP_NS || ns2 > ADC_ITP_NS) return -6;
+    double sc[32];
+    const float pi = 3.1415926f;
+    double ang = 0.0;
+    for (int s = 0; s < 16; s++) { sc[2 * s] = sin(ang); sc[2 * s + 1] = cos(ang); ang += pi / 16; }
+    const int cw = (W + ADC_ITP_CELL - 1) / ADC_ITP_CELL, ch = (H + ADC_ITP_CELL - 1) / ADC_ITP_CELL;
+    std::vector<uint8_t> cell((size_t)cw * ch), rowd((size_t)cw * ch), cdist((size_t)cw * ch);
+    for (int cy = 0; cy < ch; cy++)
+        for (int cx = 0; cx < cw; cx++) {
+            bool any = false;
+            for (int r = 0; r < ADC_ITP_CELL; r++)
+                for (int q = 0; q < ADC_ITP_CELL; q++) {
+                    const int y = cy * ADC_ITP_CELL + r, x = cx * ADC_ITP_CELL + q;
+                    if (y < H && x < W) any = any || din[(size_t)y * W + x] != ADC_INVALID_FLOAT;
+                }
+            cell[(size_t)cy * cw + cx] = any ? 1 : 0;
+        }
+    for (int c = 0; c < cw * ch; c++) rowd[c] = (uint8_t)adc_itp_rowdist(cell.data(), cw, c % cw, c / cw);
+    for (int c = 0; c < cw * ch; c++) cdist[c] = (uint8_t)adc_itp_coldist(rowd.data(), cw, ch, c % cw, c / cw);
+    // the code map: everything ADC_ITP_OUTSIDE (adc_create), then one dword per 4 padded columns around the image's own (k_itp_code)
+    const int pitch = adc_itp_code_pitch(W, ms), rows = adc_itp_code_rows(H, ms), gx = ms;
+    std::vector<uint8_t> code((size_t)pitch * rows + 64, (uint8_t)ADC_ITP_OUTSIDE);
+    const int q4 = (W + 3) >> 2;
+    for (int y = 0; y < H; y++)
+        for (int k = 0; k <= q4; k++) {
+            const int c0 = (gx & ~3) + 4 * k;
+            if (c0 + 3 >= pitch) return -4;
+            for (int b = 0; b < 4; b++) {
+                const int x = c0 + b - gx;
+                uint8_t c = ADC_ITP_OUTSIDE;
+                if (x >= 0 && x < W) c = din[(size_t)y * W + x] != ADC_INVALID_FLOAT ? (uint8_t)ADC_ITP_VALID : (uint8_t)adc_itp_skip(cdist[(size_t)(y / ADC_ITP_CELL) * cw + x / ADC_ITP_CELL]);
+                code[(size_t)y * pitch + c0 + b] = c;
+            }
+        }
+    // the tables: packed (dy << 16 | dx & 0xffff) [ms][16], linear [ms + ADC_ITP_LPAD][16]
+    std::vector<int32_t> tab((size_t)ms * 16, 0), lin((size_t)(ms + ADC_ITP_LPAD) * 16, 0);
+    for (int m = 1; m < ms; m++)
+        for (int s = 0; s < 16; s++) {
+            const long dy = lround((double)m * sc[2 * s]), dx = lround((double)m * sc[2 * s + 1]);
+            if (dy < 0 || dy >= ms || dx <= -ms || dx >= ms) return -5;
+            tab[(size_t)m * 16 + s] = (int32_t)(((uint32_t)(dy & 0xffff) << 16) | (uint32_t)(dx & 0xffff));
+            lin[(size_t)m * 16 + s] = (int32_t)(dy * pitch + dx);
+        }
+    long lookups = 0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t p = (size_t)y * W + x;
+            const float d0 = din[p];
+            if (!(label[p] == which && d0 == ADC_INVALID_FLOAT)) { dout[p] = d0; continue; }
+            const uint8_t* c0 = img_l + p * 3;
+            const bool mismatch = which == ADC_LABEL_MISMATCH;
+            int min_dist = 9999;
+            float best = mismatch ? 0.0f : ADC_LARGE_FLOAT;
+            bool any = false;
+            const long pb = (long)y * pitch + x + gx;
+            for (int s = 0; s < 16; s++) {
+                int hm = 0;
+                bool walking = true;
+                int m = 1 + (int)code[pb];
+                for (int trip = 0; walking && m < ms; trip++) {
+                    const int NS = trip == 0 ? ns1 : ns2; // (the kernel: ITP_NS1 steps in a ray's first trip, ITP_NS2 in the following ones)
+                    uint32_t c[ADC_ITP_NS];
+                    for (int j = 0; j < NS; j++) {
+                        const long q = pb + lin[(size_t)(m + j) * 16 + s];
+                        if (q < 0 || q >= (long)pitch * rows) return -1; // (the padding covers every position of the range)
+                        c[j] = code[q];
+                        lookups++;
+                    }
+                    bool act = true;
+                    const int left = ms - m;
+                    for (int j = 0; j < NS; j++) {
+                        const bool end = c[j] >= ADC_ITP_OUTSIDE || j >= left;
+                        if (act && end && c[j] == ADC_ITP_VALID && j < left) hm = m + j;
+                        act = act && !end;
+                    }
+                    walking = act;
+                    m += act ? NS + (int)c[NS - 1] : 0;
+                }
+                if (hm) {
+                    const int o = tab[(size_t)hm * 16 + s];
+                    const int yy = y + (o >> 16), xx = x + (int)(short)(o & 0xffff);
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) return -2; // (a hit lies inside the image)
+                    const float hit = din[(size_t)yy * W + xx];
+                    if (hit == ADC_INVALID_FLOAT) return -3;
+                    any = true;
+                    if (mismatch) {
+                        const int dist = adc_color_dist_l1(c0, img_l + ((size_t)yy * W + xx) * 3);
+                        if (min_dist > dist) { min_dist = dist; best = hit; }
+                    } else best = hit < best ? hit : best;
+                }
+            }
+            dout[p] = any ? best : 0.0f;
+        }
+    return lookups;
+}
+
 // ------------------------------------------------------------------ k_median_wavefront
 void emul_median_wavefront(const float* in, float* out, int W, int H)
 {

@@ -427,6 +427,12 @@ def test_refiner_parallel_forms(emul, dumps, name):
     emul.emul_interpolate_skip(P(a2), P(b2), P(o["outlier_label"]), P(left), w, h, 1, ms, 4, None)
     emul.emul_interpolate_skip(P(b2), P(a2), P(o["outlier_label"]), P(left), w, h, 2, ms, 4, None)
     assert same(a2, o["disp_after_interp"])
+    # ... and the walk on the padded code map (round 6: k_interpolate_tab as it runs now)
+    emul.emul_interpolate_code.restype = C.c_long
+    a3, b3 = o["disp_after_irv"].copy(), np.empty((h, w), np.float32)
+    assert emul.emul_interpolate_code(P(a3), P(b3), P(o["outlier_label"]), P(left), w, h, 1, ms, 2, 4) >= 0
+    assert emul.emul_interpolate_code(P(b3), P(a3), P(o["outlier_label"]), P(left), w, h, 2, ms, 2, 4) >= 0
+    assert same(a3, o["disp_after_interp"])
     m = np.empty((h, w), np.float32)
     emul.emul_median_wavefront(P(o["disp_after_dda"]), P(m), w, h)
     assert same(m, o["disp_final"])
@@ -535,6 +541,31 @@ def test_interpolation_skipping_is_exact(emul, seed, density, ns):
         assert same(got, want)
         if density <= 0.003:
             assert n < 0.6 * plain.value, (n, plain.value)   # the sparse band is crossed in jumps
+
+
+@pytest.mark.parametrize("seed,density,ms,w,h", [(1, 0.003, 96, 157, 83), (2, 0.02, 96, 160, 80), (3, 0.25, 64, 157, 83), (4, 0.003, 2, 8, 8), (5, 0.0005, 200, 131, 97),
+                                                 (6, 0.0, 96, 64, 33), (7, 0.22, 128, 203, 61), (8, 0.22, 30, 7, 150), (9, 0.22, 5, 150, 7), (10, 0.1, 1, 97, 31),
+                                                 (11, 0.05, 9, 1, 1), (12, 0.3, 600, 50, 40)])
+def test_interpolation_on_the_code_map_is_exact(emul, seed, density, ms, w, h):
+    """Round 6: the ray walk of k_interpolate_tab reads ONE byte map of the image padded by the search range (adc_device_fn.h:
+    valid / outside / skip of the cell) through linear ray offsets, 2 steps in a ray's first trip and 4 in the following ones, without bounds tests.  Every target is filled
+    exactly like by the plain walk -- widths that are not multiples of 4, rays that leave the image on every side, ranges from 1 to
+    beyond the image size, the validity density of the noise pair -- and every look-up stays inside the padded map."""
+    rng = np.random.default_rng(seed)
+    valid = rng.random((h, w)) < density
+    if w > 100:
+        valid[:, 100:] |= rng.random((h, w - 100)) < 0.3
+    disp = np.where(valid, rng.integers(0, 90, (h, w)).astype(np.float32) + rng.random((h, w)).astype(np.float32), np.float32(np.inf)).astype(np.float32)
+    label = rng.integers(0, 3, (h, w)).astype(np.uint8)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    emul.emul_interpolate_code.restype = C.c_long
+    for which in (1, 2):
+        want, got = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+        emul.emul_interpolate(P(disp), P(want), P(label), P(img), w, h, which, ms)
+        for ns1, ns2 in ((2, 4), (8, 8), (1, 7)):  # (the kernel's trip lengths, the table's limit, an odd pair)
+            n = emul.emul_interpolate_code(P(disp), P(got), P(label), P(img), w, h, which, ms, ns1, ns2)
+            assert n >= 0, n
+            assert same(got, want)
 
 
 def test_aggregation_launch_gate(emul):
