@@ -280,27 +280,28 @@ __global__ __launch_bounds__(256) void k_itp_code(const float* __restrict__ disp
 // bounds tests: outside the image the map says so; no separate cell-distance gather: the code of an invalid pixel IS its skip) and the
 // end test; the value and the colour of the hit are fetched once behind the walk.  (A first attempt of this round replaced the map
 // gathers by bit tests on 8x8 validity tiles -- fewer gathers, MORE instructions: 0.28 -> 0.44 ms, profiles/r6_ab_k9_code_map.txt.)
-// One trip of N steps of a ray: m = its next step, hm = the step of its hit (0: none so far).  Rays that have ended take no part in the
+// One trip of N steps of a ray: m = its next step, ho = the linear offset of its hit (ITP_NO_HIT: none so far).  Rays that have ended take no part in the
 // gathers (execution mask): the address unit's time goes with the lanes it serves -- measured, 0.235 -> 0.14 ms per list on the noise pair.
 template <int N>
 __device__ __forceinline__ void itp_trip(const int32_t* __restrict__ lt, const uint8_t* __restrict__ code, uint32_t pb, int s, int max_search,
-                                         bool& walking, int& m, int& hm)
+                                         bool& walking, int& m, int& ho)
 {
     const bool w0 = walking && m < max_search;
     uint32_t c[N];
+    int o[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) c[j] = ADC_ITP_OUTSIDE;
+    for (int j = 0; j < N; j++) { c[j] = ADC_ITP_OUTSIDE; o[j] = 0; }
     if (w0) {
         const int32_t* row = lt + (m * 16 + s);
 #pragma unroll
-        for (int j = 0; j < N; j++) c[j] = code[pb + (uint32_t)row[j * 16]];
+        for (int j = 0; j < N; j++) { o[j] = row[j * 16]; c[j] = code[pb + (uint32_t)o[j]]; }
     }
     bool act = w0;
     const int left = max_search - m; // steps left in the search range (> 0 for a walking ray)
 #pragma unroll
     for (int j = 0; j < N; j++) {
         const bool end = c[j] >= ADC_ITP_OUTSIDE || j >= left; // a hit, the image border or the end of the range
-        hm = (act && end && c[j] == ADC_ITP_VALID && j < left) ? m + j : hm;
+        ho = (act && end && c[j] == ADC_ITP_VALID && j < left) ? o[j] : ho; // (the hit's linear offset in the padded map)
         act = act && !end;
     }
     walking = act;
@@ -309,6 +310,7 @@ __device__ __forceinline__ void itp_trip(const int32_t* __restrict__ lt, const u
 // Trip lengths (same box, interleaved, refine stage of the noise pair, profiles/r6_ab_k9_code_map.txt): first trip / following trips
 // 2 / 4: 0.727 ms, 4 / 4: 0.732, 3 / 6: 0.732, 3 / 3: 0.742, 4 / 8: 0.747, 2 / 8: 0.751, 6 / 8: 0.760 (round 5's kernel: 0.99) -- at 22 % valid
 // pixels half of the rays end within two steps, and what a longer trip fetches behind the hit is wasted address-unit time.
+#define ITP_NO_HIT 0x7fffffff
 #ifndef ITP_NS1
 #define ITP_NS1 2 // steps of a ray's first trip ...
 #endif
@@ -319,8 +321,8 @@ static_assert(ITP_NS1 <= ADC_ITP_NS && ITP_NS2 <= ADC_ITP_NS, "trip lengths");
 template <bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
                                                          const float* __restrict__ din, float* __restrict__ dout,
-                                                         const uint32_t* __restrict__ bgr, const int32_t* __restrict__ tab, const int32_t* __restrict__ lin,
-                                                         int W, int which, int max_search, const uint8_t* __restrict__ code, int pitch, int gx)
+                                                         const uint32_t* __restrict__ bgr, const int32_t* __restrict__ lin,
+                                                         int W, int which, int max_search, const uint8_t* __restrict__ code, int pitch, int gx, float rcp_pitch)
 {
     extern __shared__ int32_t lin_lds[]; // [max_search + ADC_ITP_LPAD][16]
     if (TAB_LDS) {
@@ -342,18 +344,23 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
         pn = e + nslot < n ? list[e + nslot] : 0;
         const int y = p / W, x = p - y * W;
         const uint32_t pb = (uint32_t)(y * pitch + x + gx); // the target in the padded map
-        int hm = 0;            // step of the hit (0: none)
+        int ho = ITP_NO_HIT;   // linear offset of the hit in the padded map
         bool walking = live;
         // the ray's own step counter: next step to evaluate; the target's own code = the steps proven empty around it (a listed
         // pixel is invalid and inside the image)
         int m = 1 + (int)code[pb];
-        itp_trip<ITP_NS1>(lt, code, pb, s, max_search, walking, m, hm);
-        while (__any(walking && m < max_search)) itp_trip<ITP_NS2>(lt, code, pb, s, max_search, walking, m, hm);
-        // the hit: its position from the packed table, its value from the map
-        const int o = tab[hm * 16 + s]; // (row 0: no offset)
-        const int hitq = hm ? (y + (o >> 16)) * W + x + (int)(short)(o & 0xffff) : p;
+        itp_trip<ITP_NS1>(lt, code, pb, s, max_search, walking, m, ho);
+        while (__any(walking && m < max_search)) itp_trip<ITP_NS2>(lt, code, pb, s, max_search, walking, m, ho);
+        // the hit: ho = dy * pitch + dx with 0 <= dy and |dx| < gx <= pitch / 2, so dy = (ho + gx) / pitch -- by a float reciprocal
+        // and one correction step (ho + gx < 2^24: exact in float; the quotient is off by at most one) -- and its value from the map
+        const bool found = ho != ITP_NO_HIT;
+        const int a = found ? ho + gx : 0;
+        int dy = (int)((float)a * rcp_pitch);
+        const int r = a - dy * pitch;
+        dy += (r >= pitch ? 1 : 0) - (r < 0 ? 1 : 0);
+        const int hitq = found ? p + dy * W + (ho - dy * pitch) : p;
         const float hv = din[hitq];
-        const float hit = hm ? hv : ADC_INVALID_FLOAT; // first valid disparity along this ray
+        const float hit = found ? hv : ADC_INVALID_FLOAT; // first valid disparity along this ray
         // combine the 16 rays of this pixel (lanes with equal lane&3)
         float best;
         bool any;
@@ -407,7 +414,7 @@ hipError_t adc_launch_interpolation(adc_handle* h)
             if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(k_interp_list, dim3((P + 256 * ITP_LIST_PPT - 1) / (256 * ITP_LIST_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l,
                                h->interp_list, h->interp_counters, which, P);
-            if (h->ray_tab && max_search == h->ray_tab_rows && max_search == h->itp_ms) {
+            if (h->ray_tab && max_search == h->ray_tab_rows && max_search == h->itp_ms && (size_t)h->itp_ms * (size_t)h->itp_pitch < ((size_t)1 << 24)) { // (linear offsets exact in float: see the kernel)
                 if (k == 0 && !h->bgrx_valid) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
                 const int cw = (p.W + ITP_CELL - 1) / ITP_CELL, ch = (p.H + ITP_CELL - 1) / ITP_CELL, nc = cw * ch;
                 uint8_t* code = h->itp_cells + itp_code_offset(p.W, p.H);
@@ -422,7 +429,7 @@ hipError_t adc_launch_interpolation(adc_handle* h)
                 const bool tab_lds = lin_bytes <= 40 * 1024; // (ranges up to 576; larger ones read the table from global memory)
 #define INTERP_TAB(L_)                                                                                                 \
     hipLaunchKernelGGL((k_interpolate_tab<L_>), dim3(2048), dim3(256), L_ ? lin_bytes : 0, h->stream, h->interp_list, h->interp_counters, \
-                       h->disp_l, h->disp_tmp, h->bgrx_l, h->ray_tab, h->ray_lin, p.W, which, max_search, code, h->itp_pitch, h->itp_ms)
+                       h->disp_l, h->disp_tmp, h->bgrx_l, h->ray_lin, p.W, which, max_search, code, h->itp_pitch, h->itp_ms, 1.0f / (float)h->itp_pitch)
                 if (tab_lds) INTERP_TAB(true);
                 else INTERP_TAB(false);
 #undef INTERP_TAB
@@ -647,21 +654,46 @@ typedef float medb_v2f __attribute__((ext_vector_type(2)));
 // all of them write nothing to the map (workgroups nbands ..: chain of target b = workgroups nbands + (b-R-1)*R + j, j = 0 .. R-1).
 // Bands 1 .. R chain from the real band 0, which has no row above.  Every dependency chain is R + 1 waves long instead of 17,
 // and a wave only runs the levels at which its rows (or the hand-off its successor re-checks) are active: ~2200 instead of 4078.
-// k_median_spec_check then compares what the last copy of each chain handed over with what the real band b-1 published -- bit
+// k_median_seg_check then compares what the last copy of each chain handed over with what the real band b-1 wrote into the map -- bit
 // for bit, every column; a difference raises the error word (2) and adc_wait redoes the filter in the chained form.
+//
+// SPECULATIVE COLUMN SEGMENTS (round 6, nseg > 1; needs spec > 0 and an even width).  With the chains every wave still runs W + ~200
+// levels -- 0.27 ms at 1080p on 45 of the chip's 1024 SIMDs.  The filter forgets sideways as it forgets downwards
+// (tools/median_spec_segments.py: with 128 columns of warm-up no seam of any bench pair differs), so every link is cut into nseg
+// segments [xs, xe) (boundaries multiples of 16), one wave each: workgroup = link * nseg + segment.  The waves of a chain that serve
+// segment s > 0 run ONE window of levels [ts, te):  ts = xs - warm + 2 * (first row of the chain's real band) -- the real band's top
+// row starts `warm` columns in front of the segment, every row below it two columns further left --, te = when the real band's last row
+// has passed column xe.  Below ts a lane passes the RAW value through as its result (whole blocks: ts is a multiple of 16): the warm-up
+// starts from unfiltered pixels exactly like a chain starts from the raw row above it; a link 64 rows further up simply stands 128
+// columns further right at the same level, so all links and segments run side by side and the hand-off protocol between a link and
+// its upstream link (same segment) is the one of the whole-row form.  A real link writes the columns [xs, xe) of its rows and puts the
+// last column pair of its warm-up (xs - 2, xs - 1) into its seam slot instead of the store sink.  k_median_seg_check then compares, bit
+// for bit: the hand-off every real band b >= 1 consumed over the columns xs - 1 .. xe with the map row above it, and the seam column
+// xs - 1 of every real segment s >= 1 with the map (where segment s - 1 wrote it) -- all equal => the map is the in-place filter
+// (induction over bands and segments; CPU emulation: emul_median_spec_segments); a difference raises the error word like a failing
+// row seam does, and adc_wait redoes the filter in the chained whole-row form.
 template <bool PAIRS>
 __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* __restrict__ out, int W, int H,
                                                              int* progress, int* error_word, float* hand, int hpitch, int nbands, int spec,
-                                                             float* sinks)
+                                                             float* sinks, int nseg, int warm, float* seam)
 {
     const int tid = threadIdx.x;
-    const bool is_spec = (int)blockIdx.x >= nbands; // a copy (writes no map): link ck of the chain of target band ct
-    const int ck = is_spec ? ((int)blockIdx.x - nbands) % spec : 0, ct = is_spec ? spec + 1 + ((int)blockIdx.x - nbands) / spec : 0;
-    const int band = is_spec ? ct - spec + ck : (int)blockIdx.x; // the rows this wave filters
+    if constexpr (!PAIRS) nseg = 1; // (the one-column form runs whole rows: everything below folds to the whole-row code)
+    const int link = (int)blockIdx.x / nseg, seg = (int)blockIdx.x - link * nseg;
+    const bool is_spec = link >= nbands; // a copy (writes no map): link ck of the chain of target band ct
+    const int ck = is_spec ? (link - nbands) % spec : 0, ct = is_spec ? spec + 1 + (link - nbands) / spec : 0;
+    const int band = is_spec ? ct - spec + ck : link; // the rows this wave filters
     const int myslot = (int)blockIdx.x;                          // hand-off row it publishes its last row into
     const bool raw_above = is_spec && ck == 0;                    // first link of a chain: the raw row above as its row above
-    // hand-off row this wave reads: the link before it / for a real band the last link of its chain, or the real band above
-    const int upslot = is_spec ? (int)blockIdx.x - 1 : ((spec && band > spec) ? nbands + (band - spec - 1) * spec + spec - 1 : band - 1);
+    // hand-off row this wave reads: the link before it / for a real band the last link of its chain, or the real band above (same segment)
+    const int upslot = (is_spec ? link - 1 : ((spec && band > spec) ? nbands + (band - spec - 1) * spec + spec - 1 : band - 1)) * nseg + seg;
+    // the segment's columns, and the real band at the end of this wave's chain (bands 0 .. spec feed each other: their windows end with band spec's)
+    const int xs = nseg > 1 ? ((int)((long long)W * seg / nseg) & ~15) : 0;
+    const int xe = (nseg > 1 && seg + 1 < nseg) ? ((int)((long long)W * (seg + 1) / nseg) & ~15) : W;
+    const int chain_first = (is_spec ? ct : band) * MEDB_ROWS;
+    const int chain_lastband = is_spec ? ct : ((spec && band <= spec) ? adc_imin(spec, nbands - 1) : band);
+    const int chain_ylast = adc_imin((chain_lastband + 1) * MEDB_ROWS, H) - 1;
+    const int ts = seg > 0 ? adc_imax(0, xs - warm + 2 * chain_first) : 0; // first level that is filtered (a multiple of 16)
     const int y = band * MEDB_ROWS + tid;
     const int nsteps = W + 2 * (H - 1);
     const int yfirst = band * MEDB_ROWS, ylast = adc_imin(yfirst + MEDB_ROWS, H) - 1; // rows of this band (wave-uniform)
@@ -684,8 +716,13 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     // the first one used is level 2 * yfirst - 1 (the value the first row needs as "above" on column 0), which sits in the
     // second block -- to the last level the band BELOW re-checks hand-off values for (its first row stands on its last column
     // at level W + 2 * ylast + 1 and takes over whole blocks)
-    const int tb = spec ? adc_imax(0, 2 * yfirst - 2 * MEDB_K) & ~(MEDB_K - 1) : 0;
-    const int te = spec ? adc_imin(nsteps, W + 2 * ylast + 3 * MEDB_K) : nsteps;
+    // (segments: not before two blocks in front of the window -- one is taken over without a re-check, one passes raw values through so
+    // that the filter finds raw neighbours in its registers -- and, unless the segment ends at the image's right border, to the end of the
+    // chain's window: the link below needs this one's last row that far)
+    const int tb_rows = spec ? adc_imax(0, 2 * yfirst - 2 * MEDB_K) & ~(MEDB_K - 1) : 0;
+    const int tb = seg > 0 ? adc_imax(tb_rows, ts - 2 * MEDB_K) : tb_rows;
+    const int te = (nseg > 1 && xe < W) ? adc_imin(nsteps, xe + 2 * chain_ylast + 3 * MEDB_K)
+                                        : (spec ? adc_imin(nsteps, W + 2 * ylast + 3 * MEDB_K) : nsteps);
     const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT;
     int x = tb - 2 * y; // column at the first level
     float A0 = rowA[clampc(x)], A1 = rowA[clampc(x + 1)], A2 = rowA[clampc(x + 2)];
@@ -776,6 +813,8 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     float* const hrow = hand + (size_t)myslot * hpitch + MEDB_HPAD;
     float* const orow = out + (size_t)(row_ok ? y : 0) * W;
     const bool st_ok = row_ok && !is_spec; // (a speculative copy stores to the sink)
+    float* const seamp = seam + ((size_t)(band * nseg + seg) * MEDB_ROWS + tid) * 2; // column pair (xs - 2, xs - 1) of a real segment's warm-up
+    const bool seam_ok = st_ok && seg > 0;
 
     // One block of MEDB_K levels (SI = register set the prefetch of this iteration goes into, ST = set taken over at its end).
     // band > 0 stays behind the upstream band: the block uses hand-off values of levels < t0+MEDB_K-1 and prefetches those of
@@ -829,13 +868,16 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
             bmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ml | mr));                                           \
         }                                                                                                               \
         float res_even = 0.f;                                                                                           \
+        const bool pass = PAIRS && t0 < ts; /* (uniform; whole blocks) in front of the segment's window: raw values pass through; the one-column form runs whole rows */ \
 _Pragma("unroll")                                                                                                       \
         for (int k = 0; k < MEDB_K; k++) {                                                                              \
             const bool active = row_ok && (x >= 0) && (x < W);                                                          \
             const float F1 = medb_dpp_old<0x138>(cx[k], Pv);                                                            \
             const float B1 = medb_dpp_old<0x130>(cx[k], ca[k]);                                                         \
             float res;                                                                                                  \
-            if (bmask & (1u << k)) {                                                                                    \
+            if (pass) {                                                                                                 \
+                res = A0;                                                                                               \
+            } else if (bmask & (1u << k)) {                                                                             \
                 const bool lf = x > 0, rt = x + 1 < W;                                                                  \
                 const float v0 = (up && lf) ? Fm : PINF, v1 = up ? F0 : NINF, v2 = (up && rt) ? F1 : PINF;              \
                 const float v3 = lf ? Pv : NINF, v5 = rt ? A1 : NINF;                                                   \
@@ -850,7 +892,7 @@ _Pragma("unroll")                                                               
                 if ((k & 1) == 0) res_even = res;                                                                       \
                 else {                                                                                                  \
                     const medb_v2f pr = {res_even, res};                                                                \
-                    float* dst = (st_ok && x >= 1 && x < W) ? orow + (x - 1) : sinkf;                                   \
+                    float* dst = (st_ok && x > xs && x < xe) ? orow + (x - 1) : ((seam_ok && x == xs - 1) ? seamp : sinkf); \
                     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pr) : "memory");                    \
                 }                                                                                                       \
             } else {                                                                                                    \
@@ -911,17 +953,40 @@ _Pragma("unroll")                                                               
 #undef MEDB_TAKE8
 }
 
-// Seam check of the speculative bands: the last copy of the chain of target band b (a copy of band b - 1) must have handed over
-// exactly what the real band b - 1 published (hand-off row b - 1), at every level at which that band's last row stands on a column.
-__global__ __launch_bounds__(256) void k_median_spec_check(const float* __restrict__ hand, int hpitch, int nbands, int spec, int W, int* error_word)
+// Seam check of the speculative forms (one launch, blockIdx.y = real band b):
+//   row seams     the hand-off row band b >= 1 consumed -- the last copy of its chain (b > spec) or the real band above (b <= spec), segment
+//                 s -- must equal, at every column xs - 1 .. xe of the segment, the map row above the band (what the real band b - 1 wrote);
+//                 level at which the row 64 b - 1 stands on column c: t = c + 2 (64 b - 1)
+//   column seams  (nseg > 1) the column xs - 1 a real segment s >= 1 reached in its warm-up must equal the map (segment s - 1 wrote it)
+// Whole rows (nseg = 1): the first is round 4's check of the speculative bands (bands 1 .. spec compare a row with itself).
+__global__ __launch_bounds__(256) void k_median_seg_check(const float* __restrict__ hand, int hpitch, int nbands, int spec, int nseg, int W, int H,
+                                                          const float* __restrict__ out, const float* __restrict__ seam, int* error_word)
 {
-    const int b = spec + 1 + (int)blockIdx.y; // targets spec + 1 .. nbands - 1
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (b > nbands - 1 || x >= W) return;
-    const int t = x + 2 * ((b - 1) * MEDB_ROWS + MEDB_ROWS - 1); // level at which row 64 (b - 1) + 63 stands on column x
-    const uint32_t real = reinterpret_cast<const uint32_t*>(hand)[(size_t)(b - 1) * hpitch + MEDB_HPAD + t];
-    const uint32_t copy = reinterpret_cast<const uint32_t*>(hand)[(size_t)(nbands + (b - spec - 1) * spec + spec - 1) * hpitch + MEDB_HPAD + t];
-    if (real != copy) atomicMax(error_word, 2);
+    const int b = (int)blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int yf = b * MEDB_ROWS;
+    bool bad = false;
+    if (i < W) {
+        if (b >= 1) {
+            const int c = i, t = c + 2 * (yf - 1);
+            const int up = (spec && b > spec) ? nbands + (b - spec - 1) * spec + spec - 1 : b - 1;
+            const uint32_t want = reinterpret_cast<const uint32_t*>(out)[(size_t)(yf - 1) * W + c];
+            for (int sgm = 0; sgm < nseg; sgm++) {
+                const int xs = nseg > 1 ? ((int)((long long)W * sgm / nseg) & ~15) : 0;
+                const int xe = (nseg > 1 && sgm + 1 < nseg) ? ((int)((long long)W * (sgm + 1) / nseg) & ~15) : W;
+                if (c >= xs - 1 && c <= xe) bad = bad || reinterpret_cast<const uint32_t*>(hand)[(size_t)(up * nseg + sgm) * hpitch + MEDB_HPAD + t] != want;
+            }
+        }
+    } else {
+        const int j = i - ((W + 255) & ~255); // column seams: (segment, row of the band)
+        const int sgm = j / MEDB_ROWS, r = j - sgm * MEDB_ROWS;
+        if (j >= 0 && sgm >= 1 && sgm < nseg && yf + r < H) {
+            const int xs = (int)((long long)W * sgm / nseg) & ~15;
+            bad = reinterpret_cast<const uint32_t*>(seam)[((size_t)(b * nseg + sgm) * MEDB_ROWS + r) * 2 + 1] !=
+                  reinterpret_cast<const uint32_t*>(out)[(size_t)(yf + r) * W + xs - 1];
+        }
+    }
+    if (bad) atomicMax(error_word, 2);
 }
 
 static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float* out)
@@ -950,8 +1015,27 @@ static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float*
     return hipGetLastError();
 }
 
-// in -> out with the banded kernel; spec = 1: speculative bands + seam check.  The error word (0 ok, 1 hand-off time-out,
-// 2 speculative seam differs) goes to pin_flags[0], looked at by adc_wait.
+// Segments per band link of the speculative form: a segment should be well above its 128 columns of warm-up, and the chip takes
+// (bands + copies) x segments single-wave workgroups side by side.  ADC_MEDIAN_SEG overrides (1 = whole rows), ADC_MEDIAN_WARM the warm-up.
+#define MEDB_MAX_SEG 8
+static int median_warm()
+{
+    static const int v = [] { const char* e = getenv("ADC_MEDIAN_WARM"); const int w = e ? atoi(e) : 128; return adc_imax(0, adc_imin(w, 1024)) & ~15; }();
+    return v;
+}
+static int median_segments(int W, int spec)
+{
+    static const int env = [] { const char* e = getenv("ADC_MEDIAN_SEG"); return e ? atoi(e) : 0; }();
+    if (!spec || (W & 1)) return 1; // (the chained form and odd widths run whole rows)
+    int n = env > 0 ? env : W / 240; // 1080p: 8 segments of 240 columns, KITTI size: 5
+    n = adc_imax(1, adc_imin(n, MEDB_MAX_SEG));
+    while (n > 1 && ((W / n) & ~15) < 64) n--; // (every segment at least 64 columns wide)
+    return n;
+}
+size_t adc_median_hand_rows(int H) { return (size_t)(5 * ((H + 63) / 64) + 1) * MEDB_MAX_SEG; } // bands + chains of <= 4 copies per band, per segment
+
+// in -> out with the banded kernel; spec > 0: speculative bands (+ column segments) + seam check.  The error word (0 ok, 1 hand-off
+// time-out, 2 speculative seam differs) goes to pin_flags[0], looked at by adc_wait.
 static hipError_t launch_median_banded(adc_handle* h, const float* in, float* out, int spec)
 {
     const AdcParams& p = h->p;
@@ -962,22 +1046,27 @@ static hipError_t launch_median_banded(adc_handle* h, const float* in, float* ou
     if ((in != h->disp_l && in != h->disp_tmp) || (out != h->disp_l && out != h->disp_tmp) || in == out) return hipErrorInvalidValue;
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
     const int ncopies = spec ? (nbands - 1 - spec) * spec : 0; // a chain of `spec` copies per target band spec + 1 .. nbands - 1
+    const int nseg = median_segments(p.W, spec), nlinks = nbands + ncopies;
+    if ((size_t)nlinks * nseg + 1 > adc_median_hand_rows(p.H)) return hipErrorInvalidValue;
     // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
     // the hand-off rows are reset to the "not written yet" sentinel (all ones) before every launch
     int* prog = h->vote_counters + 160;
     hipMemsetAsync(prog + 256, 0, 16 * sizeof(int32_t), h->stream);
-    hipMemsetAsync(h->med_hand, 0xFF, (size_t)(nbands + ncopies + 1) * h->med_hpitch * sizeof(float), h->stream);
+    hipMemsetAsync(h->med_hand, 0xFF, ((size_t)nlinks * nseg + 1) * h->med_hpitch * sizeof(float), h->stream);
+    float* seam = h->med_sink + (size_t)adc_median_hand_rows(p.H) * 64 * 4; // [bands][segments][64 rows][2] behind the sinks
     // pairs of columns per instruction when the width is even (ADC_MEDIAN_PAIRS=0: always one column per instruction)
     static const bool pairs_env = [] { const char* e = getenv("ADC_MEDIAN_PAIRS"); return e ? atoi(e) != 0 : true; }();
-    if (pairs_env && (p.W & 1) == 0)
-        hipLaunchKernelGGL(k_median_banded<true>, dim3(nbands + ncopies), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
-                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink);
+    const bool pairs = pairs_env && (p.W & 1) == 0;
+    const int nseg_run = pairs ? nseg : 1;
+    if (pairs)
+        hipLaunchKernelGGL(k_median_banded<true>, dim3(nlinks * nseg_run), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
+                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink, nseg_run, median_warm(), seam);
     else
-        hipLaunchKernelGGL(k_median_banded<false>, dim3(nbands + ncopies), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
-                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink);
+        hipLaunchKernelGGL(k_median_banded<false>, dim3(nlinks), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
+                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink, 1, 0, seam);
     if (spec)
-        hipLaunchKernelGGL(k_median_spec_check, dim3((p.W + 255) / 256, nbands - 1 - spec), dim3(256), 0, h->stream, h->med_hand, h->med_hpitch,
-                           nbands, spec, p.W, prog + 260);
+        hipLaunchKernelGGL(k_median_seg_check, dim3((p.W + 255) / 256 + (MEDB_ROWS * nseg_run + 255) / 256, nbands), dim3(256), 0, h->stream, h->med_hand,
+                           h->med_hpitch, nbands, spec, nseg_run, p.W, p.H, out, seam, prog + 260);
     h->med_spec_last = spec;
     if (h->pin_flags) hipMemcpyAsync(h->pin_flags, prog + 260, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream); // checked by adc_wait
     return hipGetLastError();
@@ -989,8 +1078,6 @@ hipError_t adc_launch_median(adc_handle* h)
     static const bool banded = [] { const char* e = getenv("ADC_MEDIAN_BANDED"); return e ? atoi(e) != 0 : true; }();
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
     if (banded && nbands > 1 && nbands <= 256 && p.W >= 2 && p.H >= 2 && h->med_hand) {
-        // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
-        // the hand-off rows are reset to the "not written yet" sentinel (all ones) before every launch
         // speculative bands (ADC_MEDIAN_SPEC=0: chained form; also for a while after a seam of this handle has failed)
         // (ADC_MEDIAN_SPEC = run-in in bands, default 2 = 128 rows, 0 = chained form)
         static const int spec_env = [] { const char* e = getenv("ADC_MEDIAN_SPEC"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 4 ? 4 : v); }();

@@ -1135,14 +1135,16 @@ long emul_interpolate_code(const float* din, float* dout, const uint8_t* label, 
             bool any = false;
             const long pb = (long)y * pitch + x + gx;
             for (int s = 0; s < 16; s++) {
-                int hm = 0;
+                int ho = 0x7fffffff; // (ITP_NO_HIT)
                 bool walking = true;
                 int m = 1 + (int)code[pb];
                 for (int trip = 0; walking && m < ms; trip++) {
                     const int NS = trip == 0 ? ns1 : ns2; // (the kernel: ITP_NS1 steps in a ray's first trip, ITP_NS2 in the following ones)
                     uint32_t c[ADC_ITP_NS];
+                    int o[ADC_ITP_NS];
                     for (int j = 0; j < NS; j++) {
-                        const long q = pb + lin[(size_t)(m + j) * 16 + s];
+                        o[j] = lin[(size_t)(m + j) * 16 + s];
+                        const long q = pb + o[j];
                         if (q < 0 || q >= (long)pitch * rows) return -1; // (the padding covers every position of the range)
                         c[j] = code[q];
                         lookups++;
@@ -1151,15 +1153,23 @@ long emul_interpolate_code(const float* din, float* dout, const uint8_t* label, 
                     const int left = ms - m;
                     for (int j = 0; j < NS; j++) {
                         const bool end = c[j] >= ADC_ITP_OUTSIDE || j >= left;
-                        if (act && end && c[j] == ADC_ITP_VALID && j < left) hm = m + j;
+                        if (act && end && c[j] == ADC_ITP_VALID && j < left) { ho = o[j]; if (tab[(size_t)(m + j) * 16 + s] == 0 && m + j > 0 && o[j] == 0) return -7; }
                         act = act && !end;
                     }
                     walking = act;
                     m += act ? NS + (int)c[NS - 1] : 0;
                 }
-                if (hm) {
-                    const int o = tab[(size_t)hm * 16 + s];
-                    const int yy = y + (o >> 16), xx = x + (int)(short)(o & 0xffff);
+                if (ho != 0x7fffffff) {
+                    // the kernel's way back from the linear offset: dy = (ho + gx) / pitch by a float reciprocal + one correction step
+                    if ((long)ms * pitch >= (1L << 24)) return -8; // (the launch falls back to the f64 kernel there)
+                    const float rcp_pitch = 1.0f / (float)pitch;
+                    const int a = ho + gx;
+                    int dy = (int)((float)a * rcp_pitch);
+                    const int r = a - dy * pitch;
+                    dy += (r >= pitch ? 1 : 0) - (r < 0 ? 1 : 0);
+                    const int dx = ho - dy * pitch;
+                    if (a < 0 || dy < 0 || dx <= -ms || dx >= ms) return -9;
+                    const int yy = y + dy, xx = x + dx;
                     if (yy < 0 || yy >= H || xx < 0 || xx >= W) return -2; // (a hit lies inside the image)
                     const float hit = din[(size_t)yy * W + xx];
                     if (hit == ADC_INVALID_FLOAT) return -3;
@@ -1233,7 +1243,7 @@ void emul_median_padded(const float* in, float* out, int W, int H)
 // Speculative bands of the banded median (k_median_banded, spec = 1): bands of `rows` rows; the real band c + 1 (c >= 1) takes as
 // its "filtered row above" the last row of a COPY of band c that was filtered starting from the RAW row above band c; band 1
 // takes the real band 0's last row.  `out` = the map the real bands write; returns the number of copies whose last row differs
-// from the last row the real band wrote (what k_median_spec_check counts) -- 0 means out is the true in-place filter.
+// from the last row the real band wrote (what k_median_seg_check counts) -- 0 means out is the true in-place filter.
 static void emul_median_band_rows(const float* raw, float* dst_rows, const float* above /* filtered row y0 - 1 or nullptr */, int W, int H, int y0, int y1)
 {
     // rows [y0, y1) filtered in raster order: row above = `above` (already filtered), rows below = raw
@@ -1285,6 +1295,114 @@ long emul_median_spec_bands(const float* raw, float* out, int W, int H, int rows
         emul_median_band_rows(raw, out + (size_t)y0 * W, above, W, H, y0, y1);
         if (b > depth && memcmp(handoff.data(), out + (size_t)(y0 - 1) * W, (size_t)W * sizeof(float))) fails++; // (the real band b - 1 is done by now)
     }
+    return fails;
+}
+
+// Speculative COLUMN SEGMENTS of the banded median (round 6; k_median_banded with nseg > 1).  Every band link is cut into nseg
+// segments [xs, xe) (boundaries multiples of 16); the waves of a chain (the copies of the bands b - depth .. b - 1 and the real band b;
+// bands 0 .. depth chain from the real band 0) that serve segment s all run the SAME window of levels t = x + 2y:
+//     ts = xs - warm + 2 * (first row of the chain's real band)   (0 for segment 0: the true left border)
+//     te = xe + 2 * (last row of the chain's real band) + 48       (the link's own last row when xe == W: the true right border)
+// below ts a lane passes the raw value through (the speculation: unfiltered instead of filtered, as for the raw row above a chain),
+// from te on nothing is computed (NaN here, the hand-off sentinel on the device: must never be consumed).  A real link writes the
+// columns [xs, xe) of its rows into `out` and keeps the column xs - 1 of its warm-up as its seam.  Checks (k_median_seg_check):
+//   row seams     the hand-off a real band b >= 1 consumed over the columns xs - 1 .. xe == the map row above it
+//   column seams  the seam column of a real segment s >= 1 == the map column xs - 1 (written by segment s - 1)
+// Returns the number of failing (band, segment) pairs; 0 means `out` is the true in-place filter (induction over bands and segments).
+static bool emul_med_isnan(float v) { return v != v; }
+static void emul_median_link(const float* raw, const float* above /* W values of row y0 - 1 as the upstream published them; nullptr: no row above */,
+                             float* vals /* [y1 - y0][W] */, int W, int H, int y0, int y1, int ts, int te, bool* nan_used)
+{
+    const float PINF = ADC_INVALID_FLOAT, NINF = -ADC_INVALID_FLOAT, NANV = NAN;
+    for (int y = y0; y < y1; y++) {
+        float* cur = vals + (size_t)(y - y0) * W;
+        const float* prev = y == y0 ? above : vals + (size_t)(y - 1 - y0) * W;
+        for (int x = 0; x < W; x++) {
+            const int t = x + 2 * y;
+            if (t < ts) { cur[x] = raw[(size_t)y * W + x]; continue; }
+            if (t >= te) { cur[x] = NANV; continue; }
+            float v[9];
+            for (int r = -1; r <= 1; r++)
+                for (int c = -1; c <= 1; c++) {
+                    const int row = y + r, col = x + c, i = (r + 1) * 3 + (c + 1);
+                    const bool corner = (r != 0) && (c != 0);
+                    float val = corner ? PINF : NINF;
+                    if (row >= 0 && row < H && col >= 0 && col < W) {
+                        if (r < 0) val = prev[col];
+                        else if (r == 0 && c < 0) val = cur[col];
+                        else val = raw[(size_t)row * W + col];
+                        if (emul_med_isnan(val)) *nan_used = true;
+                    }
+                    v[i] = val;
+                }
+            cur[x] = adc_median9(v[0], v[1], v[6], v[5], v[7], v[8], v[2], v[3], v[4]);
+        }
+    }
+}
+long emul_median_spec_segments(const float* raw, float* out, int W, int H, int rows, int depth, int nseg, int warm, long* nan_reads)
+{
+    const int nb = (H + rows - 1) / rows;
+    long fails = 0;
+    bool nan_used = false;
+    std::vector<float> seam((size_t)nb * nseg * rows, 0.f), consumed((size_t)nb * nseg * W, 0.f); // per real (band, segment): seam column, hand-off row consumed
+    std::vector<std::vector<float>> real_vals((size_t)(depth + 1) * nseg); // full rows of the real links of bands 0 .. depth (they feed each other)
+    std::vector<float> a(( size_t)rows * W), b2((size_t)rows * W);
+    for (int b = 0; b < nb; b++) {
+        const int y0 = b * rows, y1 = std::min(H, y0 + rows);
+        for (int s = 0; s < nseg; s++) {
+            const int xs = (int)((long)W * s / nseg) & ~15, xe = s + 1 == nseg ? W : ((int)((long)W * (s + 1) / nseg) & ~15);
+            std::vector<float> up; // hand-off row the real link consumes
+            const int tgt_first = b <= depth ? 0 : y0; // (bands 0 .. depth: one chain rooted in band 0 -- every link of it has its own window, see below)
+            (void)tgt_first;
+            auto window = [&](int chain_y0, int chain_ylast, int link_ylast, int* ts, int* te) {
+                *ts = s == 0 ? 0 : std::max(0, xs - warm + 2 * chain_y0);
+                *te = xe == W ? W + 2 * link_ylast + 48 : xe + 2 * chain_ylast + 48;
+            };
+            int ts, te;
+            if (b > depth) {
+                for (int j = 0; j < depth; j++) { // copy of band b - depth + j
+                    const int c0 = (b - depth + j) * rows, c1 = c0 + rows;
+                    window(y0, y1 - 1, c1 - 1, &ts, &te);
+                    std::vector<float> prev(up);
+                    emul_median_link(raw, j == 0 ? raw + (size_t)(c0 - 1) * W : prev.data(), a.data(), W, H, c0, c1, ts, te, &nan_used);
+                    up.assign(a.begin() + (size_t)(rows - 1) * W, a.begin() + (size_t)rows * W);
+                }
+            } else if (b >= 1) {
+                const std::vector<float>& rv = real_vals[(size_t)(b - 1) * nseg + s];
+                up.assign(rv.end() - W, rv.end());
+            }
+            // the real link: bands 0 .. depth run to the end of band `depth`'s window (their hand-off feeds the next real band)
+            const int last_fed = std::min(depth, nb - 1);
+            const int chain_ylast = b <= depth ? std::min(H, (last_fed + 1) * rows) - 1 : y1 - 1;
+            window(y0, chain_ylast, y1 - 1, &ts, &te);
+            b2.assign((size_t)rows * W, 0.f);
+            emul_median_link(raw, b >= 1 ? up.data() : nullptr, b2.data(), W, H, y0, y1, ts, te, &nan_used);
+            for (int y = y0; y < y1; y++)
+                for (int x = xs; x < xe; x++) {
+                    const float v = b2[(size_t)(y - y0) * W + x];
+                    if (emul_med_isnan(v)) nan_used = true;
+                    out[(size_t)y * W + x] = v;
+                }
+            if (s > 0) for (int y = y0; y < y1; y++) seam[((size_t)b * nseg + s) * rows + (y - y0)] = b2[(size_t)(y - y0) * W + xs - 1];
+            if (b >= 1) std::copy(up.begin(), up.end(), consumed.begin() + ((size_t)b * nseg + s) * W);
+            if (b <= depth) real_vals[(size_t)b * nseg + s].assign(b2.begin(), b2.begin() + (size_t)(y1 - y0) * W);
+        }
+    }
+    for (int b = 0; b < nb; b++) {
+        const int y0 = b * rows, y1 = std::min(H, y0 + rows);
+        for (int s = 0; s < nseg; s++) {
+            const int xs = (int)((long)W * s / nseg) & ~15, xe = s + 1 == nseg ? W : ((int)((long)W * (s + 1) / nseg) & ~15);
+            bool bad = false;
+            if (b >= 1)
+                for (int c = std::max(xs - 1, 0); c <= std::min(xe, W - 1); c++)
+                    bad = bad || memcmp(&consumed[((size_t)b * nseg + s) * W + c], &out[(size_t)(y0 - 1) * W + c], sizeof(float)) != 0;
+            if (s >= 1)
+                for (int y = y0; y < y1; y++)
+                    bad = bad || memcmp(&seam[((size_t)b * nseg + s) * rows + (y - y0)], &out[(size_t)y * W + xs - 1], sizeof(float)) != 0;
+            if (bad) fails++;
+        }
+    }
+    if (nan_reads) *nan_reads = nan_used ? 1 : 0;
     return fails;
 }
 

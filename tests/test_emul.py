@@ -504,6 +504,34 @@ def test_median_speculative_bands(emul, port_oracle, kind, w, h, d, seed, rows, 
         assert not same(out, o["disp_final"]) or rows < 64
 
 
+@pytest.mark.parametrize("kind,w,h,d,seed,rows,depth,nseg,warm", [("structured", 400, 300, 32, 5, 64, 2, 3, 128), ("noise", 336, 330, 16, 9, 64, 2, 2, 128),
+                                                                  ("noise", 480, 200, 16, 11, 64, 2, 4, 64), ("structured", 400, 300, 32, 5, 64, 1, 3, 128),
+                                                                  ("noise", 336, 330, 16, 9, 64, 2, 3, 0), ("noise", 336, 330, 16, 9, 8, 2, 3, 16),
+                                                                  ("structured", 250, 140, 32, 7, 64, 2, 2, 32), ("noise", 130, 70, 16, 3, 64, 2, 2, 16)])
+def test_median_speculative_segments(emul, port_oracle, kind, w, h, d, seed, rows, depth, nseg, warm):
+    """k_median_banded with speculative COLUMN SEGMENTS (round 6): every band link is cut into segments whose waves run one window of
+    levels -- raw values passed through below it (the warm-up starts from unfiltered pixels, like a chain starts from the raw row
+    above), nothing computed behind it.  The emulation counts the (band, segment) pairs whose row seam (hand-off consumed over the
+    columns xs - 1 .. xe against the map) or column seam (warm-up column xs - 1 against what segment s - 1 wrote) differs -- what
+    k_median_seg_check reports.  No failing pair => the map IS the reference's in-place filter (whatever the warm-up was); and no
+    value from behind a window's end is ever consumed."""
+    from adcensus_amd import workloads
+    from oracle import pyoracle
+    l, r = workloads.structured_pair(w, h, d, seed=seed) if kind == "structured" else workloads.noise_pair(w, h, seed=seed)
+    o = port_oracle.run(l, r, pyoracle.Option(max_disparity=d), stages=["disp_after_interp", "disp_final"])
+    raw, out = np.ascontiguousarray(o["disp_after_interp"]), np.empty((h, w), np.float32)
+    emul.emul_median_spec_segments.restype = C.c_long
+    nan_reads = C.c_long(-1)
+    fails = emul.emul_median_spec_segments(P(raw), P(out), w, h, rows, depth, nseg, warm, C.byref(nan_reads))
+    assert nan_reads.value == 0
+    if fails == 0:
+        assert same(out, o["disp_final"])
+    if rows == 64 and warm >= 128:
+        assert fails == 0
+    if warm == 0 and kind == "noise":
+        assert fails > 0  # (no warm-up at all: the seams do differ, and the checks see it)
+
+
 def test_markstein_division_is_ieee_division(tmp_path):
     """The register-ring aggregation divides by the support count with Markstein's sequence on the correctly rounded
     reciprocal (k_aggregate_rr.h: rr_divide).  tools/markstein_check.c compares it with IEEE division over EVERY binary32

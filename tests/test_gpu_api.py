@@ -166,6 +166,54 @@ def test_median_band_variants(hip, env):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env,expect_failures", [({}, False), ({"ADC_MEDIAN_SEG": "3"}, False), ({"ADC_MEDIAN_SEG": "8"}, False),
+                                                 ({"ADC_MEDIAN_SEG": "2", "ADC_MEDIAN_SPEC": "1"}, None), ({"ADC_MEDIAN_SEG": "4", "ADC_MEDIAN_WARM": "64"}, None),
+                                                 ({"ADC_MEDIAN_SEG": "4", "ADC_MEDIAN_WARM": "0"}, True), ({"ADC_MEDIAN_SEG": "1"}, False)])
+def test_median_column_segments(hip, env, expect_failures):
+    """Round 6: the speculative bands of the median cut into column segments (k_median_banded with nseg > 1: every wave runs one window
+    of levels, raw values pass through in front of it; k_median_seg_check compares the row seams with the map and the column seams
+    with what the neighbouring segment wrote).  Stage-isolated median + whole Match (twice per handle) on maps of 3-7 bands, widths
+    with and without a multiple of 16 at the segment boundaries, default segment count and forced ones, a short warm-up, and NO
+    warm-up at all: there seams must fail on the noise maps, the device must see it, and the redo in the chained form must deliver the
+    exact map anyway.  Own interpreter per variant (switches are read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import adcensus_amd as A\n"
+            "from adcensus_amd import workloads\n"
+            "from tests import cases\n"
+            "from oracle import pyoracle\n"
+            "bad = {}\n"
+            "fails = 0\n"
+            "for kind, w, h, d, seed in (('structured', 640, 330, 32, 21), ('noise', 528, 400, 16, 22), ('structured', 1000, 200, 32, 23), ('noise', 770, 260, 8, 24)):\n"
+            "    l, r = workloads.structured_pair(w, h, d, seed=seed) if kind == 'structured' else workloads.noise_pair(w, h, seed=seed)\n"
+            "    opt = pyoracle.Option(max_disparity=d)\n"
+            "    o = pyoracle.load('auto').run(l, r, opt, stages=['disp_after_interp', 'disp_final'])\n"
+            "    st = A.ADCensusStereo(device=0)\n"
+            "    assert st.Initialize(w, h, cases.to_product_option(opt))\n"
+            "    st.debug_write(A.BUF_DISP_LEFT, o['disp_after_interp'])\n"
+            "    st.debug_run(A.RUN_MEDIAN)\n"
+            "    if not np.array_equal(st.debug_read(A.BUF_DISP_LEFT).view(np.uint32), o['disp_final'].view(np.uint32)): bad[(kind, w, h, 'stage')] = 1\n"
+            "    for rep in range(2):\n"
+            "        if not np.array_equal(st.match(l, r).view(np.uint32), o['disp_final'].view(np.uint32)): bad[(kind, w, h, 'match', rep)] = 1\n"
+            "    print(kind, w, h, 'speculative form:', st.debug_counter(8), 'fallbacks', st.debug_counter(0), 'seam failures', st.debug_counter(7))\n"
+            "    fails += st.debug_counter(7)\n"
+            "    st.Release()\n"
+            "print('FAILING', bad)\n"
+            "print('SEAMFAILS', fails)\n"
+            "sys.exit(1 if bad else 0)\n") % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    fails = int([l for l in out.stdout.splitlines() if l.startswith("SEAMFAILS")][-1].split()[1])
+    if expect_failures is True:
+        assert fails > 0, out.stdout[-1500:]
+    if expect_failures is False:
+        assert fails == 0, out.stdout[-1500:]
+
+
 def test_async_pipeline_assumptions_and_budgets(hip, oracle, monkeypatch):
     """Match never waits for the device in mid-pipeline: the aggregation ASSUMES the arm maxima of the previous Match of the
     handle and the voting chain has a launch BUDGET adapted from the previous Match.  Both are verified / completed by
