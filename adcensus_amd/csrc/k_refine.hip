@@ -625,6 +625,16 @@ __global__ __launch_bounds__(1024) void k_median_wavefront(const float* __restri
 #define MEDB_HPAD 4 // hand[band][MEDB_HPAD + t]
 
 
+// Chains of the speculative form (spec = R > 0): EVERY band b >= 1 takes its row above from a private chain of min(b, R) copies of the
+// bands above it (round 6: also the bands 1 .. R, whose chains start with an exact copy of band 0 -- chained to the real bands above
+// them they had to start with those bands' windows and run to the end of band R's, up to 830 levels where every other wave runs 574).
+// Copies of all chains, in the order of their target band: medb_chain_off(b) = links in front of band b's chain.
+__host__ __device__ __forceinline__ int medb_chain_depth(int b, int spec) { return b < spec ? b : spec; }
+__host__ __device__ __forceinline__ int medb_chain_off(int b, int spec) // sum of min(t, spec) over t = 1 .. b - 1
+{
+    const int t = b - 1;
+    return t <= spec ? t * (t + 1) / 2 : spec * (spec + 1) / 2 + (t - spec) * spec;
+}
 typedef float medb_v4f __attribute__((ext_vector_type(4)));
 template <int CTRL> __device__ __forceinline__ float medb_dpp(float src)
 {
@@ -651,8 +661,8 @@ typedef float medb_v2f __attribute__((ext_vector_type(2)));
 // with a run-in of 128 rows no seam of any bench pair differs; with 64 rows 1 of 16 seams of ONE of the four 1080p noise pairs
 // tried, by two pixels).  So the real band b > R takes its hand-off not from the real band b-1 but from a private CHAIN OF COPIES
 // of the bands b-R .. b-1: the copy of band b-R takes the raw row above it, each further copy the hand-off of the copy before,
-// all of them write nothing to the map (workgroups nbands ..: chain of target b = workgroups nbands + (b-R-1)*R + j, j = 0 .. R-1).
-// Bands 1 .. R chain from the real band 0, which has no row above.  Every dependency chain is R + 1 waves long instead of 17,
+// all of them write nothing to the map (workgroups nbands ..: chain of target b = workgroups nbands + medb_chain_off(b) + j).
+// The chains of the bands 1 .. R are shorter and start with an exact copy of band 0, which has no row above.  Every dependency chain is R + 1 waves long instead of 17,
 // and a wave only runs the levels at which its rows (or the hand-off its successor re-checks) are active: ~2200 instead of 4078.
 // k_median_seg_check then compares what the last copy of each chain handed over with what the real band b-1 wrote into the map -- bit
 // for bit, every column; a difference raises the error word (2) and adc_wait redoes the filter in the chained form.
@@ -681,17 +691,22 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     if constexpr (!PAIRS) nseg = 1; // (the one-column form runs whole rows: everything below folds to the whole-row code)
     const int link = (int)blockIdx.x / nseg, seg = (int)blockIdx.x - link * nseg;
     const bool is_spec = link >= nbands; // a copy (writes no map): link ck of the chain of target band ct
-    const int ck = is_spec ? (link - nbands) % spec : 0, ct = is_spec ? spec + 1 + (link - nbands) / spec : 0;
-    const int band = is_spec ? ct - spec + ck : link; // the rows this wave filters
+    int ck = 0, ct = 0;
+    if (is_spec) { // (the chains of the bands 1 .. spec are shorter: walk them; behind them every chain has spec links)
+        const int c = link - nbands, tri = spec * (spec + 1) / 2;
+        if (c < tri) { ct = 1; while (medb_chain_off(ct + 1, spec) <= c) ct++; ck = c - medb_chain_off(ct, spec); }
+        else { ct = spec + 1 + (c - tri) / spec; ck = (c - tri) % spec; }
+    }
+    const int band = is_spec ? ct - medb_chain_depth(ct, spec) + ck : link; // the rows this wave filters
     const int myslot = (int)blockIdx.x;                          // hand-off row it publishes its last row into
     const bool raw_above = is_spec && ck == 0;                    // first link of a chain: the raw row above as its row above
     // hand-off row this wave reads: the link before it / for a real band the last link of its chain, or the real band above (same segment)
-    const int upslot = (is_spec ? link - 1 : ((spec && band > spec) ? nbands + (band - spec - 1) * spec + spec - 1 : band - 1)) * nseg + seg;
-    // the segment's columns, and the real band at the end of this wave's chain (bands 0 .. spec feed each other: their windows end with band spec's)
+    const int upslot = (is_spec ? link - 1 : (spec ? nbands + medb_chain_off(band, spec) + medb_chain_depth(band, spec) - 1 : band - 1)) * nseg + seg;
+    // the segment's columns, and the real band at the end of this wave's chain
     const int xs = nseg > 1 ? ((int)((long long)W * seg / nseg) & ~15) : 0;
     const int xe = (nseg > 1 && seg + 1 < nseg) ? ((int)((long long)W * (seg + 1) / nseg) & ~15) : W;
     const int chain_first = (is_spec ? ct : band) * MEDB_ROWS;
-    const int chain_lastband = is_spec ? ct : ((spec && band <= spec) ? adc_imin(spec, nbands - 1) : band);
+    const int chain_lastband = is_spec ? ct : band;
     const int chain_ylast = adc_imin((chain_lastband + 1) * MEDB_ROWS, H) - 1;
     const int ts = seg > 0 ? adc_imax(0, xs - warm + 2 * chain_first) : 0; // first level that is filtered (a multiple of 16)
     const int y = band * MEDB_ROWS + tid;
@@ -719,6 +734,8 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     // (segments: not before two blocks in front of the window -- one is taken over without a re-check, one passes raw values through so
     // that the filter finds raw neighbours in its registers -- and, unless the segment ends at the image's right border, to the end of the
     // chain's window: the link below needs this one's last row that far)
+    // (A head start of 32 / 48 / 96 levels per link for the links further up in a chain -- so that a reader never finds a hand-off block
+    // unwritten and polls -- was measured: no difference, profiles/r6_ab_median_segments.txt.)
     const int tb_rows = spec ? adc_imax(0, 2 * yfirst - 2 * MEDB_K) & ~(MEDB_K - 1) : 0;
     const int tb = seg > 0 ? adc_imax(tb_rows, ts - 2 * MEDB_K) : tb_rows;
     const int te = (nseg > 1 && xe < W) ? adc_imin(nsteps, xe + 2 * chain_ylast + 3 * MEDB_K)
@@ -838,7 +855,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
 // before the band's first row becomes active are never consumed and are not waited for.
 #define MEDB_RECHECK(T1)                                                                                                \
     do {                                                                                                                \
-        if (band > 0 && !raw_above && (T1) + MEDB_K > 2 * yfirst - 2 && (T1) <= W + 2 * yfirst) { /* (only while the first row still needs them) */                                                              \
+        if (band > 0 && !raw_above && (T1) + MEDB_K > 2 * yfirst - 2 && (T1) <= W + 2 * yfirst && (seg == 0 || (T1) >= ts - MEDB_K)) { /* (only while the first row still needs them) */ \
             int spins = 0;                                                                                              \
             while (true) {                                                                                              \
                 uint32_t mx = 0u;                                                                                       \
@@ -969,7 +986,7 @@ __global__ __launch_bounds__(256) void k_median_seg_check(const float* __restric
     if (i < W) {
         if (b >= 1) {
             const int c = i, t = c + 2 * (yf - 1);
-            const int up = (spec && b > spec) ? nbands + (b - spec - 1) * spec + spec - 1 : b - 1;
+            const int up = spec ? nbands + medb_chain_off(b, spec) + medb_chain_depth(b, spec) - 1 : b - 1;
             const uint32_t want = reinterpret_cast<const uint32_t*>(out)[(size_t)(yf - 1) * W + c];
             for (int sgm = 0; sgm < nseg; sgm++) {
                 const int xs = nseg > 1 ? ((int)((long long)W * sgm / nseg) & ~15) : 0;
@@ -1045,7 +1062,7 @@ static hipError_t launch_median_banded(adc_handle* h, const float* in, float* ou
     // such a value makes the bands re-read until the bounded spin gives up and adc_wait runs the single-workgroup kernel.)
     if ((in != h->disp_l && in != h->disp_tmp) || (out != h->disp_l && out != h->disp_tmp) || in == out) return hipErrorInvalidValue;
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
-    const int ncopies = spec ? (nbands - 1 - spec) * spec : 0; // a chain of `spec` copies per target band spec + 1 .. nbands - 1
+    const int ncopies = spec ? medb_chain_off(nbands, spec) : 0; // a chain of min(b, spec) copies per target band b = 1 .. nbands - 1
     const int nseg = median_segments(p.W, spec), nlinks = nbands + ncopies;
     if ((size_t)nlinks * nseg + 1 > adc_median_hand_rows(p.H)) return hipErrorInvalidValue;
     // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
@@ -1081,7 +1098,9 @@ hipError_t adc_launch_median(adc_handle* h)
         // speculative bands (ADC_MEDIAN_SPEC=0: chained form; also for a while after a seam of this handle has failed)
         // (ADC_MEDIAN_SPEC = run-in in bands, default 2 = 128 rows, 0 = chained form)
         static const int spec_env = [] { const char* e = getenv("ADC_MEDIAN_SPEC"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 4 ? 4 : v); }();
-        const int spec = (nbands >= spec_env + 2 && h->med_spec_off == 0) ? spec_env : 0;
+        // (round 6: every band has its own chain, and the chains of the bands 1 .. spec are exact copies rooted in band 0 -- images of
+        // 2 .. spec + 1 bands run the speculative form too, with nothing speculative about their rows: 1920 x 192 354 -> ~110 us)
+        const int spec = h->med_spec_off == 0 ? spec_env : 0;
         launch_median_banded(h, h->disp_l, h->disp_tmp, spec);
         float* t = h->disp_l;
         h->disp_l = h->disp_tmp;

@@ -1299,8 +1299,8 @@ long emul_median_spec_bands(const float* raw, float* out, int W, int H, int rows
 }
 
 // Speculative COLUMN SEGMENTS of the banded median (round 6; k_median_banded with nseg > 1).  Every band link is cut into nseg
-// segments [xs, xe) (boundaries multiples of 16); the waves of a chain (the copies of the bands b - depth .. b - 1 and the real band b;
-// bands 0 .. depth chain from the real band 0) that serve segment s all run the SAME window of levels t = x + 2y:
+// segments [xs, xe) (boundaries multiples of 16); the waves of a chain (copies of the bands b - min(b, depth) .. b - 1 and the real band b)
+// that serve segment s all run the SAME window of levels t = x + 2y:
 //     ts = xs - warm + 2 * (first row of the chain's real band)   (0 for segment 0: the true left border)
 //     te = xe + 2 * (last row of the chain's real band) + 48       (the link's own last row when xe == W: the true right border)
 // below ts a lane passes the raw value through (the speculation: unfiltered instead of filtered, as for the raw row above a chain),
@@ -1345,36 +1345,27 @@ long emul_median_spec_segments(const float* raw, float* out, int W, int H, int r
     long fails = 0;
     bool nan_used = false;
     std::vector<float> seam((size_t)nb * nseg * rows, 0.f), consumed((size_t)nb * nseg * W, 0.f); // per real (band, segment): seam column, hand-off row consumed
-    std::vector<std::vector<float>> real_vals((size_t)(depth + 1) * nseg); // full rows of the real links of bands 0 .. depth (they feed each other)
-    std::vector<float> a(( size_t)rows * W), b2((size_t)rows * W);
+    std::vector<float> a((size_t)rows * W), b2((size_t)rows * W);
     for (int b = 0; b < nb; b++) {
         const int y0 = b * rows, y1 = std::min(H, y0 + rows);
         for (int s = 0; s < nseg; s++) {
             const int xs = (int)((long)W * s / nseg) & ~15, xe = s + 1 == nseg ? W : ((int)((long)W * (s + 1) / nseg) & ~15);
             std::vector<float> up; // hand-off row the real link consumes
-            const int tgt_first = b <= depth ? 0 : y0; // (bands 0 .. depth: one chain rooted in band 0 -- every link of it has its own window, see below)
-            (void)tgt_first;
-            auto window = [&](int chain_y0, int chain_ylast, int link_ylast, int* ts, int* te) {
-                *ts = s == 0 ? 0 : std::max(0, xs - warm + 2 * chain_y0);
-                *te = xe == W ? W + 2 * link_ylast + 48 : xe + 2 * chain_ylast + 48;
+            // the window of the chain of band b: every link runs it (its own last row decides when xe == W: the true right border)
+            auto window = [&](int link_ylast, int* ts, int* te) {
+                *ts = s == 0 ? 0 : std::max(0, xs - warm + 2 * y0);
+                *te = xe == W ? W + 2 * link_ylast + 48 : xe + 2 * (y1 - 1) + 48;
             };
             int ts, te;
-            if (b > depth) {
-                for (int j = 0; j < depth; j++) { // copy of band b - depth + j
-                    const int c0 = (b - depth + j) * rows, c1 = c0 + rows;
-                    window(y0, y1 - 1, c1 - 1, &ts, &te);
-                    std::vector<float> prev(up);
-                    emul_median_link(raw, j == 0 ? raw + (size_t)(c0 - 1) * W : prev.data(), a.data(), W, H, c0, c1, ts, te, &nan_used);
-                    up.assign(a.begin() + (size_t)(rows - 1) * W, a.begin() + (size_t)rows * W);
-                }
-            } else if (b >= 1) {
-                const std::vector<float>& rv = real_vals[(size_t)(b - 1) * nseg + s];
-                up.assign(rv.end() - W, rv.end());
+            const int dpt = std::min(b, depth); // band b >= 1: a private chain of copies of the bands b - dpt .. b - 1 (a copy of band 0 has no row above)
+            for (int j = 0; j < dpt; j++) {
+                const int c0 = (b - dpt + j) * rows, c1 = c0 + rows;
+                window(c1 - 1, &ts, &te);
+                std::vector<float> prev(up);
+                emul_median_link(raw, j == 0 ? (c0 > 0 ? raw + (size_t)(c0 - 1) * W : nullptr) : prev.data(), a.data(), W, H, c0, c1, ts, te, &nan_used);
+                up.assign(a.begin() + (size_t)(rows - 1) * W, a.begin() + (size_t)rows * W);
             }
-            // the real link: bands 0 .. depth run to the end of band `depth`'s window (their hand-off feeds the next real band)
-            const int last_fed = std::min(depth, nb - 1);
-            const int chain_ylast = b <= depth ? std::min(H, (last_fed + 1) * rows) - 1 : y1 - 1;
-            window(y0, chain_ylast, y1 - 1, &ts, &te);
+            window(y1 - 1, &ts, &te);
             b2.assign((size_t)rows * W, 0.f);
             emul_median_link(raw, b >= 1 ? up.data() : nullptr, b2.data(), W, H, y0, y1, ts, te, &nan_used);
             for (int y = y0; y < y1; y++)
@@ -1385,7 +1376,6 @@ long emul_median_spec_segments(const float* raw, float* out, int W, int H, int r
                 }
             if (s > 0) for (int y = y0; y < y1; y++) seam[((size_t)b * nseg + s) * rows + (y - y0)] = b2[(size_t)(y - y0) * W + xs - 1];
             if (b >= 1) std::copy(up.begin(), up.end(), consumed.begin() + ((size_t)b * nseg + s) * W);
-            if (b <= depth) real_vals[(size_t)b * nseg + s].assign(b2.begin(), b2.begin() + (size_t)(y1 - y0) * W);
         }
     }
     for (int b = 0; b < nb; b++) {

@@ -125,3 +125,43 @@ def test_checker_catches_a_weakened_wait_and_a_slot_copy(device_asm, tmp_path):
     open(copy, "w").write(text.replace(m.group(1), m.group(1) + "\tv_mov_b64_e32 v[250:251], %s\n" % m.group(2), 1))
     res = cal.check_file(copy)
     assert any(any("compiler instruction" in w for w, _ in r["bad"]) for r in res.values())
+
+
+def test_checker_follows_a_boolean_and_its_copy_through_a_branch():
+    """Round 6 (k_median_banded, one-column form): the compiler tests `done` once (s_cselect_b64 -> s_and_b64 vcc, exec -> branch
+    around the take-over and its wait) and re-tests a COPY of it in the block the exit path shares with the back edge.  The checker
+    follows the boolean and its copies through the first branch, so the path `done -> no wait -> back edge` does not exist for it;
+    a copy that is overwritten in between, or a take-over without its wait, must still be reported."""
+    safe = """
+\t;;#ASMSTART
+\tglobal_load_dword v5, v[0:1], off
+\t;;#ASMEND
+.LBB0_1:
+\ts_cmp_ge_i32 s4, s5
+\ts_cselect_b64 s[2:3], -1, 0
+\ts_mov_b64 s[18:19], s[2:3]
+\ts_and_b64 vcc, exec, s[2:3]
+\ts_cbranch_vccnz .LBB0_3
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0)
+\tv_mov_b32 v9, v5
+\t;;#ASMEND
+.LBB0_3:
+\ts_andn2_b64 vcc, exec, s[18:19]
+\ts_cbranch_vccz .LBB0_9
+\tv_mov_b32_e32 v5, v1
+\tv_add_u32_e32 v0, v0, v5
+\t;;#ASMSTART
+\tglobal_load_dword v5, v[0:1], off
+\t;;#ASMEND
+\ts_add_i32 s4, s4, 1
+\ts_branch .LBB0_1
+.LBB0_9:
+\ts_endpgm
+""".split("\n")
+    assert cal.analyse(safe)["bad"] == []
+    clobbered = list(safe)
+    clobbered.insert(clobbered.index(".LBB0_3:") + 1, "\ts_mov_b64 s[18:19], s[6:7]")  # the copy no longer holds `done`: the back edge is reachable without the wait
+    assert any("compiler instruction" in w for w, _ in cal.analyse(clobbered)["bad"])
+    no_wait = [ln for ln in safe if "s_waitcnt" not in ln]
+    assert cal.analyse(no_wait)["bad"]
