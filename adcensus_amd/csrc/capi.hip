@@ -164,7 +164,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMemset(h->vote_list, 0xFF, adc_irv_list_entries(p.W, p.H, p.D, h->irv_grid) * 16)); // every slot = IRV_LIST_END
     HIP_OK(hipMalloc(&h->vote_evals_arr, adc_irv_waves(h->irv_grid) * sizeof(int32_t)));
     HIP_OK(hipMemset(h->vote_evals_arr, 0, adc_irv_waves(h->irv_grid) * sizeof(int32_t)));
-    HIP_OK(hipMalloc(&h->interp_list, P * 4));
+    HIP_OK(hipMalloc(&h->interp_list, 2 * P * 4)); // both target lists of the interpolation, P entries each
     HIP_OK(hipMalloc(&h->interp_counters, 64 * sizeof(int32_t)));
     {
         const int da = p.dmax < 0 ? -p.dmax : p.dmax, di = p.dmin < 0 ? -p.dmin : p.dmin;

@@ -129,6 +129,47 @@ __global__ __launch_bounds__(256) void k_interp_list(const uint8_t* __restrict__
     }
 }
 
+// Both target lists in ONE pass (round 6): list A = the invalid pixels of the mismatch list, list B = those of the occlusion list.  The
+// first list's fills cannot change the second list's targets (a fill only touches list-A pixels), so both are known up front.
+__global__ __launch_bounds__(256) void k_interp_list2(const uint8_t* __restrict__ label, const float* __restrict__ disp,
+                                                      int32_t* __restrict__ list_a, int32_t* __restrict__ list_b, int32_t* __restrict__ counters, int P)
+{
+    __shared__ int wcnt[2][ITP_LIST_PPT][4];
+    __shared__ int base[2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long m[2][ITP_LIST_PPT];
+#pragma unroll
+    for (int k = 0; k < ITP_LIST_PPT; k++) {
+        const int p = (blockIdx.x * ITP_LIST_PPT + k) * 256 + threadIdx.x;
+        const bool inv = p < P && disp[p] == ADC_INVALID_FLOAT;
+        const int lab = p < P ? (int)label[p] : 0;
+        m[0][k] = __ballot(inv && lab == ADC_LABEL_MISMATCH);
+        m[1][k] = __ballot(inv && lab == ADC_LABEL_OCCLUSION);
+        if (lane == 0) { wcnt[0][k][wave] = __popcll(m[0][k]); wcnt[1][k][wave] = __popcll(m[1][k]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < ITP_LIST_PPT; k++) tot += wcnt[threadIdx.x][k][0] + wcnt[threadIdx.x][k][1] + wcnt[threadIdx.x][k][2] + wcnt[threadIdx.x][k][3];
+        base[threadIdx.x] = tot ? atomicAdd(&counters[threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        int32_t* list = l == 0 ? list_a : list_b;
+        int off = base[l];
+#pragma unroll
+        for (int k = 0; k < ITP_LIST_PPT; k++) {
+            const int p = (blockIdx.x * ITP_LIST_PPT + k) * 256 + threadIdx.x;
+            int mine = off;
+            for (int w = 0; w < wave; w++) mine += wcnt[l][k][w];
+            if ((m[l][k] >> lane) & 1ull) list[mine + __popcll(m[l][k] & ((1ull << lane) - 1ull))] = p;
+            off += wcnt[l][k][0] + wcnt[l][k][1] + wcnt[l][k][2] + wcnt[l][k][3];
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- K9 proper interpolation
 // The target pixels of the list are compacted first (k_interp_list), then 16 lanes
 // work on one pixel, one ray each (4 pixels per wave); the 16 first-hits are combined with a 16-lane
@@ -223,9 +264,20 @@ __device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_di
 // invalid (or outside the image, where the ray ends anyway) are passed over.
 #define ITP_CELL ADC_ITP_CELL
 // cell / row / distance maps (one byte per cell each), then -- 16-byte aligned -- the padded code map of the walk
-static size_t itp_code_offset(int W, int H) { return (3 * (size_t)((W + ITP_CELL - 1) / ITP_CELL) * ((H + ITP_CELL - 1) / ITP_CELL) + 15) & ~(size_t)15; }
-size_t adc_itp_cell_bytes(int W, int H, int ms) { return itp_code_offset(W, H) + (size_t)adc_itp_code_pitch(W, ms) * adc_itp_code_rows(H, ms) + 64; }
-__global__ __launch_bounds__(256) void k_itp_cells(const float* __restrict__ disp, uint8_t* __restrict__ cell, int W, int H, int cw, int ch)
+// (per pass: cell / row / distance maps; behind both sets -- 16-byte aligned -- the two padded code maps of the walk)
+static size_t itp_cell_stride(int W, int H) { return 3 * (size_t)((W + ITP_CELL - 1) / ITP_CELL) * ((H + ITP_CELL - 1) / ITP_CELL); }
+static size_t itp_code_offset(int W, int H) { return (2 * itp_cell_stride(W, H) + 15) & ~(size_t)15; }
+static size_t itp_code_stride(int W, int H, int ms) { return ((size_t)adc_itp_code_pitch(W, ms) * adc_itp_code_rows(H, ms) + 64 + 15) & ~(size_t)15; }
+size_t adc_itp_cell_bytes(int W, int H, int ms) { return itp_code_offset(W, H) + 2 * itp_code_stride(W, H, ms) + 64; }
+// Validity of both interpolation passes in one set of launches (round 6): the second pass sees the first pass's fills, and EVERY target
+// of the first pass is filled (a pixel no ray finds a value for gets 0.0f: multistep_refiner.cpp:246,270-272) -- so the second pass's
+// validity = valid pixels + invalid pixels of the mismatch list, known before the first pass runs.  Map 1 of every kernel (blockIdx.y)
+// is the second pass's.
+__device__ __forceinline__ bool itp_valid(const float* __restrict__ disp, const uint8_t* __restrict__ label, size_t p, int pass2)
+{
+    return disp[p] != ADC_INVALID_FLOAT || (pass2 && label[p] == ADC_LABEL_MISMATCH);
+}
+__global__ __launch_bounds__(256) void k_itp_cells(const float* __restrict__ disp, const uint8_t* __restrict__ label, uint8_t* __restrict__ cell, int W, int H, int cw, int ch, size_t map_stride)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cw * ch) return;
@@ -236,27 +288,30 @@ __global__ __launch_bounds__(256) void k_itp_cells(const float* __restrict__ dis
 #pragma unroll
         for (int q = 0; q < ITP_CELL; q++) {
             const int y = cy * ITP_CELL + r, x = cx * ITP_CELL + q;
-            if (y < H && x < W) any = any || disp[(size_t)y * W + x] != ADC_INVALID_FLOAT;
+            if (y < H && x < W) any = any || itp_valid(disp, label, (size_t)y * W + x, (int)blockIdx.y);
         }
-    cell[c] = any ? 1 : 0;
+    cell[blockIdx.y * map_stride + c] = any ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_itp_rowdist(const uint8_t* __restrict__ cell, uint8_t* __restrict__ rowd, int cw, int ch)
+__global__ __launch_bounds__(256) void k_itp_rowdist(const uint8_t* __restrict__ cell, uint8_t* __restrict__ rowd, int cw, int ch, size_t map_stride)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cw * ch) return;
-    rowd[c] = (uint8_t)adc_itp_rowdist(cell, cw, c % cw, c / cw);
+    rowd[blockIdx.y * map_stride + c] = (uint8_t)adc_itp_rowdist(cell + blockIdx.y * map_stride, cw, c % cw, c / cw);
 }
-__global__ __launch_bounds__(256) void k_itp_coldist(const uint8_t* __restrict__ rowd, uint8_t* __restrict__ cdist, int cw, int ch)
+__global__ __launch_bounds__(256) void k_itp_coldist(const uint8_t* __restrict__ rowd, uint8_t* __restrict__ cdist, int cw, int ch, size_t map_stride)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cw * ch) return;
-    cdist[c] = (uint8_t)adc_itp_coldist(rowd, cw, ch, c % cw, c / cw);
+    cdist[blockIdx.y * map_stride + c] = (uint8_t)adc_itp_coldist(rowd + blockIdx.y * map_stride, cw, ch, c % cw, c / cw);
 }
+
 // The code map of the walk (adc_device_fn.h): four pixels of an image row per thread, one 32-bit store; the padding around the image
 // (ADC_ITP_OUTSIDE) is written once, when the object is created.  `code` points at the map's row 0, `gx` = columns of padding on the left.
-__global__ __launch_bounds__(256) void k_itp_code(const float* __restrict__ disp, const uint8_t* __restrict__ cdist, uint8_t* __restrict__ code,
-                                                  int W, int H, int cw, int pitch, int gx)
+__global__ __launch_bounds__(256) void k_itp_code(const float* __restrict__ disp, const uint8_t* __restrict__ label, const uint8_t* __restrict__ cdist,
+                                                  uint8_t* __restrict__ code, int W, int H, int cw, int pitch, int gx, size_t cell_stride, size_t code_stride)
 {
+    cdist += blockIdx.y * cell_stride;
+    code += blockIdx.y * code_stride;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int q4 = (W + 3) >> 2; // threads per row; thread (y, k) covers the padded columns (gx & ~3) + 4k .. + 3
     if (i >= q4 * H + H) return;
@@ -267,7 +322,7 @@ __global__ __launch_bounds__(256) void k_itp_code(const float* __restrict__ disp
     for (int b = 0; b < 4; b++) {
         const int x = c0 + b - gx;
         uint32_t c = ADC_ITP_OUTSIDE;
-        if (x >= 0 && x < W) c = disp[(size_t)y * W + x] != ADC_INVALID_FLOAT ? (uint32_t)ADC_ITP_VALID : (uint32_t)adc_itp_skip(cdist[(y / ITP_CELL) * cw + (x / ITP_CELL)]);
+        if (x >= 0 && x < W) c = itp_valid(disp, label, (size_t)y * W + x, (int)blockIdx.y) ? (uint32_t)ADC_ITP_VALID : (uint32_t)adc_itp_skip(cdist[(y / ITP_CELL) * cw + (x / ITP_CELL)]);
         v |= c << (8 * b);
     }
     *reinterpret_cast<uint32_t*>(code + (size_t)y * pitch + c0) = v; // (pitch and c0 are multiples of 4; c0 + 3 <= gx + W + 6 < pitch: adc_itp_code_pitch)
@@ -320,7 +375,7 @@ __device__ __forceinline__ void itp_trip(const int32_t* __restrict__ lt, const u
 static_assert(ITP_NS1 <= ADC_ITP_NS && ITP_NS2 <= ADC_ITP_NS, "trip lengths");
 template <bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
-                                                         const float* __restrict__ din, float* __restrict__ dout,
+                                                         float* dmap /* read at the hits, written at the targets: IN PLACE (see the launch) */,
                                                          const uint32_t* __restrict__ bgr, const int32_t* __restrict__ lin,
                                                          int W, int which, int max_search, const uint8_t* __restrict__ code, int pitch, int gx, float rcp_pitch)
 {
@@ -359,7 +414,7 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
         const int r = a - dy * pitch;
         dy += (r >= pitch ? 1 : 0) - (r < 0 ? 1 : 0);
         const int hitq = found ? p + dy * W + (ho - dy * pitch) : p;
-        const float hv = din[hitq];
+        const float hv = dmap[hitq];
         const float hit = found ? hv : ADC_INVALID_FLOAT; // first valid disparity along this ray
         // combine the 16 rays of this pixel (lanes with equal lane&3)
         float best;
@@ -386,7 +441,7 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
             any = val != ADC_INVALID_FLOAT;
             best = val;
         }
-        if (live && s == 0) dout[e] = any ? best : 0.0f; // fill value of list entry e; no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
+        if (live && s == 0) dmap[p] = any ? best : 0.0f; // the fill, in place; no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
     }
 }
 
@@ -404,41 +459,48 @@ hipError_t adc_launch_interpolation(adc_handle* h)
     const int P = p.W * p.H;
     const int dmaxa = p.dmax < 0 ? -p.dmax : p.dmax, dmina = p.dmin < 0 ? -p.dmin : p.dmin;
     const int max_search = dmaxa > dmina ? dmaxa : dmina; // multistep_refiner.cpp:236
-    for (int k = 0; k < 2; k++) {
-        const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
-        {
-            // The reference computes the fill values of a whole list from the UNCHANGED map and writes them back afterwards
-            // (fill_disps, multistep_refiner.cpp:246-303): same structure here -- fill[e] per list entry (disp_tmp serves
-            // as the array), then a scatter into the map in place.  No copy of the map, no buffer swap.
-            hipError_t e;
-            if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k_interp_list, dim3((P + 256 * ITP_LIST_PPT - 1) / (256 * ITP_LIST_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l,
-                               h->interp_list, h->interp_counters, which, P);
-            if (h->ray_tab && max_search == h->ray_tab_rows && max_search == h->itp_ms && (size_t)h->itp_ms * (size_t)h->itp_pitch < ((size_t)1 << 24)) { // (linear offsets exact in float: see the kernel)
-                if (k == 0 && !h->bgrx_valid) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
-                const int cw = (p.W + ITP_CELL - 1) / ITP_CELL, ch = (p.H + ITP_CELL - 1) / ITP_CELL, nc = cw * ch;
-                uint8_t* code = h->itp_cells + itp_code_offset(p.W, p.H);
-                {
-                    hipLaunchKernelGGL(k_itp_cells, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->disp_l, h->itp_cells, p.W, p.H, cw, ch);
-                    hipLaunchKernelGGL(k_itp_rowdist, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->itp_cells, h->itp_cells + nc, cw, ch);
-                    hipLaunchKernelGGL(k_itp_coldist, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->itp_cells + nc, h->itp_cells + 2 * nc, cw, ch);
-                    hipLaunchKernelGGL(k_itp_code, dim3((((p.W + 3) / 4 + 1) * p.H + 255) / 256), dim3(256), 0, h->stream, h->disp_l, h->itp_cells + 2 * (size_t)nc,
-                                       code, p.W, p.H, cw, h->itp_pitch, h->itp_ms);
-                }
-                const size_t lin_bytes = (size_t)(max_search + ADC_ITP_LPAD) * 16 * sizeof(int32_t);
-                const bool tab_lds = lin_bytes <= 40 * 1024; // (ranges up to 576; larger ones read the table from global memory)
+    if (h->ray_tab && max_search == h->ray_tab_rows && max_search == h->itp_ms && (size_t)h->itp_ms * (size_t)h->itp_pitch < ((size_t)1 << 24)) { // (linear offsets exact in float: see the kernel)
+        // Round 6: ONE list pass, ONE set of map launches for both passes, fills written IN PLACE.  The reference computes the fill
+        // values of a whole list from the UNCHANGED map and writes them back afterwards (fill_disps, multistep_refiner.cpp:246-303); a
+        // walk here never reads the map at a pixel its own pass writes: it tests the CODE map (a snapshot) and fetches map values only at
+        // hits, which are valid pixels of that snapshot -- targets are invalid in it.  The second pass's snapshot counts the first
+        // pass's targets as valid (all of them get filled), and its walk runs behind the first one: it reads their fills.
+        hipError_t e;
+        if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_interp_list2, dim3((P + 256 * ITP_LIST_PPT - 1) / (256 * ITP_LIST_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l,
+                           h->interp_list, h->interp_list + P, h->interp_counters, P);
+        if (!h->bgrx_valid) hipLaunchKernelGGL(k_pack_bgr, dim3((P + 255) / 256), dim3(256), 0, h->stream, h->img_l, h->bgrx_l, P);
+        const int cw = (p.W + ITP_CELL - 1) / ITP_CELL, ch = (p.H + ITP_CELL - 1) / ITP_CELL, nc = cw * ch;
+        const size_t cs = itp_cell_stride(p.W, p.H), ks = itp_code_stride(p.W, p.H, h->itp_ms);
+        uint8_t* code = h->itp_cells + itp_code_offset(p.W, p.H);
+        hipLaunchKernelGGL(k_itp_cells, dim3((nc + 255) / 256, 2), dim3(256), 0, h->stream, h->disp_l, h->label, h->itp_cells, p.W, p.H, cw, ch, cs);
+        hipLaunchKernelGGL(k_itp_rowdist, dim3((nc + 255) / 256, 2), dim3(256), 0, h->stream, h->itp_cells, h->itp_cells + nc, cw, ch, cs);
+        hipLaunchKernelGGL(k_itp_coldist, dim3((nc + 255) / 256, 2), dim3(256), 0, h->stream, h->itp_cells + nc, h->itp_cells + 2 * nc, cw, ch, cs);
+        hipLaunchKernelGGL(k_itp_code, dim3((((p.W + 3) / 4 + 1) * p.H + 255) / 256, 2), dim3(256), 0, h->stream, h->disp_l, h->label, h->itp_cells + 2 * (size_t)nc,
+                           code, p.W, p.H, cw, h->itp_pitch, h->itp_ms, cs, ks);
+        const size_t lin_bytes = (size_t)(max_search + ADC_ITP_LPAD) * 16 * sizeof(int32_t);
+        const bool tab_lds = lin_bytes <= 40 * 1024; // (ranges up to 576; larger ones read the table from global memory)
+        for (int k = 0; k < 2; k++) {
+            const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
 #define INTERP_TAB(L_)                                                                                                 \
-    hipLaunchKernelGGL((k_interpolate_tab<L_>), dim3(2048), dim3(256), L_ ? lin_bytes : 0, h->stream, h->interp_list, h->interp_counters, \
-                       h->disp_l, h->disp_tmp, h->bgrx_l, h->ray_lin, p.W, which, max_search, code, h->itp_pitch, h->itp_ms, 1.0f / (float)h->itp_pitch)
-                if (tab_lds) INTERP_TAB(true);
-                else INTERP_TAB(false);
+    hipLaunchKernelGGL((k_interpolate_tab<L_>), dim3(2048), dim3(256), L_ ? lin_bytes : 0, h->stream, h->interp_list + (size_t)k * P, h->interp_counters + k, \
+                       h->disp_l, h->bgrx_l, h->ray_lin, p.W, which, max_search, code + k * ks, h->itp_pitch, h->itp_ms, 1.0f / (float)h->itp_pitch)
+            if (tab_lds) INTERP_TAB(true);
+            else INTERP_TAB(false);
 #undef INTERP_TAB
-            }
-            else
-                hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_l,
-                                   h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
-            hipLaunchKernelGGL(k_interp_scatter, dim3(1024), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_tmp, h->disp_l);
         }
+        return hipGetLastError();
+    }
+    for (int k = 0; k < 2; k++) { // (a ray step too close to a rounding tie for the integer tables: the f64 walk, list by list)
+        const int which = k == 0 ? ADC_LABEL_MISMATCH : ADC_LABEL_OCCLUSION;
+        hipError_t e;
+        if ((e = hipMemsetAsync(h->interp_counters, 0, 8 * sizeof(int32_t), h->stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_interp_list, dim3((P + 256 * ITP_LIST_PPT - 1) / (256 * ITP_LIST_PPT)), dim3(256), 0, h->stream, h->label, h->disp_l,
+                           h->interp_list, h->interp_counters, which, P);
+        // fill[e] per list entry (disp_tmp serves as the array), then a scatter into the map in place: no copy of the map, no buffer swap
+        hipLaunchKernelGGL(k_interpolate_rays, dim3(2048), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_l,
+                           h->disp_tmp, h->img_l, h->ray_sincos, p.W, p.H, which, max_search);
+        hipLaunchKernelGGL(k_interp_scatter, dim3(1024), dim3(256), 0, h->stream, h->interp_list, h->interp_counters, h->disp_tmp, h->disp_l);
     }
     return hipGetLastError();
 }
