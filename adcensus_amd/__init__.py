@@ -301,7 +301,8 @@ class ADCensusStereo:
         return lib().adc_wait(self._h) == 0
 
     def set_profiling(self, on=True):
-        lib().adc_set_profiling(self._h, 1 if on else 0)
+        """False / 0: off; True / 1: stage timers + aggregation launch marks; 2: aggregation launch marks only (adcensus_c_api.h)"""
+        lib().adc_set_profiling(self._h, int(on) if not isinstance(on, bool) else (1 if on else 0))
 
     def set_verbose(self, on=True):
         lib().adc_set_verbose(self._h, 1 if on else 0)

@@ -388,7 +388,7 @@ static bool heavy_exclusive()
 // restarts at the first aggregation pass -- possible whenever that pass computes the matching cost itself (no input volume).
 static hipError_t run_heavy(adc_handle* h, bool from_aggregation = false)
 {
-    const bool prof = h->profiling != 0;
+    const bool prof = h->profiling == 1; // (level 2: only the marks around the aggregation launches, k_aggregate.hip)
 #define MARK(i, s) do { if (prof) HIP_OK(hipEventRecord(h->ev[i], s)); } while (0)
     if (h->heavy != h->stream) {
         HIP_OK(hipEventRecord(h->ev_in, h->stream));
@@ -470,7 +470,7 @@ static hipError_t run_pipeline(adc_handle* h, bool from_aggregation = false)
         HIP_OK(run_heavy(h, from_aggregation));
     }
     HIP_OK(run_refine(h));                       // MultiStepRefine, :117 (object stream)
-    if (h->profiling) HIP_OK(hipEventRecord(h->ev[6], h->stream));
+    if (h->profiling == 1) HIP_OK(hipEventRecord(h->ev[6], h->stream));
     h->timings_pending = h->profiling != 0;
     return hipSuccess;
 }
@@ -481,7 +481,7 @@ static void collect_timings(adc_handle* h)
     h->timings_pending = false;
     for (int i = 0; i < ADC_STAGE_COUNT; i++) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = -1.f;
+        if (h->profiling != 1 || hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = -1.f; // (level 2: no stage marks were recorded)
         h->stage_ms[i] = ms;
     }
     float tot = 0.f;

@@ -243,10 +243,9 @@ __global__ __launch_bounds__(256) void k_interpolate_rays(const int32_t* __restr
 // packed (dy << 16 | dx & 0xffff): one 64-byte segment per step for the 16 rays of a pixel.  The walk issues
 // 4 steps' loads at once (the loads past the hit are clamped in-image and ignored).
 __global__ void k_pack_bgr(const uint8_t* __restrict__ img, uint32_t* __restrict__ out, int P); // k_arms.hip
-__device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_dist_l1 on packed B | G<<8 | R<<16
+__device__ __forceinline__ int packed_l1(uint32_t a, uint32_t b) // adc_color_dist_l1 on packed B | G<<8 | R<<16 (top byte 0 in both): ONE v_sad_u8
 {
-    return adc_iabs((int)(a & 255u) - (int)(b & 255u)) + adc_iabs((int)((a >> 8) & 255u) - (int)((b >> 8) & 255u)) +
-           adc_iabs((int)((a >> 16) & 255u) - (int)((b >> 16) & 255u));
+    return (int)__builtin_amdgcn_sad_u8(a, b, 0u);
 }
 
 // 16 lanes per target pixel (one ray each), 4 list-consecutive (mostly x-adjacent) pixels per wave.  Lane layout
@@ -372,7 +371,10 @@ __device__ __forceinline__ void itp_trip(const int32_t* __restrict__ lt, const u
 #ifndef ITP_NS2
 #define ITP_NS2 4 // ... and of the following ones (<= ADC_ITP_NS: the table's padding)
 #endif
-static_assert(ITP_NS1 <= ADC_ITP_NS && ITP_NS2 <= ADC_ITP_NS, "trip lengths");
+#ifndef ITP_NS3
+#define ITP_NS3 0 // > 0: steps of the trips from the third one on (2 / 4 / 6 and 2 / 4 / 8 measured: 0.538 - 0.547 ms against 0.540 - 0.542: no difference)
+#endif
+static_assert(ITP_NS1 <= ADC_ITP_NS && ITP_NS2 <= ADC_ITP_NS && ITP_NS3 <= ADC_ITP_NS, "trip lengths");
 template <bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
                                                          float* dmap /* read at the hits, written at the targets: IN PLACE (see the launch) */,
@@ -405,7 +407,12 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
         // pixel is invalid and inside the image)
         int m = 1 + (int)code[pb];
         itp_trip<ITP_NS1>(lt, code, pb, s, max_search, walking, m, ho);
+#if ITP_NS3
+        if (__any(walking && m < max_search)) itp_trip<ITP_NS2>(lt, code, pb, s, max_search, walking, m, ho);
+        while (__any(walking && m < max_search)) itp_trip<ITP_NS3>(lt, code, pb, s, max_search, walking, m, ho); // (few rays are left: long trips)
+#else
         while (__any(walking && m < max_search)) itp_trip<ITP_NS2>(lt, code, pb, s, max_search, walking, m, ho);
+#endif
         // the hit: ho = dy * pitch + dx with 0 <= dy and |dx| < gx <= pitch / 2, so dy = (ho + gx) / pitch -- by a float reciprocal
         // and one correction step (ho + gx < 2^24: exact in float; the quotient is off by at most one) -- and its value from the map
         const bool found = ho != ITP_NO_HIT;

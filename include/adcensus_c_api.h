@@ -137,7 +137,10 @@ int adc_farm_wait(adc_farm* f, uint64_t ticket);
 int64_t adc_farm_drain(adc_farm* f);
 
 /* Stage timers (ms, HIP events on the handle's stream) of the most recent completed match.
- * Enable with adc_set_profiling(h,1).  Order: see adc_stage_name(). */
+ * Enable with adc_set_profiling(h,1).  Order: see adc_stage_name().
+ * Level 2 records only the marks around the aggregation launches (adc_aggregate_info: the live duration of the roofline kernel) and
+ * no stage marks -- every event record on the stream costs ~6 us of its time, ten of them 1.3 % of a 1080p Match (bench.py times its
+ * region at level 2 and measures the stage times on extra Matches behind it). */
 enum {
     ADC_STAGE_COST = 0,       /* gray + census + AD-census cost volume   (cost_computor.cpp)      */
     ADC_STAGE_ARMS,           /* cross arms + support counts             (cross_aggregator.cpp:76-86,271-325) */
