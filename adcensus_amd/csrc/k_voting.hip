@@ -767,6 +767,8 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     // a short chain (an image with next to no listed pixel: 6 kernels) gets 4 surplus kernels, a long one 40 %
     // (measured on 24 distinct structured pairs: with a quarter of margin 1-2 of ~28 Matches still overran -- the chains of a stream
     // vary 48-75 kernels --, and a continuation costs ~1.5 ms where 6 more surplus kernels cost 0.03 ms: 40 %)
-    h->irv_budget = fixed > 0 ? fixed : adc_imin(1 << 16, longest + adc_imax(2 * longest / 5, 2) + 2);
+    // (an EMPTY work list -- BEGIN, then DONE: no round whose count could vary -- needs no margin beyond the floor of 4 kernels:
+    // two surplus kernels less per Match of a noise-like stream, 10 us)
+    h->irv_budget = fixed > 0 ? fixed : (longest <= 2 ? 4 : adc_imin(1 << 16, longest + adc_imax(2 * longest / 5, 2) + 2));
     return hipSuccess;
 }
