@@ -375,12 +375,55 @@ __device__ __forceinline__ void itp_trip(const int32_t* __restrict__ lt, const u
 #define ITP_NS3 0 // > 0: steps of the trips from the third one on (2 / 4 / 6 and 2 / 4 / 8 measured: 0.538 - 0.547 ms against 0.540 - 0.542: no difference)
 #endif
 static_assert(ITP_NS1 <= ADC_ITP_NS && ITP_NS2 <= ADC_ITP_NS && ITP_NS3 <= ADC_ITP_NS, "trip lengths");
+// K targets per lane and iteration (ITP_K).  After the code map the walk waits for memory three quarters of its time (SQ counters:
+// wait_any 0.73, vector ALU 0.10 busy) at the occupancy limit of 8 waves per SIMD, so K = 2 .. 4 independent targets per lane were
+// tried to overlap their round trips: SLOWER (refine stage of the noise pair 0.531 / 0.557 / 0.582 / 0.657 ms for K = 1 / 2 / 3 / 4,
+// profiles/r6_ab_k9_code_map.txt) -- the trips of a wave then run until the longest of K x 64 rays has ended, and what the walk waits
+// for is the address unit, not latency.  K = 1.
+#ifndef ITP_K
+#define ITP_K 1
+#endif
+template <int N, int K>
+__device__ __forceinline__ void itp_trips(const int32_t* __restrict__ lt, const uint8_t* __restrict__ code, const uint32_t (&pb)[K], int s, int max_search,
+                                          bool (&walking)[K], int (&m)[K], int (&ho)[K])
+{
+    uint32_t c[K][N];
+    int o[K][N];
+    bool w0[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        w0[k] = walking[k] && m[k] < max_search;
+#pragma unroll
+        for (int j = 0; j < N; j++) { c[k][j] = ADC_ITP_OUTSIDE; o[k][j] = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        if (w0[k]) { // (rays that have ended take no part in the gathers)
+            const int32_t* row = lt + (m[k] * 16 + s);
+#pragma unroll
+            for (int j = 0; j < N; j++) { o[k][j] = row[j * 16]; c[k][j] = code[pb[k] + (uint32_t)o[k][j]]; }
+        }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        bool act = w0[k];
+        const int left = max_search - m[k]; // steps left in the search range (> 0 for a walking ray)
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const bool end = c[k][j] >= ADC_ITP_OUTSIDE || j >= left; // a hit, the image border or the end of the range
+            ho[k] = (act && end && c[k][j] == ADC_ITP_VALID && j < left) ? o[k][j] : ho[k]; // (the hit's linear offset in the padded map)
+            act = act && !end;
+        }
+        walking[k] = act;
+        m[k] += act ? N + (int)c[k][N - 1] : 0; // (the code of the trip's last position: an invalid pixel inside the image = its skip)
+    }
+}
 template <bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restrict__ list, const int32_t* __restrict__ counters,
                                                          float* dmap /* read at the hits, written at the targets: IN PLACE (see the launch) */,
                                                          const uint32_t* __restrict__ bgr, const int32_t* __restrict__ lin,
                                                          int W, int which, int max_search, const uint8_t* __restrict__ code, int pitch, int gx, float rcp_pitch)
 {
+    constexpr int K = ITP_K;
     extern __shared__ int32_t lin_lds[]; // [max_search + ADC_ITP_LPAD][16]
     if (TAB_LDS) {
         for (int i = threadIdx.x; i < (max_search + ADC_ITP_LPAD) * 16; i += 256) lin_lds[i] = lin[i];
@@ -393,62 +436,83 @@ __global__ __launch_bounds__(256) void k_interpolate_tab(const int32_t* __restri
     const int slot = ((blockIdx.x * 256 + threadIdx.x) >> 6) * 4 + (lane & 3); // pixel slot
     const int nslot = (gridDim.x * 256) >> 4;
     const bool mismatch = which == ADC_LABEL_MISMATCH;
-    const int nr = (n + 3) & ~3; // whole waves iterate together (4 pixels per wave)
-    int pn = slot < n ? list[slot] : 0;
-    for (int e = slot; e < nr; e += nslot) {
-        const bool live = e < n;
-        const int p = pn;
-        pn = e + nslot < n ? list[e + nslot] : 0;
-        const int y = p / W, x = p - y * W;
-        const uint32_t pb = (uint32_t)(y * pitch + x + gx); // the target in the padded map
-        int ho = ITP_NO_HIT;   // linear offset of the hit in the padded map
-        bool walking = live;
+    const int nr = (n + 3) & ~3; // whole waves iterate together (4 pixels per wave and target set)
+    int pn[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) pn[k] = slot + k * nslot < n ? list[slot + k * nslot] : 0;
+    for (int e0 = slot; e0 < nr; e0 += K * nslot) {
+        bool live[K], walking[K];
+        int p[K], m[K], ho[K];
+        uint32_t pb[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int e = e0 + k * nslot;
+            live[k] = e < n;
+            p[k] = pn[k];
+            pn[k] = e + K * nslot < n ? list[e + K * nslot] : 0;
+            const int y = p[k] / W, x = p[k] - y * W;
+            pb[k] = (uint32_t)(y * pitch + x + gx); // the target in the padded map
+            ho[k] = ITP_NO_HIT;                      // linear offset of the hit in the padded map
+            walking[k] = live[k];
+        }
         // the ray's own step counter: next step to evaluate; the target's own code = the steps proven empty around it (a listed
         // pixel is invalid and inside the image)
-        int m = 1 + (int)code[pb];
-        itp_trip<ITP_NS1>(lt, code, pb, s, max_search, walking, m, ho);
-#if ITP_NS3
-        if (__any(walking && m < max_search)) itp_trip<ITP_NS2>(lt, code, pb, s, max_search, walking, m, ho);
-        while (__any(walking && m < max_search)) itp_trip<ITP_NS3>(lt, code, pb, s, max_search, walking, m, ho); // (few rays are left: long trips)
-#else
-        while (__any(walking && m < max_search)) itp_trip<ITP_NS2>(lt, code, pb, s, max_search, walking, m, ho);
-#endif
+#pragma unroll
+        for (int k = 0; k < K; k++) m[k] = 1 + (int)code[pb[k]];
+        itp_trips<ITP_NS1, K>(lt, code, pb, s, max_search, walking, m, ho);
+        while (true) {
+            bool more = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) more = more || (walking[k] && m[k] < max_search);
+            if (!__any(more)) break;
+            itp_trips<ITP_NS2, K>(lt, code, pb, s, max_search, walking, m, ho);
+        }
         // the hit: ho = dy * pitch + dx with 0 <= dy and |dx| < gx <= pitch / 2, so dy = (ho + gx) / pitch -- by a float reciprocal
         // and one correction step (ho + gx < 2^24: exact in float; the quotient is off by at most one) -- and its value from the map
-        const bool found = ho != ITP_NO_HIT;
-        const int a = found ? ho + gx : 0;
-        int dy = (int)((float)a * rcp_pitch);
-        const int r = a - dy * pitch;
-        dy += (r >= pitch ? 1 : 0) - (r < 0 ? 1 : 0);
-        const int hitq = found ? p + dy * W + (ho - dy * pitch) : p;
-        const float hv = dmap[hitq];
-        const float hit = found ? hv : ADC_INVALID_FLOAT; // first valid disparity along this ray
-        // combine the 16 rays of this pixel (lanes with equal lane&3)
-        float best;
-        bool any;
-        if (mismatch) { // colour-nearest, first minimum in ray order (multistep_refiner.cpp:276-289; min_dist starts at 9999)
-            const int dist = packed_l1(bgr[p], bgr[hitq]); // <= 765 < 9999
-            int key = hit != ADC_INVALID_FLOAT ? dist * 16 + s : 0x7fffffff;
-            float val = hit;
+        int hitq[K];
+        float hv[K];
+        uint32_t c_own[K], c_hit[K];
 #pragma unroll
-            for (int msk = 32; msk >= 4; msk >>= 1) {
-                const int ok = __shfl_xor(key, msk, 64);
-                const float ov = __shfl_xor(val, msk, 64);
-                if (ok < key) { key = ok; val = ov; }
-            }
-            any = key != 0x7fffffff;
-            best = any ? val : 0.0f;
-        } else { // smallest disparity (multistep_refiner.cpp:290-296)
-            float val = hit;
-#pragma unroll
-            for (int msk = 32; msk >= 4; msk >>= 1) {
-                const float ov = __shfl_xor(val, msk, 64);
-                val = ov < val ? ov : val;
-            }
-            any = val != ADC_INVALID_FLOAT;
-            best = val;
+        for (int k = 0; k < K; k++) {
+            const bool found = ho[k] != ITP_NO_HIT;
+            const int a = found ? ho[k] + gx : 0;
+            int dy = (int)((float)a * rcp_pitch);
+            const int r = a - dy * pitch;
+            dy += (r >= pitch ? 1 : 0) - (r < 0 ? 1 : 0);
+            hitq[k] = found ? p[k] + dy * W + (ho[k] - dy * pitch) : p[k];
+            hv[k] = dmap[hitq[k]];
+            if (mismatch) { c_own[k] = bgr[p[k]]; c_hit[k] = bgr[hitq[k]]; }
         }
-        if (live && s == 0) dmap[p] = any ? best : 0.0f; // the fill, in place; no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const float hit = ho[k] != ITP_NO_HIT ? hv[k] : ADC_INVALID_FLOAT; // first valid disparity along this ray
+            // combine the 16 rays of this pixel (lanes with equal lane&3)
+            float best;
+            bool any;
+            if (mismatch) { // colour-nearest, first minimum in ray order (multistep_refiner.cpp:276-289; min_dist starts at 9999)
+                const int dist = packed_l1(c_own[k], c_hit[k]); // <= 765 < 9999
+                int key = hit != ADC_INVALID_FLOAT ? dist * 16 + s : 0x7fffffff;
+                float val = hit;
+#pragma unroll
+                for (int msk = 32; msk >= 4; msk >>= 1) {
+                    const int ok = __shfl_xor(key, msk, 64);
+                    const float ov = __shfl_xor(val, msk, 64);
+                    if (ok < key) { key = ok; val = ov; }
+                }
+                any = key != 0x7fffffff;
+                best = any ? val : 0.0f;
+            } else { // smallest disparity (multistep_refiner.cpp:290-296)
+                float val = hit;
+#pragma unroll
+                for (int msk = 32; msk >= 4; msk >>= 1) {
+                    const float ov = __shfl_xor(val, msk, 64);
+                    val = ov < val ? ov : val;
+                }
+                any = val != ADC_INVALID_FLOAT;
+                best = val;
+            }
+            if (live[k] && s == 0) dmap[p[k]] = any ? best : 0.0f; // the fill, in place; no ray hit: value-initialised fill (multistep_refiner.cpp:246,270-272)
+        }
     }
 }
 
