@@ -227,6 +227,19 @@ ADC_HD int adc_itp_code_rows(int H, int ms) { return H + ms; }
 static_assert((ADC_ITP_CAP + 1 - 1) * ADC_ITP_CELL - 1 < ADC_ITP_OUTSIDE && ADC_ITP_NS + (ADC_ITP_CAP * ADC_ITP_CELL - 1) + ADC_ITP_NS <= ADC_ITP_LPAD,
               "skip codes stay below the end codes; the table padding covers a trip behind the largest skip");
 
+// ---- K11 median, column segments (k_refine.hip; CPU emulation: tests/emul/emul.cpp) ----
+// First column of segment s of nseg (multiples of 16; s <= 0 -> 0, s >= nseg -> W).  Segment 0 starts at the true left border: its
+// chain links stand 128 columns further right per link and cannot start before their rows do, so it runs `lead` = 128 * run-in bands
+// levels where the other segments run `warm` levels of warm-up -- it is made narrower by the difference (shift) so that all waves run
+// about the same number of levels.
+ADC_HD int adc_med_seg_x(int W, int nseg, int s, int shift)
+{
+    if (s <= 0 || nseg <= 1) return s <= 0 ? 0 : W;
+    if (s >= nseg) return W;
+    const long long x = ((long long)(W + shift) * s / nseg - shift) & ~15LL;
+    return (int)(x < 16 ? 16 : (x > W ? W : x));
+}
+
 // ---- WTA sub-pixel (ADCensusStereo.cpp:227-240) ----
 ADC_HD float adc_subpixel(int best, float c1, float c2, float cmin)
 {

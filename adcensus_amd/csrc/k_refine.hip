@@ -818,7 +818,7 @@ typedef float medb_v2f __attribute__((ext_vector_type(2)));
 template <bool PAIRS>
 __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __restrict__ in, float* __restrict__ out, int W, int H,
                                                              int* progress, int* error_word, float* hand, int hpitch, int nbands, int spec,
-                                                             float* sinks, int nseg, int warm, float* seam)
+                                                             float* sinks, int nseg, int warm, float* seam, int seg_shift)
 {
     const int tid = threadIdx.x;
     if constexpr (!PAIRS) nseg = 1; // (the one-column form runs whole rows: everything below folds to the whole-row code)
@@ -836,8 +836,7 @@ __global__ __launch_bounds__(MEDB_ROWS) void k_median_banded(const float* __rest
     // hand-off row this wave reads: the link before it / for a real band the last link of its chain, or the real band above (same segment)
     const int upslot = (is_spec ? link - 1 : (spec ? nbands + medb_chain_off(band, spec) + medb_chain_depth(band, spec) - 1 : band - 1)) * nseg + seg;
     // the segment's columns, and the real band at the end of this wave's chain
-    const int xs = nseg > 1 ? ((int)((long long)W * seg / nseg) & ~15) : 0;
-    const int xe = (nseg > 1 && seg + 1 < nseg) ? ((int)((long long)W * (seg + 1) / nseg) & ~15) : W;
+    const int xs = adc_med_seg_x(W, nseg, seg, seg_shift), xe = adc_med_seg_x(W, nseg, seg + 1, seg_shift);
     const int chain_first = (is_spec ? ct : band) * MEDB_ROWS;
     const int chain_lastband = is_spec ? ct : band;
     const int chain_ylast = adc_imin((chain_lastband + 1) * MEDB_ROWS, H) - 1;
@@ -1110,7 +1109,7 @@ _Pragma("unroll")                                                               
 //   column seams  (nseg > 1) the column xs - 1 a real segment s >= 1 reached in its warm-up must equal the map (segment s - 1 wrote it)
 // Whole rows (nseg = 1): the first is round 4's check of the speculative bands (bands 1 .. spec compare a row with itself).
 __global__ __launch_bounds__(256) void k_median_seg_check(const float* __restrict__ hand, int hpitch, int nbands, int spec, int nseg, int W, int H,
-                                                          const float* __restrict__ out, const float* __restrict__ seam, int* error_word)
+                                                          const float* __restrict__ out, const float* __restrict__ seam, int* error_word, int seg_shift)
 {
     const int b = (int)blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1122,8 +1121,7 @@ __global__ __launch_bounds__(256) void k_median_seg_check(const float* __restric
             const int up = spec ? nbands + medb_chain_off(b, spec) + medb_chain_depth(b, spec) - 1 : b - 1;
             const uint32_t want = reinterpret_cast<const uint32_t*>(out)[(size_t)(yf - 1) * W + c];
             for (int sgm = 0; sgm < nseg; sgm++) {
-                const int xs = nseg > 1 ? ((int)((long long)W * sgm / nseg) & ~15) : 0;
-                const int xe = (nseg > 1 && sgm + 1 < nseg) ? ((int)((long long)W * (sgm + 1) / nseg) & ~15) : W;
+                const int xs = adc_med_seg_x(W, nseg, sgm, seg_shift), xe = adc_med_seg_x(W, nseg, sgm + 1, seg_shift);
                 if (c >= xs - 1 && c <= xe) bad = bad || reinterpret_cast<const uint32_t*>(hand)[(size_t)(up * nseg + sgm) * hpitch + MEDB_HPAD + t] != want;
             }
         }
@@ -1131,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_median_seg_check(const float* __restric
         const int j = i - ((W + 255) & ~255); // column seams: (segment, row of the band)
         const int sgm = j / MEDB_ROWS, r = j - sgm * MEDB_ROWS;
         if (j >= 0 && sgm >= 1 && sgm < nseg && yf + r < H) {
-            const int xs = (int)((long long)W * sgm / nseg) & ~15;
+            const int xs = adc_med_seg_x(W, nseg, sgm, seg_shift);
             bad = reinterpret_cast<const uint32_t*>(seam)[((size_t)(b * nseg + sgm) * MEDB_ROWS + r) * 2 + 1] !=
                   reinterpret_cast<const uint32_t*>(out)[(size_t)(yf + r) * W + xs - 1];
         }
@@ -1173,13 +1171,24 @@ static int median_warm()
     static const int v = [] { const char* e = getenv("ADC_MEDIAN_WARM"); const int w = e ? atoi(e) : 128; return adc_imax(0, adc_imin(w, 1024)) & ~15; }();
     return v;
 }
+// (segment 0 is narrower by `shift` = 128 columns per run-in band minus the warm-up, adc_device_fn.h: adc_med_seg_x; ADC_MEDIAN_SHIFT=0: equal widths)
+static int median_seg_shift(int spec)
+{
+    static const int env = [] { const char* e = getenv("ADC_MEDIAN_SHIFT"); return e ? atoi(e) : -1; }();
+    return env >= 0 ? (env & ~15) : adc_imax(0, 2 * MEDB_ROWS * spec - median_warm());
+}
 static int median_segments(int W, int spec)
 {
     static const int env = [] { const char* e = getenv("ADC_MEDIAN_SEG"); return e ? atoi(e) : 0; }();
     if (!spec || (W & 1)) return 1; // (the chained form and odd widths run whole rows)
-    int n = env > 0 ? env : W / 240; // 1080p: 8 segments of 240 columns, KITTI size: 5
+    int n = env > 0 ? env : (W + median_seg_shift(spec)) / 256; // 1080p: 128 + 7 x 256 columns, KITTI size: 5 segments
     n = adc_imax(1, adc_imin(n, MEDB_MAX_SEG));
-    while (n > 1 && ((W / n) & ~15) < 64) n--; // (every segment at least 64 columns wide)
+    while (n > 1) { // (every segment at least 64 columns wide)
+        bool ok = true;
+        for (int s = 0; s < n; s++) ok = ok && adc_med_seg_x(W, n, s + 1, median_seg_shift(spec)) - adc_med_seg_x(W, n, s, median_seg_shift(spec)) >= 64;
+        if (ok) break;
+        n--;
+    }
     return n;
 }
 size_t adc_median_hand_rows(int H) { return (size_t)(5 * ((H + 63) / 64) + 1) * MEDB_MAX_SEG; } // bands + chains of <= 4 copies per band, per segment
@@ -1210,13 +1219,13 @@ static hipError_t launch_median_banded(adc_handle* h, const float* in, float* ou
     const int nseg_run = pairs ? nseg : 1;
     if (pairs)
         hipLaunchKernelGGL(k_median_banded<true>, dim3(nlinks * nseg_run), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
-                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink, nseg_run, median_warm(), seam);
+                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink, nseg_run, median_warm(), seam, median_seg_shift(spec));
     else
         hipLaunchKernelGGL(k_median_banded<false>, dim3(nlinks), dim3(MEDB_ROWS), 0, h->stream, in, out, p.W, p.H, prog, prog + 260,
-                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink, 1, 0, seam);
+                           h->med_hand, h->med_hpitch, nbands, spec, h->med_sink, 1, 0, seam, 0);
     if (spec)
         hipLaunchKernelGGL(k_median_seg_check, dim3((p.W + 255) / 256 + (MEDB_ROWS * nseg_run + 255) / 256, nbands), dim3(256), 0, h->stream, h->med_hand,
-                           h->med_hpitch, nbands, spec, nseg_run, p.W, p.H, out, seam, prog + 260);
+                           h->med_hpitch, nbands, spec, nseg_run, p.W, p.H, out, seam, prog + 260, median_seg_shift(spec));
     h->med_spec_last = spec;
     if (h->pin_flags) hipMemcpyAsync(h->pin_flags, prog + 260, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream); // checked by adc_wait
     return hipGetLastError();

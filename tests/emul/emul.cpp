@@ -1339,7 +1339,7 @@ static void emul_median_link(const float* raw, const float* above /* W values of
         }
     }
 }
-long emul_median_spec_segments(const float* raw, float* out, int W, int H, int rows, int depth, int nseg, int warm, long* nan_reads)
+long emul_median_spec_segments(const float* raw, float* out, int W, int H, int rows, int depth, int nseg, int warm, long* nan_reads, int seg_shift)
 {
     const int nb = (H + rows - 1) / rows;
     long fails = 0;
@@ -1349,7 +1349,7 @@ long emul_median_spec_segments(const float* raw, float* out, int W, int H, int r
     for (int b = 0; b < nb; b++) {
         const int y0 = b * rows, y1 = std::min(H, y0 + rows);
         for (int s = 0; s < nseg; s++) {
-            const int xs = (int)((long)W * s / nseg) & ~15, xe = s + 1 == nseg ? W : ((int)((long)W * (s + 1) / nseg) & ~15);
+            const int xs = adc_med_seg_x(W, nseg, s, seg_shift), xe = adc_med_seg_x(W, nseg, s + 1, seg_shift);
             std::vector<float> up; // hand-off row the real link consumes
             // the window of the chain of band b: every link runs it (its own last row decides when xe == W: the true right border)
             auto window = [&](int link_ylast, int* ts, int* te) {
@@ -1381,7 +1381,7 @@ long emul_median_spec_segments(const float* raw, float* out, int W, int H, int r
     for (int b = 0; b < nb; b++) {
         const int y0 = b * rows, y1 = std::min(H, y0 + rows);
         for (int s = 0; s < nseg; s++) {
-            const int xs = (int)((long)W * s / nseg) & ~15, xe = s + 1 == nseg ? W : ((int)((long)W * (s + 1) / nseg) & ~15);
+            const int xs = adc_med_seg_x(W, nseg, s, seg_shift), xe = adc_med_seg_x(W, nseg, s + 1, seg_shift);
             bool bad = false;
             if (b >= 1)
                 for (int c = std::max(xs - 1, 0); c <= std::min(xe, W - 1); c++)

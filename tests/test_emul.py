@@ -522,7 +522,8 @@ def test_median_speculative_segments(emul, port_oracle, kind, w, h, d, seed, row
     raw, out = np.ascontiguousarray(o["disp_after_interp"]), np.empty((h, w), np.float32)
     emul.emul_median_spec_segments.restype = C.c_long
     nan_reads = C.c_long(-1)
-    fails = emul.emul_median_spec_segments(P(raw), P(out), w, h, rows, depth, nseg, warm, C.byref(nan_reads))
+    shift = max(0, 2 * rows * depth - warm) & ~15 if (seed % 2) else 0  # (segment 0 narrower, as the launcher does, or equal widths)
+    fails = emul.emul_median_spec_segments(P(raw), P(out), w, h, rows, depth, nseg, warm, C.byref(nan_reads), shift)
     assert nan_reads.value == 0
     if fails == 0:
         assert same(out, o["disp_final"])
