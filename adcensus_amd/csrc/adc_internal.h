@@ -136,6 +136,8 @@ struct adc_handle {
     float* med_sink;      // banded median: 16-byte store sink per lane of every wave (bands + speculative copies)
     int med_spec_off;     // > 0: the banded median runs in its chained form (a speculative seam failed; counts down per Match)
     int med_spec_last;    // the last banded launch used speculative bands
+    int med_seg_last;     // ... and this many column segments per band link
+    int med_seg_off;      // > 0: whole rows (a seam failed while column segments were on; counts down per Match)
     int med_spec_fails;   // how often adc_wait had to redo the median because a speculative seam differed
     int force_median_fallback; // test hook (ADC_DEBUG_FORCE_MEDIAN_FALLBACK via adc_debug_run): adc_wait takes the fallback path
     int median_fallbacks;      // how often adc_wait had to redo the median

@@ -705,6 +705,7 @@ int adc_wait(adc_handle* h)
     }
     h->force_median_fallback = 0;
     if (h->med_spec_off > 0 && h->med_spec_last == 0) h->med_spec_off--;
+    else if (h->med_seg_off > 0 && h->med_seg_last <= 1) h->med_seg_off--; // (whole rows again because a segment seam had failed)
     if (h->async_dst) {
         if (h->async_dst_direct == 2) {
             if (ADC_HIP(hipMemcpy(h->async_dst, h->disp_l, (size_t)h->p.W * h->p.H * 4, hipMemcpyDeviceToHost)) != hipSuccess) { set_error("adc_wait: copy-out", hipGetLastError()); abort_match(h); return 2; }
@@ -1069,6 +1070,7 @@ int64_t adc_debug_counter(adc_handle* h, int which)
     case 12: return h->agg_dual;      // > 0: the next Match enqueues both plans
     case 13: return h->agg_so_fusions; // Matches whose last aggregation pass ran inside the first scanline pass
     case 14: return h->irv_xcd_mode;   // the voting chain sweeps band -> XCD (the mapping was probed on this device)
+    case 15: return h->med_seg_last;   // column segments per band link of the last banded median launch (1: whole rows)
     case 3: return h->irv_budget;
     case 7: return h->med_spec_fails;
     case 8: return h->med_spec_last;

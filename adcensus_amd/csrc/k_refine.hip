@@ -1205,7 +1205,7 @@ static hipError_t launch_median_banded(adc_handle* h, const float* in, float* ou
     if ((in != h->disp_l && in != h->disp_tmp) || (out != h->disp_l && out != h->disp_tmp) || in == out) return hipErrorInvalidValue;
     const int nbands = (p.H + MEDB_ROWS - 1) / MEDB_ROWS;
     const int ncopies = spec ? medb_chain_off(nbands, spec) : 0; // a chain of min(b, spec) copies per target band b = 1 .. nbands - 1
-    const int nseg = median_segments(p.W, spec), nlinks = nbands + ncopies;
+    const int nseg = h->med_seg_off > 0 ? 1 : median_segments(p.W, spec), nlinks = nbands + ncopies;
     if ((size_t)nlinks * nseg + 1 > adc_median_hand_rows(p.H)) return hipErrorInvalidValue;
     // error word + store sinks live in vote_counters[160..]: prog[260] error word, prog[262..267] sinks of idle lanes;
     // the hand-off rows are reset to the "not written yet" sentinel (all ones) before every launch
@@ -1227,6 +1227,7 @@ static hipError_t launch_median_banded(adc_handle* h, const float* in, float* ou
         hipLaunchKernelGGL(k_median_seg_check, dim3((p.W + 255) / 256 + (MEDB_ROWS * nseg_run + 255) / 256, nbands), dim3(256), 0, h->stream, h->med_hand,
                            h->med_hpitch, nbands, spec, nseg_run, p.W, p.H, out, seam, prog + 260, median_seg_shift(spec));
     h->med_spec_last = spec;
+    h->med_seg_last = spec ? nseg_run : 1;
     if (h->pin_flags) hipMemcpyAsync(h->pin_flags, prog + 260, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream); // checked by adc_wait
     return hipGetLastError();
 }
@@ -1265,9 +1266,18 @@ hipError_t adc_median_fallback(adc_handle* h)
 {
     hipError_t e;
     if (h->med_spec_last && h->pin_flags && (h->pin_flags[0] == 2 || h->force_median_fallback == 2) && h->force_median_fallback != 1) {
-        // a speculative seam differed: the chained form of the banded kernel needs no assumption (and may itself report a
-        // time-out, then the single-workgroup kernel below runs); whole bands for the next Matches of the handle
+        // a speculative seam differed.  With column segments on, the speculative bands alone (whole rows: round 4's form, which has run
+        // on every pair since) come first -- segments stay off for the next 64 Matches of the handle; if that fails too, or no segments
+        // were on, the chained form of the banded kernel, which needs no assumption (and may itself report a time-out, then the
+        // single-workgroup kernel below runs), and whole chained bands for the next 64 Matches.
         h->med_spec_fails++;
+        if (h->med_seg_last > 1 && h->force_median_fallback != 2) {
+            h->med_seg_off = 64;
+            e = launch_median_banded(h, h->disp_tmp, h->disp_l, h->med_spec_last); // (med_seg_off: whole rows)
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) return e;
+            if (h->pin_flags[0] == 0) return hipSuccess;
+        }
         h->med_spec_off = 64;
         e = launch_median_banded(h, h->disp_tmp, h->disp_l, 0);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);

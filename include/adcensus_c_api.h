@@ -249,7 +249,8 @@ int adc_debug_run(adc_handle* h, int stage, int arg);
  * aggregation was enqueued as two plans (the device chose), 11 -> redos that restarted at the aggregation, 12 -> Matches for which
  * both plans will still be enqueued, 13 -> Matches whose last aggregation pass ran inside the first scanline pass (the fused tail of
  * short-arm images, k_scanline_seg_agg), 14 -> the voting chain's band -> XCD sweep is in use (0: the device's workgroup -> XCD
- * mapping is not the assumed round-robin, plain schedule).  ADC_RUN_REGION_VOTING of adc_debug_run takes the budget of that run as `arg` (0 = keep;
+ * mapping is not the assumed round-robin, plain schedule), 15 -> column segments per band link of the last banded median launch (1:
+ * whole rows -- odd widths, the chained form, or a segment seam failed within the last 64 Matches).  ADC_RUN_REGION_VOTING of adc_debug_run takes the budget of that run as `arg` (0 = keep;
  * arg < 0: run nothing, set the budget of the NEXT Match's chain to -arg). */
 int64_t adc_debug_counter(adc_handle* h, int which);
 /* Statistics of the last region-voting run: rounds of the fixed-point iteration (all ten passes of the reference iterate at
