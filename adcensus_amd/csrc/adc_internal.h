@@ -150,7 +150,6 @@ struct adc_handle {
     int irv_xcd_mode;    // 1: the chain's work list uses the band -> XCD sweep layout (the device's workgroup -> XCD mapping was probed)
     int irv_grid;        // workgroups of the voting chain (adc_irv_grid, fixed per handle: the work-list layout depends on it)
     int irv_budget;      // kernels the next Match enqueues for the voting chain (adapted from the last Matches)
-    int irv_full_until;  // > 0: kernels of the next chain from this index on run with one wave per workgroup (the budget's margin: k_voting.hip)
     int irv_used_hist[8]; // kernels the last 8 Matches needed
     unsigned irv_used_pos;
     int irv_chain;       // kernels of the chain enqueued so far (continuation starts here)

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 8), amd
     IRV_TR(8);
     IRV_T(0);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, WPB = blockDim.x >> 6, T = blockDim.x; // (wave: uniform, kept in a scalar register)
-    const int gw = blockIdx.x * IRV_MAXW + wave, NW = gridDim.x * IRV_MAXW; // (statistics slots: the same for every workgroup shape of a chain)
+    const int gw = blockIdx.x * WPB + wave, NW = gridDim.x * WPB;
     // Everything the first phase of a ROUND needs is known at launch time: this wave's entries of batch 0, and -- the change
     // tiles being stamped and double-buffered by KERNEL index -- which plane and which stamp to look for.  So the entry,
     // state and tile loads are issued before the chain state (written by another XCD's workgroup 0 of the previous kernel:
@@ -678,11 +678,7 @@ static int irv_use_slack()
     return v;
 }
 size_t adc_irv_px_words(int W, int H) { return (size_t)IRV_PX_PLANES * irv_px_pitch(W) * H + 16; }
-// slim_from: kernels of the chain from this index on are launched with ONE wave per workgroup.  The budget's margin behind the longest
-// chain of the last Matches is almost always surplus: a no-op of 1024 x 8 waves costs 4.6 us, of 1024 x 1 wave 2.7 us (measured,
-// tools/r6c_noop.sh).  The kernel is the same for every workgroup shape (its waves pool the dirty entries of the workgroup's segment),
-// so a slim kernel that does find work runs its round -- slower, and exact (tests: the whole chain slim).
-static hipError_t irv_launch(adc_handle* h, int k0, int count, int slim_from = 0x7fffffff)
+static hipError_t irv_launch(adc_handle* h, int k0, int count)
 {
     if (k0 == 0) { // the block of rarely used arguments of this chain (stream-ordered: in front of the chain's first kernel).  Staged in
         // PINNED memory: a copy from pageable host memory is synchronous inside the runtime (+0.19 ms per Match, measured)
@@ -706,16 +702,14 @@ static hipError_t irv_launch(adc_handle* h, int k0, int count, int slim_from = 0
     }
     const AdcParams& p = h->p;
     const int tpitch = h->chg_pitch, chg_bytes = tpitch * ((p.H + IRV_TILE - 1) / IRV_TILE);
-    const int wpb_full = irv_wpb(p.D);
-    for (int i = 0; i < count; i++) {
-        const int wpb = k0 + i >= slim_from ? 1 : wpb_full;
-        const size_t lds = (size_t)((wpb * IRV_LEVELS * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
+    const int wpb = irv_wpb(p.D);
+    const size_t lds = (size_t)((wpb * IRV_LEVELS * p.D + 3) & ~3) * 4 + (size_t)wpb * 64 * 16;
+    for (int i = 0; i < count; i++)
         hipLaunchKernelGGL(k_irv_u, dim3((unsigned)h->irv_grid), dim3(64 * wpb), lds, h->stream, h->vote_counters, k0 + i,
                            reinterpret_cast<const IrvCold*>(h->irv_cold), h->st16, reinterpret_cast<int4*>(h->vote_list), h->chg_a,
                            reinterpret_cast<const uint32_t*>(h->arms), p.W, p.H, h->st16_pitch, p.dmin, p.D, chg_bytes, tpitch, p.opt.irv_ts, p.opt.irv_th,
-                           h->vote_evals_arr, (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb_full, h->irv_xcd_mode), h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
+                           h->vote_evals_arr, (int)irv_seg_cap(p.W, p.H, h->irv_grid, wpb, h->irv_xcd_mode), h->vote_evals_arr + (size_t)IRV_MAXW * h->irv_grid,
                            h->irv_px, irv_px_pitch(p.W), irv_use_slack());
-    }
     return hipGetLastError();
 }
 
@@ -727,11 +721,7 @@ hipError_t adc_run_region_voting(adc_handle* h)
     hipError_t e;
     if ((e = hipMemsetAsync(h->vote_counters, 0, IRV_CTRL_INTS * sizeof(int32_t), h->stream)) != hipSuccess) return e;
     if (h->irv_budget < 4) h->irv_budget = 4;
-    // (ADC_IRV_SLIM=0: every kernel with the full workgroup shape; ADC_IRV_SLIM_FROM=k: slim from kernel k on, whatever the history says -- tests)
-    static const int slim_env = [] { const char* ev = getenv("ADC_IRV_SLIM"); return ev ? atoi(ev) : 1; }();
-    static const int slim_from_env = [] { const char* ev = getenv("ADC_IRV_SLIM_FROM"); return ev ? atoi(ev) : -1; }();
-    const int slim_from = !slim_env ? 0x7fffffff : (slim_from_env >= 0 ? slim_from_env : (h->irv_full_until > 0 ? h->irv_full_until : 0x7fffffff));
-    if ((e = irv_launch(h, 0, h->irv_budget, slim_from)) != hipSuccess) return e;
+    if ((e = irv_launch(h, 0, h->irv_budget)) != hipSuccess) return e;
     h->irv_chain = h->irv_budget;
     // the state the last kernel published (slot chain & 1), read by adc_wait / adc_voting_finish
     if (h->pin_flags)
@@ -780,6 +770,5 @@ hipError_t adc_voting_finish(adc_handle* h, int* continued)
     // (an EMPTY work list -- BEGIN, then DONE: no round whose count could vary -- needs no margin beyond the floor of 4 kernels:
     // two surplus kernels less per Match of a noise-like stream, 10 us)
     h->irv_budget = fixed > 0 ? fixed : (longest <= 2 ? 4 : adc_imin(1 << 16, longest + adc_imax(2 * longest / 5, 2) + 2));
-    h->irv_full_until = longest + 2; // the kernels behind the longest chain of the last Matches (the budget's margin) run slim (irv_launch)
     return hipSuccess;
 }

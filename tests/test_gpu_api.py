@@ -219,40 +219,6 @@ def test_median_column_segments(hip, env, expect_failures):
         assert fails == 0, out.stdout[-1500:]
 
 
-@pytest.mark.parametrize("env", [{"ADC_IRV_SLIM_FROM": "0"}, {"ADC_IRV_SLIM_FROM": "2"}, {"ADC_IRV_SLIM_FROM": "9"}, {"ADC_IRV_SLIM": "0"}])
-def test_voting_chain_slim_kernels(hip, env):
-    """Round 6: the kernels of the voting chain behind the longest chain of the last Matches (the budget's margin) are launched with ONE
-    wave per workgroup -- a no-op of that shape costs 2.7 us instead of 4.6.  The kernel is the same for every workgroup shape; here
-    the shape changes at kernel 0 (BEGIN, list building, every round and the write-back run slim), at kernel 2 (every round) and in the
-    middle of the heavy rounds: whole Match (three times per handle: the budget adapts) and the stage-isolated voting must equal the
-    oracle bit for bit.  Own interpreter per variant (the switch is read once)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "import numpy as np\n"
-            "import adcensus_amd as A\n"
-            "from adcensus_amd import workloads\n"
-            "from tests import cases\n"
-            "from oracle import pyoracle\n"
-            "bad = {}\n"
-            "for kind, w, h, d, seed in (('structured', 320, 200, 32, 31), ('structured', 517, 133, 64, 32), ('noise', 200, 150, 16, 33), ('structured', 96, 420, 16, 34)):\n"
-            "    l, r = workloads.structured_pair(w, h, d, seed=seed) if kind == 'structured' else workloads.noise_pair(w, h, seed=seed)\n"
-            "    opt = pyoracle.Option(max_disparity=d)\n"
-            "    o = pyoracle.load('auto').run(l, r, opt, stages=['disp_final'])\n"
-            "    st = A.ADCensusStereo(device=0)\n"
-            "    assert st.Initialize(w, h, cases.to_product_option(opt))\n"
-            "    for rep in range(3):\n"
-            "        if not np.array_equal(st.match(l, r).view(np.uint32), o['disp_final'].view(np.uint32)): bad[(kind, w, h, 'match', rep)] = 1\n"
-            "    print(kind, w, h, 'rounds / evaluations', st.voting_stats(), 'budget', st.debug_counter(3), 'continuations', st.debug_counter(1))\n"
-            "    st.Release()\n"
-            "print('FAILING', bad)\n"
-            "sys.exit(1 if bad else 0)\n") % root
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-
-
 def test_async_pipeline_assumptions_and_budgets(hip, oracle, monkeypatch):
     """Match never waits for the device in mid-pipeline: the aggregation ASSUMES the arm maxima of the previous Match of the
     handle and the voting chain has a launch BUDGET adapted from the previous Match.  Both are verified / completed by
