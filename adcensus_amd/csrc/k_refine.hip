@@ -530,7 +530,8 @@ hipError_t adc_launch_interpolation(adc_handle* h)
     const int P = p.W * p.H;
     const int dmaxa = p.dmax < 0 ? -p.dmax : p.dmax, dmina = p.dmin < 0 ? -p.dmin : p.dmin;
     const int max_search = dmaxa > dmina ? dmaxa : dmina; // multistep_refiner.cpp:236
-    if (h->ray_tab && max_search == h->ray_tab_rows && max_search == h->itp_ms && (size_t)h->itp_ms * (size_t)h->itp_pitch < ((size_t)1 << 24)) { // (linear offsets exact in float: see the kernel)
+    if (h->ray_tab && max_search == h->ray_tab_rows && max_search == h->itp_ms && (size_t)h->itp_ms * (size_t)h->itp_pitch < ((size_t)1 << 24) && // (linear offsets exact in float: see the kernel)
+        (size_t)h->itp_pitch * (size_t)adc_itp_code_rows(p.H, h->itp_ms) < ((size_t)1 << 31)) { // (32-bit positions in the padded map)
         // Round 6: ONE list pass, ONE set of map launches for both passes, fills written IN PLACE.  The reference computes the fill
         // values of a whole list from the UNCHANGED map and writes them back afterwards (fill_disps, multistep_refiner.cpp:246-303); a
         // walk here never reads the map at a pixel its own pass writes: it tests the CODE map (a snapshot) and fetches map values only at
