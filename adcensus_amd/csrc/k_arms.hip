@@ -17,30 +17,52 @@ __global__ __launch_bounds__(256) void k_pack_bgr(const uint8_t* __restrict__ im
 }
 
 // One arm from (x,y) along (dx,dy): rules of cross_aggregator.cpp:151-198.
-__device__ __forceinline__ int arm_length(const uint32_t* __restrict__ img, int W, int H, int x, int y, int dx, int dy,
-                                          int L1, int L2, int t1, int t2)
+// (The colour distance max(|dB|, |dG|, |dR|) on packed pixels: each channel masked out once per pixel, then ONE v_sad_u8 per channel and
+// a v_max3 -- the search is bound by its vector-ALU instructions (2 273 per wave on the structured 1080p pair, SQ counters), and the
+// byte-extract / subtract / abs form cost three times as many per distance.  Same integers: adc_color_dist_max_u32 is the definition.)
+struct ArmPix { uint32_t b, g, r; };
+__device__ __forceinline__ ArmPix arm_pix(uint32_t c) { return ArmPix{c & 0x000000FFu, c & 0x0000FF00u, c & 0x00FF0000u}; }
+__device__ __forceinline__ int arm_dist(const ArmPix& a, const ArmPix& b)
 {
-    const uint32_t c0 = img[(size_t)y * W + x];
-    uint32_t cl = c0;
-    int len = 0;
-    int xn = x + dx, yn = y + dy;
-    const int nmax = adc_imin(L1, 255); // MAX_ARM_LENGTH, cross_aggregator.h:22
-    for (int n = 0; n < nmax; n++) {
-        if (xn < 0 || xn >= W || yn < 0 || yn >= H) break;
-        const uint32_t c = img[(size_t)yn * W + xn];
-        const int d1 = adc_color_dist_max_u32(c, c0);
-        if (d1 >= t1) break;
-        if (n > 0) {
-            const int d2 = adc_color_dist_max_u32(c, cl);
-            if (d2 >= t1) break;
+    const uint32_t d0 = __builtin_amdgcn_sad_u8(a.b, b.b, 0u), d1 = __builtin_amdgcn_sad_u8(a.g, b.g, 0u), d2 = __builtin_amdgcn_sad_u8(a.r, b.r, 0u);
+    return (int)(d2 > d1 ? (d2 > d0 ? d2 : d0) : (d1 > d0 ? d1 : d0));
+}
+// The four arms of a pixel in ONE branch-free loop (round 6, second session): the rules of cross_aggregator.cpp:151-198
+// per step n = 0, 1, ... of an arm -- the pixel must lie inside the image, d1 = dist(pixel, anchor) < t1, from the second step on d2 =
+// dist(pixel, previous pixel) < t1, and beyond L2 steps d1 < t2 -- as predicates: `room` (steps that stay inside the image) folds the
+// bounds test into the step limit, a lane whose arm has ended stays where it is (its loads hit the same line), and the wave leaves the
+// loop when no arm of its 64 pixels is alive.  The loop-with-four-breaks form spent more scalar instructions on execution masks (2 725
+// per wave) than vector instructions on pixels (2 273), once per direction; here the four directions' loads are in flight together.
+__device__ __forceinline__ uchar4 arm_lengths(const uint32_t* __restrict__ img, int W, int H, int x, int y, int L1, int L2, int t1, int t2)
+{
+    const int p = y * W + x;
+    const int lim = adc_imin(L1, 255); // MAX_ARM_LENGTH, cross_aggregator.h:22
+    const int step[4] = {-1, +1, -W, +W};                       // left, right, top, bottom
+    const int nmax[4] = {adc_imin(lim, x), adc_imin(lim, W - 1 - x), adc_imin(lim, y), adc_imin(lim, H - 1 - y)};
+    const ArmPix c0 = arm_pix(img[p]);
+    ArmPix cl[4] = {c0, c0, c0, c0};
+    int q[4] = {p, p, p, p}, len[4] = {0, 0, 0, 0};
+    bool alive[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) alive[k] = nmax[k] > 0;
+    for (int n = 0; __any(alive[0] || alive[1] || alive[2] || alive[3]); n++) {
+        ArmPix c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            q[k] += alive[k] ? step[k] : 0;
+            c[k] = arm_pix(img[q[k]]);
         }
-        if (n + 1 > L2 && d1 >= t2) break;
-        len++;
-        cl = c;
-        xn += dx;
-        yn += dy;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int d1 = arm_dist(c[k], c0), d2 = arm_dist(c[k], cl[k]);
+            const bool ok = d1 < t1 && (n == 0 || d2 < t1) && !(n + 1 > L2 && d1 >= t2);
+            alive[k] = alive[k] && ok;
+            len[k] += alive[k] ? 1 : 0;
+            cl[k] = c[k];
+            alive[k] = alive[k] && n + 1 < nmax[k];
+        }
     }
-    return len;
+    return make_uchar4((unsigned char)len[0], (unsigned char)len[1], (unsigned char)len[2], (unsigned char)len[3]);
 }
 
 __global__ __launch_bounds__(256) void k_build_arms(const uint32_t* __restrict__ img_l, uchar4* __restrict__ arms, int W,
@@ -53,10 +75,7 @@ __global__ __launch_bounds__(256) void k_build_arms(const uint32_t* __restrict__
     __syncthreads();
     uchar4 a = make_uchar4(0, 0, 0, 0);
     if (x < W && y < H) {
-    a.x = (uint8_t)arm_length(img_l, W, H, x, y, -1, 0, L1, L2, t1, t2); // left
-    a.y = (uint8_t)arm_length(img_l, W, H, x, y, +1, 0, L1, L2, t1, t2); // right
-    a.z = (uint8_t)arm_length(img_l, W, H, x, y, 0, -1, L1, L2, t1, t2); // top
-    a.w = (uint8_t)arm_length(img_l, W, H, x, y, 0, +1, L1, L2, t1, t2); // bottom
+    a = arm_lengths(img_l, W, H, x, y, L1, L2, t1, t2); // {left, right, top, bottom}
     arms[(size_t)y * W + x] = a;
     }
     // image-wide maximum arm per direction (lets the aggregation pick its window depth from the data)
