@@ -219,6 +219,7 @@ hipError_t adc_paper_aggregate(adc_handle* h, int iterations);  // k_paper.hip: 
 hipError_t adc_paper_accumulate(adc_handle* h, float* acc, const float* src, int first, int last);
 hipError_t adc_launch_lrcheck(adc_handle* h);
 size_t adc_itp_cell_bytes(int W, int H, int ms);
+#define ADC_MEDB_MAX_SEG 12                    // column segments per band link of the median, at most (k_refine.hip; sizes the hand-off / sink / seam buffers)
 size_t adc_median_hand_rows(int H);             // hand-off rows / store-sink blocks of the banded median (k_refine.hip)       // byte maps of the interpolation's empty-space skipping (k_refine.hip)
 int adc_irv_probe_xcd_mode(int device);         // 1 iff workgroup g of a launch runs on XCD g % 8 on this device (probed once)
 int adc_irv_grid(size_t pixels);                // workgroups of the voting chain for an image of this size

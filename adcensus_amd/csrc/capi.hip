@@ -124,7 +124,7 @@ static hipError_t alloc_all(adc_handle* h)
     HIP_OK(hipMalloc(&h->cost_lrec, P * 16));
     h->med_hpitch = ((p.W + 2 * p.H + 64 + 15) / 16) * 16;
     HIP_OK(hipMalloc(&h->med_hand, adc_median_hand_rows(p.H) * h->med_hpitch * sizeof(float))); // (bands + chains of <= 4 speculative copies per band, per column segment)
-    HIP_OK(hipMalloc(&h->med_sink, adc_median_hand_rows(p.H) * 64 * 16 + (size_t)((p.H + 63) / 64) * 8 * 64 * 8 + 64)); // store sinks, then the segments' seam columns
+    HIP_OK(hipMalloc(&h->med_sink, adc_median_hand_rows(p.H) * 64 * 16 + (size_t)((p.H + 63) / 64) * ADC_MEDB_MAX_SEG * 64 * 8 + 64)); // store sinks, then the segments' seam columns
     HIP_OK(hipMalloc(&h->gray_r, P));
     HIP_OK(hipMalloc(&h->census_l, P * 8));
     HIP_OK(hipMalloc(&h->census_r, P * 8));

@@ -1166,7 +1166,7 @@ static hipError_t launch_median_wavefront(adc_handle* h, const float* in, float*
 
 // Segments per band link of the speculative form: a segment should be well above its 128 columns of warm-up, and the chip takes
 // (bands + copies) x segments single-wave workgroups side by side.  ADC_MEDIAN_SEG overrides (1 = whole rows), ADC_MEDIAN_WARM the warm-up.
-#define MEDB_MAX_SEG 8
+#define MEDB_MAX_SEG ADC_MEDB_MAX_SEG
 static int median_warm()
 {
     static const int v = [] { const char* e = getenv("ADC_MEDIAN_WARM"); const int w = e ? atoi(e) : 128; return adc_imax(0, adc_imin(w, 1024)) & ~15; }();
@@ -1182,7 +1182,8 @@ static int median_segments(int W, int spec)
 {
     static const int env = [] { const char* e = getenv("ADC_MEDIAN_SEG"); return e ? atoi(e) : 0; }();
     if (!spec || (W & 1)) return 1; // (the chained form and odd widths run whole rows)
-    int n = env > 0 ? env : (W + median_seg_shift(spec)) / 256; // 1080p: 128 + 7 x 256 columns, KITTI size: 5 segments
+    // (segments of ~170 columns, 10 at most: 1080p 8 / 10 / 12 segments -> refine 0.518 / 0.510 / 0.513 ms, KITTI size 5 / 8 / 10 -> 0.267 / 0.256 / 0.256)
+    int n = env > 0 ? env : adc_imin((W + median_seg_shift(spec)) / 170, 10); // 1080p: 10 segments, KITTI size: 8
     n = adc_imax(1, adc_imin(n, MEDB_MAX_SEG));
     while (n > 1) { // (every segment at least 64 columns wide)
         bool ok = true;
